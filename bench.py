@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Benchmark of the Chebyshev graph-convolution forward (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward of the layer over one batch of synthetic maps already resident in HBM
+(headline workload: nside=1024 full sphere, K=5, Fin=Fout=64, batch 4, fp32).  Prints ONE JSON
+line on rank 0: throughput in Mpix*channels/s (= N*M*Fout / t), the HBM-roofline figures of the
+kernel(s) of one forward measured with HIP events, and a CPU baseline (the oracle's fp32 port
+of the reference op sequence on a bounded sample, host cores counted).
+
+With N > 1 the map is sharded over the ranks by contiguous NEST pixel ranges (base pixels and
+their quarters) and the (K-1)-ring halo of x is exchanged over RCCL inside every timed step:
+strong scaling on the fixed headline map.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "deepsphere-cosmo-tf2_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (nside, K, Fin, Fout, batch)  -- BASELINE.json configs[0..2]
+    "c1": (64, 5, 1, 16, 1),
+    "c2": (256, 5, 16, 32, 8),
+    "c3": (1024, 5, 64, 64, 4),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(N, M, Fin, Fout, K, W_ell, bias=False):
+    """x once + y once + L~ (int32 col + fp32 val, padded ELL) once + weights."""
+    return 4 * N * M * Fin + 4 * N * M * Fout + 8 * W_ell * M + 4 * K * Fin * Fout + (4 * Fout if bias else 0)
+
+
+def build_laplacian(nside, device):
+    """Full-sphere 8-neighbour normalised Laplacian, rescaled like Chebyshev.__init__: ELL arrays."""
+    from deepsphere import _native, healpix, utils
+
+    cols_t, vals_t = healpix.grid_laplacian_ell_torch(nside, device=device)
+    cols = cols_t.cpu().numpy()
+    plan_L = _native.LaplacianPlan(cols, vals_t.to(torch.float32).cpu().numpy(), device=device.index)
+    lam = utils.lanczos_lmax(plan_L, iters=64)
+    plan_L.close()
+    lmax = 1.02 * lam
+    vals = utils.rescale_ell(cols_t, vals_t, lmax=lmax, scale=0.75).cpu().numpy()
+    return cols, vals, lmax
+
+
+def cpu_baseline(K, Fin, Fout, device, budget_s):
+    """The oracle's fp32 port of the reference op sequence on nside=256, one map (1/64 of the
+    headline pixel-batch), all host cores."""
+    from scipy import sparse
+
+    from oracle import cheb_cpu_baseline as cb
+
+    nside_s, N_s = 256, 1
+    cols, vals, _ = build_laplacian(nside_s, device)
+    M = cols.shape[0]
+    Wd = cols.shape[1]
+    Lt = sparse.csr_matrix((vals.reshape(-1), cols.reshape(-1), np.arange(0, Wd * M + 1, Wd)), shape=(M, M))
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((N_s, M, Fin), dtype=np.float32)
+    w = (np.random.default_rng(13).standard_normal((Fin * K, Fout)) / np.sqrt(Fin * (K + 0.5) / 2)).astype(np.float32)
+    cores = os.cpu_count() or 1
+    res = cb.time_forward(Lt, x, w, K, budget_s=budget_s, threads=cores)
+    value = N_s * M * Fout / res["seconds"] / 1e6
+    return {
+        "value": round(value, 3),
+        "unit": "Mpix*channels/s",
+        "cores": int(res["threads"]),
+        "kind": "port",
+        "sample": f"nside={nside_s} full-sphere, batch={N_s}, K={K}, Fin={Fin}, Fout={Fout} "
+                  f"(1/64 of the headline pixel-batch); torch-CPU fp32 port of gnn_layers.py:131-150, "
+                  f"median of {res['reps']} forwards, {res['seconds'] * 1e3:.0f} ms each",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "unfused", "fused"])
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline; 0 disables it")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from deepsphere import gnn_layers
+
+    nside, K, Fin, Fout, N = CONFIGS[args.config]
+    t0 = time.time()
+    cols, vals, lmax = build_laplacian(nside, device)
+    M, W_ell = cols.shape
+    w_np = (np.random.default_rng(13).standard_normal((Fin * K, Fout)) / np.sqrt(Fin * (K + 0.5) / 2)).astype(np.float32)
+
+    if world == 1:
+        layer = gnn_layers.Chebyshev.from_prepared_ell(
+            cols, vals, K, lmax=lmax, Fout=Fout, device=device, precision=args.precision, algo=args.algo,
+            initializer=lambda t: t.copy_(torch.from_numpy(w_np)),
+        )
+        gen = torch.Generator(device=device).manual_seed(11)
+        x = torch.randn((N, M, Fin), device=device, generator=gen)
+        run = lambda: layer(x)  # noqa: E731
+        fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
+        kernel_name = "cheb_fused_kernel" if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
+    else:
+        from deepsphere import sharding
+
+        shard = sharding.ShardedChebyshev(cols, vals, K, Fout=Fout, rank=rank, world=world, device=device,
+                                          precision=args.precision, algo=args.algo, kernel=w_np)
+        gen = torch.Generator(device=device).manual_seed(11 + rank)
+        x = torch.randn((N, shard.own_rows, Fin), device=device, generator=gen)
+        run = lambda: shard(x)  # noqa: E731
+        fused = shard.fused
+        kernel_name = ("cheb_fused_kernel" if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \
+            " + halo exchange"
+    setup_s = time.time() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t_start = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        run()
+        b.record()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    per_fwd_ms = [a.elapsed_time(b) for a, b in ev]  # HIP events on the stream the kernels run on
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = N * M * Fout / (elapsed / args.steps) / 1e6
+
+    if rank == 0:
+        b_alg = algorithmic_bytes(N, M // world if world > 1 else M, Fin, Fout, K, W_ell)
+        dev_ms = float(np.mean(per_fwd_ms))
+        achieved = b_alg / (dev_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                rec = json.load(open(tpath))
+                key = f"{args.config}:{args.precision}:{'fused' if fused else 'unfused'}:{world}"
+                traffic = rec.get(key, {}).get("hbm_bytes_per_forward")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpix*channels/s Chebyshev-conv fwd, nside=1024 K=5 F=64; HBM roofline %",
+            "value": round(value, 2),
+            "unit": "Mpix*channels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f32 (contraction: 3-pass split-bf16 MFMA, f32 accumulate)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"nside={nside} full-sphere, K={K}, Fin={Fin}, Fout={Fout}, batch={N} ({args.config})",
+                "pixels": M,
+                "ell_width": W_ell,
+                "graph": "8-neighbour HEALPix grid stencil, normalised Laplacian, lmax by 64-step Lanczos",
+                "algo": "fused" if fused else "unfused",
+                "sharding": "none" if world == 1 else f"{world} contiguous NEST ranges, (K-1)-ring halo of x per step",
+                "setup_s": round(setup_s, 1),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": kernel_name,
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes": b_alg,
+                "avg_forward_ms_hip_events": round(dev_ms, 4),
+            },
+        }
+        if world == 1 and args.cpu_budget > 0:
+            out["cpu_baseline"] = cpu_baseline(K, Fin, Fout, device, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,246 @@
+// C ABI of include/dsphere.h: plan management and the host-side sequencing of the kernels.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "dsphere_common.h"
+
+namespace dsph {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return DSPH_E_HIP;
+}
+
+// RAII device switch: plans may live on a device other than the caller's current one.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int64_t step_rows(const dsph_plan* p, int K, int k) {
+  // rows on which recurrence step k (1..K-1) must be valid
+  if (p->levels.empty()) return p->n_rows;
+  const int lvl = K - 1 - k;
+  const int last = (int)p->levels.size() - 1;
+  return p->levels[lvl < last ? lvl : last];
+}
+
+static int64_t out_rows(const dsph_plan* p) { return p->levels.empty() ? p->n_rows : p->levels[0]; }
+
+}  // namespace dsph
+
+using namespace dsph;
+
+extern "C" {
+
+int dsph_abi_version(void) { return DSPH_ABI_VERSION; }
+
+const char* dsph_last_error(void) { return g_err; }
+
+int dsph_plan_create(dsph_plan** out, int64_t n_rows, int64_t n_cols, int32_t ell_width,
+                     const int32_t* cols, const float* vals, int device) {
+  if (!out) { set_error("plan_create: out is NULL"); return DSPH_E_BADARG; }
+  *out = nullptr;
+  if (n_rows <= 0 || n_cols < n_rows || ell_width <= 0 || !cols || !vals) {
+    set_error("plan_create: bad shape n_rows=%lld n_cols=%lld width=%d or NULL arrays",
+              (long long)n_rows, (long long)n_cols, (int)ell_width);
+    return DSPH_E_BADARG;
+  }
+  if (n_cols > 0x7fffffffLL) {
+    set_error("plan_create: n_cols=%lld exceeds int32 column indices", (long long)n_cols);
+    return DSPH_E_UNSUPPORTED;
+  }
+  const int64_t nnz = n_rows * (int64_t)ell_width;
+  for (int64_t i = 0; i < nnz; ++i) {
+    if (cols[i] < 0 || (int64_t)cols[i] >= n_cols) {
+      set_error("plan_create: column %d at row %lld slot %lld outside [0, %lld)", (int)cols[i],
+                (long long)(i / ell_width), (long long)(i % ell_width), (long long)n_cols);
+      return DSPH_E_BADARG;
+    }
+  }
+  int ndev = 0;
+  DSPH_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) {
+    set_error("plan_create: device %d not in [0, %d)", device, ndev);
+    return DSPH_E_BADARG;
+  }
+  DeviceGuard guard(device);
+  if (!guard.ok) { set_error("plan_create: cannot select device %d", device); return DSPH_E_HIP; }
+  dsph_plan* p = new (std::nothrow) dsph_plan();
+  if (!p) { set_error("plan_create: out of host memory"); return DSPH_E_BADARG; }
+  p->device = device;
+  p->n_rows = n_rows;
+  p->n_cols = n_cols;
+  p->width = ell_width;
+  hipError_t e = hipMalloc((void**)&p->d_cols, (size_t)nnz * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_vals, (size_t)nnz * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(p->d_cols, cols, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->d_vals, vals, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    dsph_plan_destroy(p);
+    return hip_fail(e, "plan_create upload");
+  }
+  p->fused = fused_plan_build(p, cols, vals);  // may be NULL: graph not tileable
+  *out = p;
+  return DSPH_OK;
+}
+
+void dsph_plan_destroy(dsph_plan* p) {
+  if (!p) return;
+  DeviceGuard guard(p->device);
+  if (p->fused) fused_plan_destroy(p->fused);
+  if (p->d_cols) (void)hipFree(p->d_cols);
+  if (p->d_vals) (void)hipFree(p->d_vals);
+  delete p;
+}
+
+int dsph_plan_set_levels(dsph_plan* p, int32_t n_levels, const int64_t* rows_at_level) {
+  if (!p || n_levels <= 0 || !rows_at_level) { set_error("set_levels: bad arguments"); return DSPH_E_BADARG; }
+  int64_t prev = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    if (rows_at_level[i] < prev || rows_at_level[i] > p->n_rows || rows_at_level[i] <= 0) {
+      set_error("set_levels: level %d = %lld not in non-decreasing (0, %lld]", i,
+                (long long)rows_at_level[i], (long long)p->n_rows);
+      return DSPH_E_BADARG;
+    }
+    prev = rows_at_level[i];
+  }
+  p->levels.assign(rows_at_level, rows_at_level + n_levels);
+  return DSPH_OK;
+}
+
+int64_t dsph_plan_rows(const dsph_plan* p) { return p ? p->n_rows : 0; }
+int64_t dsph_plan_cols(const dsph_plan* p) { return p ? p->n_cols : 0; }
+int32_t dsph_plan_ell_width(const dsph_plan* p) { return p ? p->width : 0; }
+int64_t dsph_plan_out_rows(const dsph_plan* p, int32_t K) { (void)K; return p ? out_rows(p) : 0; }
+
+int dsph_plan_fused_ok(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K) {
+  return (p && fused_supported(p, Fin, Fout, K)) ? 1 : 0;
+}
+
+static int resolve_algo(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo) {
+  if (algo == DSPH_ALGO_UNFUSED) return DSPH_ALGO_UNFUSED;
+  if (fused_supported(p, Fin, Fout, K)) return DSPH_ALGO_FUSED;
+  return algo == DSPH_ALGO_FUSED ? -1 : DSPH_ALGO_UNFUSED;
+}
+
+size_t dsph_workspace_bytes(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
+                            int32_t precision, int32_t algo) {
+  if (!p || N <= 0 || Fin <= 0 || K <= 0) return 0;
+  const int a = resolve_algo(p, Fin, Fout, K, algo);
+  if (a == DSPH_ALGO_FUSED) return fused_workspace_bytes(p, N, Fin, Fout, K, precision);
+  // unfused: planes 1..K-1, each (N, n_cols, Fin) fp32, 256-byte aligned
+  const size_t plane = align_up((size_t)N * (size_t)p->n_cols * (size_t)Fin * sizeof(float), 256);
+  return plane * (size_t)(K > 1 ? K - 1 : 0);
+}
+
+int dsph_cheb_step(const dsph_plan* p, const float* in, const float* prev, float* out, int64_t N,
+                   int32_t F, float alpha, float beta, int64_t rows, void* hip_stream) {
+  if (!p || !in || !out || N < 0 || F <= 0) { set_error("cheb_step: bad arguments"); return DSPH_E_BADARG; }
+  if (rows <= 0) rows = p->n_rows;
+  if (rows > p->n_rows) { set_error("cheb_step: rows %lld > plan rows %lld", (long long)rows, (long long)p->n_rows); return DSPH_E_BADARG; }
+  DeviceGuard guard(p->device);
+  return launch_cheb_step(p, in, p->n_cols, prev, p->n_cols, out, p->n_cols, N, F, alpha, beta,
+                          rows, (hipStream_t)hip_stream);
+}
+
+int dsph_cheb_contract(const float* const* planes, int64_t plane_rows, const float* w,
+                       const float* bias, float* y, int64_t N, int64_t rows, int32_t Fin,
+                       int32_t Fout, int32_t K, int32_t act, int32_t precision, int device,
+                       void* hip_stream) {
+  if (!planes || !w || !y || N < 0 || rows < 0 || rows > plane_rows || Fin <= 0 || Fout <= 0 || K <= 0) {
+    set_error("cheb_contract: bad arguments");
+    return DSPH_E_BADARG;
+  }
+  for (int k = 0; k < K; ++k)
+    if (!planes[k]) { set_error("cheb_contract: plane %d is NULL", k); return DSPH_E_BADARG; }
+  DeviceGuard guard(device);
+  return launch_cheb_contract(planes, plane_rows, w, bias, y, N, rows, Fin, Fout, K, act, precision,
+                              (hipStream_t)hip_stream);
+}
+
+int dsph_cheb_forward(const dsph_plan* p, const float* x, const float* w, const float* bias,
+                      float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
+                      int32_t precision, int32_t algo, void* workspace, size_t workspace_bytes,
+                      void* hip_stream) {
+  if (!p || !x || !w || !y || N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) {
+    set_error("cheb_forward: bad arguments (NULL pointer or non-positive size)");
+    return DSPH_E_BADARG;
+  }
+  if (act < DSPH_ACT_NONE || act > DSPH_ACT_TANH) { set_error("cheb_forward: unknown activation %d", act); return DSPH_E_BADARG; }
+  if (precision != DSPH_PREC_FP32 && precision != DSPH_PREC_BF16X3) { set_error("cheb_forward: unknown precision %d", precision); return DSPH_E_BADARG; }
+  if (!p->levels.empty() && (int)p->levels.size() < K) {
+    set_error("cheb_forward: plan has %d levels, K = %d needs %d", (int)p->levels.size(), K, K);
+    return DSPH_E_BADARG;
+  }
+  if (N == 0) return DSPH_OK;
+  const int a = resolve_algo(p, Fin, Fout, K, algo);
+  if (a < 0) { set_error("cheb_forward: fused kernel cannot run this plan/shape (Fin=%d Fout=%d K=%d)", Fin, Fout, K); return DSPH_E_UNSUPPORTED; }
+  const size_t need = dsph_workspace_bytes(p, N, Fin, Fout, K, precision, a);
+  if (need > 0 && (!workspace || workspace_bytes < need)) {
+    set_error("cheb_forward: workspace %zu bytes, need %zu", workspace_bytes, need);
+    return DSPH_E_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  DeviceGuard guard(p->device);
+  if (a == DSPH_ALGO_FUSED)
+    return launch_cheb_fused(p, x, w, bias, y, N, Fin, Fout, K, act, precision, workspace,
+                             workspace_bytes, stream);
+
+  // ---- unfused: K-1 SpMM launches into workspace planes, then one contraction ---------------
+  if (K > 64) { set_error("cheb_forward: K = %d exceeds 64", K); return DSPH_E_UNSUPPORTED; }
+  const size_t plane = align_up((size_t)N * (size_t)p->n_cols * (size_t)Fin * sizeof(float), 256);
+  const float* planes[64];
+  planes[0] = x;
+  for (int k = 1; k < K; ++k)
+    planes[k] = reinterpret_cast<const float*>(static_cast<char*>(workspace) + plane * (size_t)(k - 1));
+  for (int k = 1; k < K; ++k) {
+    float* outp = const_cast<float*>(planes[k]);
+    const int64_t rows = step_rows(p, K, k);
+    int rc;
+    if (k == 1)
+      rc = launch_cheb_step(p, planes[0], p->n_cols, nullptr, p->n_cols, outp, p->n_cols, N, Fin, 1.f, 0.f, rows, stream);
+    else
+      rc = launch_cheb_step(p, planes[k - 1], p->n_cols, planes[k - 2], p->n_cols, outp, p->n_cols, N, Fin, 2.f, 1.f, rows, stream);
+    if (rc != DSPH_OK) return rc;
+  }
+  return launch_cheb_contract(planes, p->n_cols, w, bias, y, N, out_rows(p), Fin, Fout, K, act,
+                              precision, stream);
+}
+
+int dsph_rows_pack(const float* src, int64_t src_rows, const int32_t* idx, int64_t n_idx,
+                   float* buf, int64_t N, int32_t F, int device, void* hip_stream) {
+  if (!src || !idx || !buf || n_idx < 0 || N < 0 || F <= 0) { set_error("rows_pack: bad arguments"); return DSPH_E_BADARG; }
+  DeviceGuard guard(device);
+  return launch_rows_pack(src, src_rows, idx, n_idx, buf, N, F, false, (hipStream_t)hip_stream);
+}
+
+int dsph_rows_unpack(float* dst, int64_t dst_rows, const int32_t* idx, int64_t n_idx,
+                     const float* buf, int64_t N, int32_t F, int device, void* hip_stream) {
+  if (!dst || !idx || !buf || n_idx < 0 || N < 0 || F <= 0) { set_error("rows_unpack: bad arguments"); return DSPH_E_BADARG; }
+  DeviceGuard guard(device);
+  return launch_rows_pack(dst, dst_rows, idx, n_idx, const_cast<float*>(buf), N, F, true, (hipStream_t)hip_stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// Internal declarations shared by the HIP translation units behind include/dsphere.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "dsphere.h"
+
+namespace dsph {
+
+// thread-local error text returned by dsph_last_error()
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define DSPH_HIP(call)                                           \
+  do {                                                           \
+    hipError_t e__ = (call);                                     \
+    if (e__ != hipSuccess) return ::dsph::hip_fail(e__, #call);  \
+  } while (0)
+
+struct FusedPlan;  // tile decomposition for the single-launch kernel (cheb_fused.hip)
+
+}  // namespace dsph
+
+// The opaque plan of the C ABI: the rescaled Laplacian in padded ELL form, resident in HBM.
+struct dsph_plan {
+  int device = 0;
+  int64_t n_rows = 0;   // rows of L~ (one ELL row each)
+  int64_t n_cols = 0;   // length of the vectors L~ multiplies (>= n_rows; tail = halo rows)
+  int32_t width = 0;    // ELL width W
+  int32_t* d_cols = nullptr;  // [n_rows][W] row-major (wave-uniform row reads)
+  float* d_vals = nullptr;    // [n_rows][W]
+  std::vector<int64_t> levels;  // optional shrinking schedule, see dsph_plan_set_levels
+  dsph::FusedPlan* fused = nullptr;
+};
+
+namespace dsph {
+
+// out[n,m,:] = alpha * sum_j vals[m,j] * in[n, cols[m,j], :] - beta * prev[n,m,:],  m < rows
+int launch_cheb_step(const dsph_plan* plan, const float* in, int64_t in_rows, const float* prev,
+                     int64_t prev_rows, float* out, int64_t out_rows, int64_t N, int32_t F,
+                     float alpha, float beta, int64_t rows, hipStream_t stream);
+
+int launch_cheb_contract(const float* const* planes, int64_t plane_rows, const float* w,
+                         const float* bias, float* y, int64_t N, int64_t rows, int32_t Fin,
+                         int32_t Fout, int32_t K, int32_t act, int32_t precision,
+                         hipStream_t stream);
+
+int launch_rows_pack(const float* src, int64_t src_rows, const int32_t* idx, int64_t n_idx,
+                     float* buf, int64_t N, int32_t F, bool unpack, hipStream_t stream);
+
+// fused path (cheb_fused.hip)
+FusedPlan* fused_plan_build(const dsph_plan* plan, const int32_t* h_cols, const float* h_vals);
+void fused_plan_destroy(FusedPlan* fp);
+bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
+int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
+                      float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
+                      int32_t precision, void* workspace, size_t workspace_bytes,
+                      hipStream_t stream);
+size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
+                             int32_t precision);
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case DSPH_ACT_RELU: return v > 0.f ? v : 0.f;
+    case DSPH_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    case DSPH_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case DSPH_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Give every XCD one
+// contiguous range of tiles so that neighbouring pixel rows -- which gather each other's data --
+// share an L2.  Bijective for any grid size.  Speed only; never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, i = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+}  // namespace dsph

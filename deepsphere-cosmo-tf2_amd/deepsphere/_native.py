@@ -1,0 +1,268 @@
+"""ctypes binding of ``libdsphere_hip.so`` (the C ABI declared in ``include/dsphere.h``).
+
+There is no CPU fallback: if the shared library is missing, or a forward is requested
+without a HIP device, this module raises.  Build the library with
+``make -C deepsphere-cosmo-tf2_amd/csrc`` (or ``__graft_entry__.build()``).
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libdsphere_hip.so")
+_lib = None
+
+OK = 0
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+PREC_FP32, PREC_BF16X3 = 0, 1
+ALGO_AUTO, ALGO_UNFUSED, ALGO_FUSED = 0, 1, 2
+
+_c_i64 = ctypes.c_int64
+_c_i32 = ctypes.c_int32
+_c_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); one entry per function declared in include/dsphere.h
+SIGNATURES = {
+    "dsph_abi_version": (ctypes.c_int, []),
+    "dsph_last_error": (ctypes.c_char_p, []),
+    "dsph_plan_create": (ctypes.c_int, [ctypes.POINTER(_c_vp), _c_i64, _c_i64, _c_i32, _c_vp, _c_vp, ctypes.c_int]),
+    "dsph_plan_destroy": (None, [_c_vp]),
+    "dsph_plan_set_levels": (ctypes.c_int, [_c_vp, _c_i32, _c_vp]),
+    "dsph_plan_rows": (_c_i64, [_c_vp]),
+    "dsph_plan_cols": (_c_i64, [_c_vp]),
+    "dsph_plan_ell_width": (_c_i32, [_c_vp]),
+    "dsph_plan_out_rows": (_c_i64, [_c_vp, _c_i32]),
+    "dsph_plan_fused_ok": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
+    "dsph_workspace_bytes": (ctypes.c_size_t, [_c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32]),
+    "dsph_cheb_forward": (
+        ctypes.c_int,
+        [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp,
+         ctypes.c_size_t, _c_vp],
+    ),
+    "dsph_cheb_step": (
+        ctypes.c_int,
+        [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i32, ctypes.c_float, ctypes.c_float, _c_i64, _c_vp],
+    ),
+    "dsph_cheb_contract": (
+        ctypes.c_int,
+        [_c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, ctypes.c_int,
+         _c_vp],
+    ),
+    "dsph_rows_pack": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_i64, _c_i32, ctypes.c_int, _c_vp]),
+    "dsph_rows_unpack": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_i64, _c_i32, ctypes.c_int, _c_vp]),
+}
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def lib():
+    """The loaded library; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"HIP library not found at {_LIB_PATH}: build it with "
+                "`make -C deepsphere-cosmo-tf2_amd/csrc` (there is no CPU fallback)"
+            )
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.dsph_abi_version() != 1:
+            raise RuntimeError("libdsphere_hip.so has an unexpected ABI version")
+        _lib = handle
+    return _lib
+
+
+def last_error():
+    msg = lib().dsph_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, what):
+    if rc == OK:
+        return
+    msg = f"{what} failed ({rc}): {last_error()}"
+    if rc == -1:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def require_gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "the Chebyshev forward runs only on a HIP device (MI355X); no GPU is visible and there is no CPU fallback"
+        )
+
+
+class LaplacianPlan:
+    """Owner of one ``dsph_plan``: the rescaled Laplacian, padded ELL, resident on one GPU."""
+
+    def __init__(self, ell_cols, ell_vals, n_cols=None, device=0, levels=None):
+        cols = np.ascontiguousarray(ell_cols, dtype=np.int32)
+        vals = np.ascontiguousarray(ell_vals, dtype=np.float32)
+        if cols.ndim != 2 or cols.shape != vals.shape:
+            raise ValueError("ELL cols/vals must be 2-D arrays of equal shape [rows, width]")
+        self.n_rows, self.width = int(cols.shape[0]), int(cols.shape[1])
+        self.n_cols = int(n_cols) if n_cols is not None else self.n_rows
+        self.device = int(device)
+        self._h = _c_vp()
+        require_gpu()
+        rc = lib().dsph_plan_create(
+            ctypes.byref(self._h), self.n_rows, self.n_cols, self.width, cols.ctypes.data, vals.ctypes.data,
+            self.device,
+        )
+        check(rc, "dsph_plan_create")
+        self.levels = None
+        if levels is not None:
+            self.set_levels(levels)
+
+    def set_levels(self, levels):
+        lv = np.ascontiguousarray(levels, dtype=np.int64)
+        check(lib().dsph_plan_set_levels(self._h, int(lv.shape[0]), lv.ctypes.data), "dsph_plan_set_levels")
+        self.levels = lv.copy()
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("plan already destroyed")
+        return self._h
+
+    @property
+    def out_rows(self):
+        return int(lib().dsph_plan_out_rows(self.handle, 1))
+
+    def fused_ok(self, Fin, Fout, K):
+        return bool(lib().dsph_plan_fused_ok(self.handle, int(Fin), int(Fout), int(K)))
+
+    def workspace_bytes(self, N, Fin, Fout, K, precision=PREC_FP32, algo=ALGO_AUTO):
+        return int(lib().dsph_workspace_bytes(self.handle, int(N), int(Fin), int(Fout), int(K), int(precision),
+                                              int(algo)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().dsph_plan_destroy(self._h)
+            self._h = _c_vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _ptr(t):
+    return _c_vp(t.data_ptr()) if t is not None else _c_vp()
+
+
+def _stream_ptr(device):
+    import torch
+
+    return _c_vp(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check_dev(t, plan, name):
+    import torch
+
+    if not t.is_cuda or t.device.index != plan.device:
+        raise ValueError(f"{name} must live on cuda:{plan.device}")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous float32 tensor")
+
+
+def cheb_forward(plan, x, w, bias, K, act=ACT_NONE, precision=PREC_FP32, algo=ALGO_AUTO, workspace=None, out=None):
+    """y = dsph_cheb_forward(...) on torch CUDA tensors; x (N, n_cols, Fin), w (Fin*K, Fout)."""
+    import torch
+
+    _check_dev(x, plan, "x")
+    _check_dev(w, plan, "w")
+    N, rows, Fin = x.shape
+    if rows != plan.n_cols:
+        raise ValueError(f"x has {rows} rows, the plan multiplies vectors of {plan.n_cols} rows")
+    if w.shape[0] != Fin * K:
+        raise ValueError(f"w has {w.shape[0]} rows, expected Fin*K = {Fin * K}")
+    Fout = int(w.shape[1])
+    if bias is not None:
+        _check_dev(bias, plan, "bias")
+        if bias.numel() != Fout:
+            raise ValueError("bias must have Fout elements")
+    need = plan.workspace_bytes(N, Fin, Fout, K, precision, algo)
+    if need > 0 and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    orows = plan.out_rows
+    if out is None:
+        out = torch.empty((N, orows, Fout), dtype=torch.float32, device=x.device)
+    else:
+        _check_dev(out, plan, "out")
+        if tuple(out.shape) != (N, orows, Fout):
+            raise ValueError("out has the wrong shape")
+    rc = lib().dsph_cheb_forward(
+        plan.handle, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), int(N), int(Fin), Fout, int(K), int(act),
+        int(precision), int(algo), _ptr(workspace) if need > 0 else _c_vp(),
+        (workspace.numel() * workspace.element_size()) if need > 0 else 0, _stream_ptr(x.device),
+    )
+    check(rc, "dsph_cheb_forward")
+    return out, workspace
+
+
+def cheb_step(plan, inp, prev, alpha, beta, rows=0, out=None):
+    """out = alpha * (L~ @ inp) - beta * prev on (N, n_cols, F) planes."""
+    import torch
+
+    _check_dev(inp, plan, "in")
+    N, r, F = inp.shape
+    if r != plan.n_cols:
+        raise ValueError("plane row count must equal the plan's n_cols")
+    if prev is not None:
+        _check_dev(prev, plan, "prev")
+    if out is None:
+        out = torch.zeros_like(inp)
+    rc = lib().dsph_cheb_step(plan.handle, _ptr(inp), _ptr(prev), _ptr(out), int(N), int(F), float(alpha),
+                              float(beta), int(rows), _stream_ptr(inp.device))
+    check(rc, "dsph_cheb_step")
+    return out
+
+
+def cheb_contract(planes, w, bias, rows, K, act=ACT_NONE, precision=PREC_FP32):
+    """Contraction over a list of K (N, plane_rows, Fin) planes -> (N, rows, Fout)."""
+    import torch
+
+    p0 = planes[0]
+    N, plane_rows, Fin = p0.shape
+    Fout = int(w.shape[1])
+    arr = (_c_vp * K)(*[p.data_ptr() for p in planes])
+    out = torch.empty((N, rows, Fout), dtype=torch.float32, device=p0.device)
+    rc = lib().dsph_cheb_contract(ctypes.cast(arr, _c_vp), int(plane_rows), _ptr(w), _ptr(bias), _ptr(out), int(N),
+                                  int(rows), int(Fin), Fout, int(K), int(act), int(precision), p0.device.index,
+                                  _stream_ptr(p0.device))
+    check(rc, "dsph_cheb_contract")
+    return out
+
+
+def rows_pack(src, idx, out=None):
+    """buf[n, i, :] = src[n, idx[i], :]; idx is an int32 CUDA tensor."""
+    import torch
+
+    N, rows, F = src.shape
+    n_idx = int(idx.numel())
+    if out is None:
+        out = torch.empty((N, n_idx, F), dtype=torch.float32, device=src.device)
+    rc = lib().dsph_rows_pack(_ptr(src), int(rows), _ptr(idx), n_idx, _ptr(out), int(N), int(F), src.device.index,
+                              _stream_ptr(src.device))
+    check(rc, "dsph_rows_pack")
+    return out
+
+
+def rows_unpack(dst, idx, buf):
+    """dst[n, idx[i], :] = buf[n, i, :] in place."""
+    N, rows, F = dst.shape
+    rc = lib().dsph_rows_unpack(_ptr(dst), int(rows), _ptr(idx), int(idx.numel()), _ptr(buf), int(N), int(F),
+                                dst.device.index, _stream_ptr(dst.device))
+    check(rc, "dsph_rows_unpack")
+    return dst

@@ -1,0 +1,265 @@
+"""Graph layers: the Chebyshev graph convolution on MI355X.
+
+Host-side mirror of the reference's ``deepsphere.gnn_layers.Chebyshev`` (a Keras ``Model``,
+``/root/reference/src/deepsphere/gnn_layers.py:12-161``) as a ``torch.nn.Module`` with the same
+constructor arguments, lazy weight creation, attribute names, weight layout and error
+behaviour.  The arithmetic is not here: ``forward`` hands device pointers to the C ABI of
+``include/dsphere.h`` (hand-written HIP for gfx950).  Without that library and a GPU the
+forward raises; there is no CPU path in this package.
+"""
+
+import numpy as np
+import torch
+
+from . import _native
+from . import utils
+
+# Activations addressable by name, like ``getattr(tf.keras.activations, name)``
+# (gnn_layers.py:55-60).  Those with a code are fused into the kernel epilogue; the others run
+# as one extra elementwise pass after it.
+_ACT_BY_NAME = {
+    "linear": (None, _native.ACT_NONE),
+    "relu": (torch.relu, _native.ACT_RELU),
+    "elu": (torch.nn.functional.elu, _native.ACT_ELU),
+    "sigmoid": (torch.sigmoid, _native.ACT_SIGMOID),
+    "tanh": (torch.tanh, _native.ACT_TANH),
+    "softplus": (torch.nn.functional.softplus, None),
+    "softsign": (torch.nn.functional.softsign, None),
+    "selu": (torch.selu, None),
+    "gelu": (torch.nn.functional.gelu, None),
+    "swish": (torch.nn.functional.silu, None),
+    "silu": (torch.nn.functional.silu, None),
+    "leaky_relu": (lambda t: torch.nn.functional.leaky_relu(t, 0.2), None),
+    "exponential": (torch.exp, None),
+    "hard_sigmoid": (lambda t: torch.clamp(t / 6.0 + 0.5, 0.0, 1.0), None),
+    "mish": (torch.nn.functional.mish, None),
+    "softmax": (lambda t: torch.softmax(t, dim=-1), None),
+}
+
+_PRECISIONS = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3}
+_ALGOS = {"auto": _native.ALGO_AUTO, "unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}
+
+
+def _resolve_activation(activation):
+    """-> (callable or None, fused code or None).  Unknown names raise ValueError exactly where
+    the reference does (gnn_layers.py:60)."""
+    if activation is None:
+        return None, _native.ACT_NONE
+    if callable(activation):
+        for fn, code in ((torch.relu, _native.ACT_RELU), (torch.nn.functional.relu, _native.ACT_RELU),
+                         (torch.nn.functional.elu, _native.ACT_ELU), (torch.sigmoid, _native.ACT_SIGMOID),
+                         (torch.tanh, _native.ACT_TANH)):
+            if activation is fn:
+                return activation, code
+        return activation, None
+    if isinstance(activation, str) and activation in _ACT_BY_NAME:
+        return _ACT_BY_NAME[activation]
+    raise ValueError(f"Could not find activation <{activation}> in tf.keras.activations...")
+
+
+class Chebyshev(torch.nn.Module):
+    """A graph convolutional layer using the Chebyshev approximation.
+
+    y[n, m, o] = act( BN( sum_f sum_k (T_k(L~) x[n, :, f])[m] * kernel[f*K + k, o] ) + bias[o] )
+    with T_0 = I, T_1 = L~, T_k = 2 L~ T_{k-1} - T_{k-2} and L~ = 1.5/lmax * L - I,
+    lmax = 1.02 * lambda_max(L).
+    """
+
+    def __init__(
+        self,
+        L,
+        K,
+        Fout=None,
+        initializer=None,
+        activation=None,
+        use_bias=False,
+        use_bn=False,
+        n_matmul_splits=1,
+        **kwargs,
+    ):
+        """
+        :param L: graph Laplacian (M x M): scipy sparse matrix or dense array
+        :param K: number of polynomial terms T_0 .. T_{K-1}
+        :param Fout: output channels, defaults to the number of input channels
+        :param initializer: ``None`` (truncated normal, stddev 1/sqrt(Fin*(K+0.5)/2)), or a callable
+            applied in place to the new ``[K*Fin, Fout]`` kernel tensor (``torch.nn.init`` style), or
+            a callable ``shape -> array``
+        :param activation: ``None``, a callable, or a Keras activation name ("linear", "relu", "elu", ...)
+        :param use_bias: add a learnable bias of shape [1, 1, Fout]
+        :param use_bn: batch normalisation (no scale/shift, momentum 0.9, eps 1e-5) before the bias
+        :param n_matmul_splits: accepted for compatibility; the reference needs it only to stay under
+            TensorFlow-GPU's sparse-matmul size limit, the HIP kernel has none
+        :param kwargs: the reference forwards these to ``add_weight`` (regularizer, ...); stored in
+            ``self.kwargs``.  Three keys are consumed here: ``device`` (torch device of the layer,
+            default: current CUDA device), ``precision`` ("fp32" exact | "bf16x3" split-bf16 MFMA
+            contraction) and ``algo`` ("auto" | "unfused" | "fused").
+        """
+        super().__init__()
+        self.L = L
+        self.K = int(K)
+        if self.K < 1:
+            raise ValueError("K must be at least 1")
+        self.Fout = Fout
+        self.use_bias = use_bias
+        self.use_bn = use_bn
+        self.bn = None  # created in build() once Fout is known
+        self.initializer = initializer
+        self.activation, self._act_code = _resolve_activation(activation)
+        self.n_matmul_splits = n_matmul_splits
+        device = kwargs.pop("device", None)
+        precision = kwargs.pop("precision", "fp32")
+        algo = kwargs.pop("algo", "auto")
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        if algo not in _ALGOS:
+            raise ValueError(f"algo must be one of {sorted(_ALGOS)}")
+        self.precision = precision
+        self.algo = algo
+        self.kwargs = kwargs
+        self._device = torch.device(device) if device is not None else None
+
+        # Rescaled Laplacian (host, float64 -> float32), then padded ELL for the kernels.
+        Lt, self.lmax = utils.prepare_L(L, scale=0.75)
+        self._M = Lt.shape[0]
+        self._ell_cols, self._ell_vals = utils.csr_to_ell(Lt)
+        self._nnz = int(Lt.nnz)
+        self._plan = None
+        self._workspace = None
+        self.kernel = None
+        self.bias = None
+        self._built = False
+
+    # -- Keras-style lazy build ---------------------------------------------------------------
+    def build(self, input_shape):
+        """Create the weights for inputs of shape (batch, M, Fin)."""
+        Fin = int(input_shape[-1])
+        Fout = Fin if self.Fout is None else int(self.Fout)
+        dev = self._resolve_device(None)
+        kernel = torch.empty((self.K * Fin, Fout), dtype=torch.float32)
+        if self.initializer is None:
+            stddev = 1.0 / np.sqrt(Fin * (self.K + 0.5) / 2.0)
+            torch.nn.init.trunc_normal_(kernel, mean=0.0, std=stddev, a=-2.0 * stddev, b=2.0 * stddev)
+        else:
+            res = self.initializer(kernel)
+            if res is not None and res is not kernel:
+                kernel = torch.as_tensor(np.asarray(res), dtype=torch.float32).reshape(self.K * Fin, Fout).clone()
+        self.kernel = torch.nn.Parameter(kernel.to(dev))
+        if self.use_bias:
+            # the reference creates the bias without an initializer (gnn_layers.py:104), i.e. the
+            # framework default for add_weight: glorot-uniform on shape [1, 1, Fout]
+            lim = float(np.sqrt(6.0 / (1.0 + Fout)))
+            self.bias = torch.nn.Parameter((torch.rand((1, 1, Fout)) * 2.0 - 1.0).mul_(lim).to(dev))
+        if self.use_bn:
+            # Keras momentum 0.9 == torch momentum 0.1; center=False, scale=False
+            self.bn = torch.nn.BatchNorm1d(Fout, eps=1e-5, momentum=0.1, affine=False).to(dev)
+        self._Fin = Fin
+        self._built = True
+
+    def _resolve_device(self, x):
+        if self._device is None:
+            if x is not None and isinstance(x, torch.Tensor) and x.is_cuda:
+                self._device = x.device
+            elif torch.cuda.is_available():
+                self._device = torch.device("cuda", torch.cuda.current_device())
+            else:
+                self._device = torch.device("cpu")  # weights can be created; forward will refuse
+        return self._device
+
+    def _get_plan(self):
+        if self._plan is None:
+            _native.require_gpu()
+            dev = self._resolve_device(None)
+            if dev.type != "cuda":
+                raise RuntimeError("the Chebyshev forward needs a HIP device; there is no CPU fallback")
+            index = dev.index if dev.index is not None else torch.cuda.current_device()
+            self._device = torch.device("cuda", index)
+            self._plan = _native.LaplacianPlan(self._ell_cols, self._ell_vals, device=index)
+        return self._plan
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward(self, input_tensor, training=None):
+        """
+        :param input_tensor: (batch, M, Fin) tensor or array; cast to float32 like Keras does
+        :param training: batch-norm mode; defaults to the module's ``self.training``
+        :return: (batch, M, Fout) float32 tensor on the layer's device
+        """
+        if not isinstance(input_tensor, torch.Tensor):
+            input_tensor = torch.as_tensor(np.asarray(input_tensor))
+        if input_tensor.dim() != 3:
+            raise ValueError("input must have shape (batch, M, Fin)")
+        N, M, Fin = (int(s) for s in input_tensor.shape)
+        if M != self._M:
+            raise ValueError(f"input has {M} nodes, the Laplacian has {self._M}")
+        self._resolve_device(input_tensor)
+        if not self._built:
+            self.build(input_tensor.shape)
+        if Fin != self._Fin:
+            raise ValueError(f"layer was built for Fin = {self._Fin}, got {Fin}")
+        plan = self._get_plan()
+        x = input_tensor.detach().to(device=self._device, dtype=torch.float32).contiguous()
+        bias = self.bias.detach().reshape(-1).contiguous() if self.use_bias else None
+
+        fuse_epilogue = not self.use_bn
+        act_code = self._act_code if (fuse_epilogue and self._act_code is not None) else _native.ACT_NONE
+        y, self._workspace = _native.cheb_forward(
+            plan, x, self.kernel.detach(), bias if fuse_epilogue else None, self.K, act=act_code,
+            precision=_PRECISIONS[self.precision], algo=_ALGOS[self.algo], workspace=self._workspace,
+        )
+        if self.use_bn:  # BN -> bias -> activation, the reference's order (gnn_layers.py:152-159)
+            was_training = self.bn.training
+            self.bn.train(self.training if training is None else bool(training))
+            y = self.bn(y.transpose(1, 2)).transpose(1, 2).contiguous()
+            self.bn.train(was_training)
+            if bias is not None:
+                y = y + self.bias.detach()
+            if self.activation is not None:
+                y = self.activation(y)
+        elif self.activation is not None and self._act_code is None:
+            y = self.activation(y)
+        return y
+
+    call = forward
+
+    @classmethod
+    def from_prepared_ell(cls, ell_cols, ell_vals, K, lmax=None, **kwargs):
+        """Layer over an already rescaled Laplacian given as padded ELL arrays (cols int32,
+        vals float32, shape [M, W]), skipping the ARPACK eigen-solve of the constructor -- for
+        graphs too large for it (nside >= 512) and for tests that share one prepared L~ between
+        the oracle and the kernels.  Not part of the reference API."""
+        self = cls.__new__(cls)
+        torch.nn.Module.__init__(self)
+        self.L = None
+        self.K = int(K)
+        if self.K < 1:
+            raise ValueError("K must be at least 1")
+        self.Fout = kwargs.pop("Fout", None)
+        self.use_bias = kwargs.pop("use_bias", False)
+        self.use_bn = kwargs.pop("use_bn", False)
+        self.bn = None
+        self.initializer = kwargs.pop("initializer", None)
+        self.activation, self._act_code = _resolve_activation(kwargs.pop("activation", None))
+        self.n_matmul_splits = kwargs.pop("n_matmul_splits", 1)
+        device = kwargs.pop("device", None)
+        self.precision = kwargs.pop("precision", "fp32")
+        self.algo = kwargs.pop("algo", "auto")
+        if self.precision not in _PRECISIONS or self.algo not in _ALGOS:
+            raise ValueError("unknown precision or algo")
+        self.kwargs = kwargs
+        self._device = torch.device(device) if device is not None else None
+        self.lmax = lmax
+        cols = np.ascontiguousarray(ell_cols, dtype=np.int32)
+        vals = np.ascontiguousarray(ell_vals, dtype=np.float32)
+        if cols.ndim != 2 or cols.shape != vals.shape:
+            raise ValueError("ELL arrays must have shape [M, W]")
+        self._M = cols.shape[0]
+        self._ell_cols, self._ell_vals = cols, vals
+        self._nnz = int(np.count_nonzero(vals))
+        self._plan = None
+        self._workspace = None
+        self.kernel = None
+        self.bias = None
+        self._built = False
+        return self
+
+
+__all__ = ["Chebyshev"]

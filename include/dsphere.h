@@ -1,0 +1,134 @@
+/* dsphere.h -- C ABI of the MI355X-native Chebyshev graph-convolution forward.
+ *
+ * Drop-in boundary for ONE path of deepsphere/deepsphere-cosmo-tf2: the forward of
+ * `deepsphere.gnn_layers.Chebyshev` (reference src/deepsphere/gnn_layers.py:106-161) with
+ * its one-time Laplacian upload (gnn_layers.py:64-72).  The reference has no FFI of its
+ * own for this path -- it calls TensorFlow ops from Python -- so every entry point below
+ * names the Python/TF call sites it replaces.  Plain pointers and sizes only; no torch
+ * types.  All device pointers are HIP device memory on the plan's device; the caller
+ * (PyTorch) owns x, w, bias, y and the workspace.  Functions return 0 on success or a
+ * negative DSPH_E_* code; the message is available from dsph_last_error() (thread-local).
+ * Nothing here allocates, frees or synchronises inside dsph_cheb_* (graph-capture safe).
+ */
+#ifndef DSPHERE_H
+#define DSPHERE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSPH_ABI_VERSION 1
+
+/* error codes */
+#define DSPH_OK 0
+#define DSPH_E_BADARG (-1)      /* null pointer, negative size, inconsistent shapes */
+#define DSPH_E_HIP (-2)         /* a HIP runtime call failed */
+#define DSPH_E_UNSUPPORTED (-3) /* shape outside what the kernels implement */
+#define DSPH_E_WORKSPACE (-4)   /* workspace too small */
+
+/* fused epilogue activations (reference: tf.keras.activations looked up by name,
+ * gnn_layers.py:55-60; anything else is applied by the host layer after the call) */
+#define DSPH_ACT_NONE 0
+#define DSPH_ACT_RELU 1
+#define DSPH_ACT_ELU 2
+#define DSPH_ACT_SIGMOID 3
+#define DSPH_ACT_TANH 4
+
+/* arithmetic of the dense [K*Fin]x[Fout] contraction (the recurrence is always fp32) */
+#define DSPH_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain        */
+#define DSPH_PREC_BF16X3 1 /* hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+
+/* which implementation dsph_cheb_forward runs */
+#define DSPH_ALGO_AUTO 0
+#define DSPH_ALGO_UNFUSED 1 /* K-1 ELL SpMM launches into workspace planes + one contraction launch */
+#define DSPH_ALGO_FUSED 2   /* one launch: tile + halo in LDS, planes never leave the CU */
+
+typedef struct dsph_plan dsph_plan;
+
+/* Upload the rescaled Laplacian L~ once.
+ * Replaces: the tf.constant triple built in Chebyshev.__init__ (gnn_layers.py:68-72) and the
+ * per-call tf.SparseTensor + tf.sparse.reorder (gnn_layers.py:114-115).
+ *   n_rows      rows of L~ held by this plan (outputs are produced for rows [0, n_rows))
+ *   n_cols      length of the vectors L~ is applied to; n_cols >= n_rows.  Equal for a whole
+ *               graph; larger for a shard whose trailing n_cols - n_rows entries are halo rows
+ *               received from other shards.
+ *   ell_width   padded row width W (max non-zeros per row, diagonal included)
+ *   cols, vals  HOST arrays [n_rows][ell_width], row-major; padding entries carry val 0 and any
+ *               valid column (conventionally the row itself)
+ *   device      HIP device ordinal
+ */
+int dsph_plan_create(dsph_plan** out, int64_t n_rows, int64_t n_cols, int32_t ell_width,
+                     const int32_t* cols, const float* vals, int device);
+
+void dsph_plan_destroy(dsph_plan* plan);
+
+/* Optional shrinking schedule for a plan whose rows are ordered by graph distance from the
+ * rows it owns (sharded, deep-halo mode): rows_at_level[j] = number of leading rows within j
+ * hops of the owned rows, j = 0..n_levels-1, non-decreasing, rows_at_level[0] = owned rows,
+ * rows_at_level[n_levels-1] <= n_rows.  With a schedule, recurrence step k of a K-term forward
+ * is evaluated on rows_at_level[K-1-k] rows and y is written for rows_at_level[0] rows.
+ * Without one every step covers n_rows rows.  Host array, copied. */
+int dsph_plan_set_levels(dsph_plan* plan, int32_t n_levels, const int64_t* rows_at_level);
+
+int64_t dsph_plan_rows(const dsph_plan* plan);
+int64_t dsph_plan_cols(const dsph_plan* plan);
+int32_t dsph_plan_ell_width(const dsph_plan* plan);
+int64_t dsph_plan_out_rows(const dsph_plan* plan, int32_t K); /* rows y is produced for */
+/* 1 if the fused single-launch kernel can run this (plan, shape); 0 otherwise */
+int dsph_plan_fused_ok(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
+
+/* Bytes of scratch dsph_cheb_forward needs for this call shape (0 is possible). */
+size_t dsph_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout,
+                            int32_t K, int32_t precision, int32_t algo);
+
+/* The whole forward:  y[n,m,o] = act( sum_f sum_k (T_k(L~) x[n,:,f])[m] * w[f*K + k, o] + bias[o] )
+ * Replaces: Chebyshev.call (gnn_layers.py:131-150, 155-159) including the K-1 calls of
+ * utils.split_sparse_dense_matmul (utils.py:49-78) and tf.matmul (gnn_layers.py:149).
+ *   x     device (N, n_cols, Fin) fp32, channels fastest, NEST pixel order as given by the caller
+ *   w     device [Fin*K, Fout] fp32, row index f*K + k  (the reference's `kernel` variable)
+ *   bias  device [Fout] fp32 or NULL                    (the reference's `bias`, shape [1,1,Fout])
+ *   y     device (N, out_rows, Fout) fp32
+ * Batch normalisation (gnn_layers.py:152-153) sits between the contraction and the bias in the
+ * reference; a layer with use_bn=True calls this with bias=NULL, act=NONE and finishes on the host.
+ * Asynchronous on `hip_stream` (a hipStream_t; NULL = the default stream). */
+int dsph_cheb_forward(const dsph_plan* plan, const float* x, const float* w, const float* bias,
+                      float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
+                      int32_t precision, int32_t algo, void* workspace, size_t workspace_bytes,
+                      void* hip_stream);
+
+/* One recurrence step on (N, n_cols, F) planes:  out = alpha * (L~ @ in) - beta * prev
+ * for rows [0, rows) of every map (rows <= n_rows; rows <= 0 means n_rows); prev may be NULL
+ * when beta == 0.  Replaces one utils.split_sparse_dense_matmul call plus the `2*... - x0`
+ * temporaries (gnn_layers.py:138,141).  Exposed for the one-ring-halo-per-step sharded mode,
+ * where the host exchanges boundary rows between steps, and for tests. */
+int dsph_cheb_step(const dsph_plan* plan, const float* in, const float* prev, float* out,
+                   int64_t N, int32_t F, float alpha, float beta, int64_t rows, void* hip_stream);
+
+/* The dense contraction alone on K planes of shape (N, plane_rows, Fin), plane k at
+ * planes[k] (device pointers in a HOST array of K entries):
+ *   y[n,m,o] = act( sum_k sum_f planes[k][n,m,f] * w[f*K + k, o] + bias[o] ),  m < rows.
+ * Replaces tf.stack/reshape/transpose/matmul (gnn_layers.py:144-150). */
+int dsph_cheb_contract(const float* const* planes, int64_t plane_rows, const float* w,
+                       const float* bias, float* y, int64_t N, int64_t rows, int32_t Fin,
+                       int32_t Fout, int32_t K, int32_t act, int32_t precision, int device,
+                       void* hip_stream);
+
+/* Gather / scatter of boundary rows for the halo exchange of the sharded path:
+ *   pack:   buf[n, i, :] = src[n, idx[i], :]       src (N, src_rows, F), buf (N, n_idx, F)
+ *   unpack: dst[n, idx[i], :] = buf[n, i, :]
+ * idx is a DEVICE int32 array. */
+int dsph_rows_pack(const float* src, int64_t src_rows, const int32_t* idx, int64_t n_idx,
+                   float* buf, int64_t N, int32_t F, int device, void* hip_stream);
+int dsph_rows_unpack(float* dst, int64_t dst_rows, const int32_t* idx, int64_t n_idx,
+                     const float* buf, int64_t N, int32_t F, int device, void* hip_stream);
+
+const char* dsph_last_error(void);
+int dsph_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSPHERE_H */

