@@ -1,19 +1,534 @@
-// Single-launch fused forward (tile + halo resident in LDS).  Placeholder until the tile
-// engine lands: every plan reports "not tileable" and dsph_cheb_forward takes the unfused path.
+// Single-launch fused Chebyshev forward: the K planes never leave the compute unit.
+//
+// Replaces the whole of Chebyshev.call (reference gnn_layers.py:131-150): the reference
+// materialises K planes of size |x| in memory (tf.stack) and re-lays them out twice; here a
+// workgroup owns a tile of P consecutive rows (NEST order: a 16x16 pixel square on a HEALPix
+// map), loads the tile plus its (K-1)-hop halo into LDS one 16-channel slice at a time, runs the
+// three-term recurrence in LDS on a region that shrinks by one ring per step, and feeds every
+// plane T_k straight into MFMA accumulators that stay in registers until y is written once.
+//
+// The decomposition is generic: rings come from a breadth-first search over the ELL pattern, so
+// k-NN graphs, partial-sky graphs, sharded plans with halo rows and arbitrary sparse matrices all
+// take the same path; a graph whose halo does not fit in LDS simply reports "not tileable" and
+// the caller falls back to the unfused kernels.
+//
+// Data layout (device):
+//   region_rows[tile_off[t] ..]   row ids of tile t's region, ring 0 (the tile's own rows, in
+//                                 order) first, then ring 1, ... ring D, each ring ascending
+//   ring_end[t][r]                number of region entries within r hops (r = 0..D)
+//   lcols/lvals                   tile-local ELL of the rows within D-1 hops, column = index into
+//                                 the region list (uint16), stored [slot][row] per tile so that
+//                                 lane i reads row i coalesced
+// LDS: two planes [Rmax][16] fp32 (16-byte slots XOR-swizzled so that 16 lanes reading the same
+// slot of 16 different rows hit 16 different bank groups) + the weight fragments of all
+// (order, slice) pairs in MFMA operand order.
+// Registers: each lane owns one (or two) region rows for the whole tile: their ELL values and
+// pre-swizzled LDS addresses stay in VGPRs across all slices and all maps of the batch.
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "dsphere_common.h"
 
 namespace dsph {
 
-struct FusedPlan {};
+constexpr int FUSED_P = 256;       // rows per tile
+constexpr int FUSED_CH = 16;       // channels per slice
+constexpr int FUSED_DMAX = 8;      // deepest halo supported (K <= 9)
+constexpr int FUSED_THREADS = 512; // 8 waves, 2 per SIMD
+constexpr int LDS_BYTES = 160 * 1024;
 
-FusedPlan* fused_plan_build(const dsph_plan*, const int32_t*, const float*) { return nullptr; }
-void fused_plan_destroy(FusedPlan* fp) { delete fp; }
-bool fused_supported(const dsph_plan*, int32_t, int32_t, int32_t) { return false; }
-size_t fused_workspace_bytes(const dsph_plan*, int64_t, int32_t, int32_t, int32_t, int32_t) { return 0; }
-int launch_cheb_fused(const dsph_plan*, const float*, const float*, const float*, float*, int64_t,
-                      int32_t, int32_t, int32_t, int32_t, int32_t, void*, size_t, hipStream_t) {
-  set_error("fused kernel not available");
-  return DSPH_E_UNSUPPORTED;
+struct FusedTiles {
+  int D = 0;
+  int width = 0;     // ELL width of the tile-local table (template width, >= plan width)
+  int rpl = 0;       // region rows per lane
+  int ntiles = 0;
+  int rmax = 0;      // largest region (rows), rounded up to a multiple of 16, >= FUSED_P
+  int emax = 0;      // largest number of rows that carry an ELL row
+  bool ok = false;
+  int32_t* d_tile_off = nullptr;
+  int32_t* d_ring_end = nullptr;   // [ntiles][DMAX+1]
+  int64_t* d_ell_off = nullptr;    // [ntiles] in rows
+  int32_t* d_region = nullptr;
+  uint16_t* d_lcols = nullptr;
+  float* d_lvals = nullptr;
+};
+
+struct FusedPlan {
+  std::vector<int32_t> h_cols;  // host copy of the ELL (needed to build tiles for a new K)
+  std::vector<float> h_vals;
+  std::mutex mu;
+  std::map<int, FusedTiles> by_depth;
+  int num_cu = 256;
+};
+
+static int template_width(int w) {
+  if (w <= 9) return 9;
+  if (w <= 12) return 12;
+  return 0;
+}
+
+static void free_tiles(FusedTiles& ft) {
+  if (ft.d_tile_off) (void)hipFree(ft.d_tile_off);
+  if (ft.d_ring_end) (void)hipFree(ft.d_ring_end);
+  if (ft.d_ell_off) (void)hipFree(ft.d_ell_off);
+  if (ft.d_region) (void)hipFree(ft.d_region);
+  if (ft.d_lcols) (void)hipFree(ft.d_lcols);
+  if (ft.d_lvals) (void)hipFree(ft.d_lvals);
+  ft = FusedTiles();
+}
+
+FusedPlan* fused_plan_build(const dsph_plan* plan, const int32_t* h_cols, const float* h_vals) {
+  if (template_width(plan->width) == 0) return nullptr;
+  FusedPlan* fp = new FusedPlan();
+  const size_t nnz = (size_t)plan->n_rows * plan->width;
+  fp->h_cols.assign(h_cols, h_cols + nnz);
+  fp->h_vals.assign(h_vals, h_vals + nnz);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0)
+    fp->num_cu = prop.multiProcessorCount;
+  return fp;
+}
+
+void fused_plan_destroy(FusedPlan* fp) {
+  if (!fp) return;
+  for (auto& kv : fp->by_depth) free_tiles(kv.second);
+  delete fp;
+}
+
+// Breadth-first rings of every tile; uploads the tables.  Returns a reference to the cached entry.
+static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
+  FusedPlan* fp = plan->fused;
+  std::lock_guard<std::mutex> lock(fp->mu);
+  auto it = fp->by_depth.find(D);
+  if (it != fp->by_depth.end()) return it->second;
+  FusedTiles& ft = fp->by_depth[D];
+  ft.D = D;
+  ft.width = template_width(plan->width);
+  const int W = plan->width, WT = ft.width;
+  const int64_t out_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
+  const int64_t nt64 = (out_rows + FUSED_P - 1) / FUSED_P;
+  if (D < 1 || D > FUSED_DMAX || nt64 > (1 << 30)) return ft;
+  const int ntiles = (int)nt64;
+  const int32_t* cols = fp->h_cols.data();
+  const float* vals = fp->h_vals.data();
+
+  std::vector<int32_t> stamp((size_t)plan->n_cols, -1), local((size_t)plan->n_cols, 0);
+  std::vector<int32_t> tile_off((size_t)ntiles + 1, 0), ring_end((size_t)ntiles * (FUSED_DMAX + 1), 0);
+  std::vector<int64_t> ell_off((size_t)ntiles, 0);
+  std::vector<int32_t> region;
+  std::vector<uint16_t> lcols;
+  std::vector<float> lvals;
+  region.reserve((size_t)ntiles * 600);
+  std::vector<int32_t> ring, next;
+  int rmax = 0, emax = 0;
+  int64_t ell_rows = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const int64_t r0 = (int64_t)t * FUSED_P, r1 = std::min<int64_t>(out_rows, r0 + FUSED_P);
+    const size_t base = region.size();
+    if (base > 0x7fffffffULL - 70000) return ft;  // offsets are int32
+    tile_off[t] = (int32_t)base;
+    ring.clear();
+    for (int64_t r = r0; r < r1; ++r) {
+      stamp[r] = t;
+      local[r] = (int32_t)(r - r0);
+      ring.push_back((int32_t)r);
+      region.push_back((int32_t)r);
+    }
+    int32_t* re = &ring_end[(size_t)t * (FUSED_DMAX + 1)];
+    re[0] = (int32_t)ring.size();
+    for (int d = 1; d <= D; ++d) {
+      next.clear();
+      for (int32_t r : ring) {
+        if (r >= plan->n_rows) return ft;  // a row that must be computed has no ELL row
+        const int32_t* c = cols + (size_t)r * W;
+        const float* v = vals + (size_t)r * W;
+        for (int j = 0; j < W; ++j) {
+          if (v[j] == 0.f) continue;
+          const int32_t cj = c[j];
+          if (stamp[cj] != t) {
+            stamp[cj] = t;
+            next.push_back(cj);
+          }
+        }
+      }
+      std::sort(next.begin(), next.end());
+      for (int32_t r : next) {
+        local[r] = (int32_t)(region.size() - base);
+        region.push_back(r);
+      }
+      re[d] = (int32_t)(region.size() - base);
+      ring.swap(next);
+    }
+    for (int d = D + 1; d <= FUSED_DMAX; ++d) re[d] = re[D];
+    const int R = re[D], E = re[D - 1];
+    if (R > 65535) return ft;  // uint16 local columns
+    rmax = std::max(rmax, R);
+    emax = std::max(emax, E);
+    // tile-local ELL of the rows within D-1 hops, stored [slot][row]
+    ell_off[t] = ell_rows;
+    const size_t lbase = lcols.size();
+    lcols.resize(lbase + (size_t)E * WT, 0);
+    lvals.resize(lbase + (size_t)E * WT, 0.f);
+    for (int i = 0; i < E; ++i) {
+      const int32_t r = region[base + i];
+      if (r >= plan->n_rows) return ft;
+      const int32_t* c = cols + (size_t)r * W;
+      const float* v = vals + (size_t)r * W;
+      for (int j = 0; j < WT; ++j) {
+        uint16_t lc = (uint16_t)i;
+        float lv = 0.f;
+        if (j < W && v[j] != 0.f) {
+          lc = (uint16_t)local[c[j]];
+          lv = v[j];
+        }
+        lcols[lbase + (size_t)j * E + i] = lc;
+        lvals[lbase + (size_t)j * E + i] = lv;
+      }
+    }
+    ell_rows += E;
+  }
+  tile_off[ntiles] = (int32_t)region.size();
+  ft.ntiles = ntiles;
+  ft.rmax = std::max((rmax + 15) / 16 * 16, FUSED_P);
+  ft.emax = emax;
+  ft.rpl = (emax + FUSED_THREADS - 1) / FUSED_THREADS;
+  if (ft.rpl > 2) return ft;
+
+  auto up = [](void** dst, const void* src, size_t bytes) -> bool {
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(dst, bytes) != hipSuccess) return false;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  if (lcols.empty()) { lcols.push_back(0); lvals.push_back(0.f); }
+  bool good = up((void**)&ft.d_tile_off, tile_off.data(), tile_off.size() * 4) &&
+              up((void**)&ft.d_ring_end, ring_end.data(), ring_end.size() * 4) &&
+              up((void**)&ft.d_ell_off, ell_off.data(), ell_off.size() * 8) &&
+              up((void**)&ft.d_region, region.data(), region.size() * 4) &&
+              up((void**)&ft.d_lcols, lcols.data(), lcols.size() * 2) &&
+              up((void**)&ft.d_lvals, lvals.data(), lvals.size() * 4);
+  if (!good) {
+    FusedTiles keep = ft;
+    free_tiles(ft);
+    ft.D = keep.D;
+    return ft;
+  }
+  ft.ok = true;
+  return ft;
+}
+
+static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
+  const int C = (Fin + FUSED_CH - 1) / FUSED_CH, NB = (Fout + 31) / 32;
+  return (size_t)K * C * NB * 2048;
+}
+
+bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
+  if (!plan->fused) return false;
+  if (K < 2 || K - 1 > FUSED_DMAX) return false;
+  if (Fin % 4 != 0 || Fin < 8 || Fout > 64 || Fout < 1) return false;
+  const FusedTiles& ft = get_tiles(plan, K - 1);
+  if (!ft.ok) return false;
+  const size_t lds = (size_t)2 * ft.rmax * FUSED_CH * 4 + wfrag_bytes(Fin, Fout, K);
+  return lds <= (size_t)LDS_BYTES;
+}
+
+size_t fused_workspace_bytes(const dsph_plan*, int64_t, int32_t Fin, int32_t Fout, int32_t K, int32_t) {
+  return wfrag_bytes(Fin, Fout, K);
+}
+
+// ------------------------------------------------------------------------------------------
+// device code
+// ------------------------------------------------------------------------------------------
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct FusedArgs {
+  const float* x;
+  const float* bias;
+  float* y;
+  const unsigned char* wfrag;
+  const int32_t* tile_off;
+  const int32_t* ring_end;
+  const int64_t* ell_off;
+  const int32_t* region;
+  const uint16_t* lcols;
+  const float* lvals;
+  int64_t x_rows, y_rows;
+  int N, Fin, Fout, K, ntiles, rmax, nchunks, act, wfrag_bytes;
+};
+
+// Weight fragments in MFMA operand order, one 2 KiB block per (order k, slice c, column block nb):
+//   bf16x3: lane l, element j  <- w[(c*16 + 8*(l>>5) + j)*K + k][32*nb + (l&31)], hi at +0, lo at +1024
+//   fp32  : step t, lane l     <- w[(c*16 + 8*(l>>5) + t)*K + k][32*nb + (l&31)] at t*256 + l*4
+__global__ __launch_bounds__(256) void fused_wprep_kernel(const float* __restrict__ w,
+                                                          unsigned char* __restrict__ out, int Fin,
+                                                          int Fout, int K, int C, int NB, int prec) {
+  const int blk = blockIdx.x;  // (k*C + c)*NB + nb
+  const int nb = blk % NB, c = (blk / NB) % C, k = blk / (NB * C);
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int l = e >> 3, j = e & 7;
+    const int ch = c * FUSED_CH + 8 * (l >> 5) + j, col = 32 * nb + (l & 31);
+    const float v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * Fout + col] : 0.f;
+    unsigned char* base = out + (size_t)blk * 2048;
+    if (prec == DSPH_PREC_BF16X3) {
+      const __bf16 hi = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)hi);
+      reinterpret_cast<__bf16*>(base)[l * 8 + j] = hi;
+      reinterpret_cast<__bf16*>(base + 1024)[l * 8 + j] = lo;
+    } else {
+      reinterpret_cast<float*>(base)[j * 64 + l] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ int plane_off(int row, int slot) {
+  // float index of 16-byte slot `slot` (0..3) of region row `row` in a [R][16] fp32 plane
+  return row * FUSED_CH + 4 * (slot ^ ((row >> 2) & 3));
+}
+
+template <int NB, int PREC>
+__device__ __forceinline__ void mfma_plane(const float* __restrict__ plane,
+                                           const unsigned char* __restrict__ sWblk, int wave, int lane,
+                                           f32x16 (&acc)[NB]) {
+  const int r = lane & 31, h = lane >> 5;
+  const int row = wave * 32 + r;
+  const float4 a0 = *reinterpret_cast<const float4*>(plane + plane_off(row, 2 * h));
+  const float4 a1 = *reinterpret_cast<const float4*>(plane + plane_off(row, 2 * h + 1));
+  const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  if (PREC == DSPH_PREC_BF16X3) {
+    bf16x8 ahi, alo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const __bf16 hi = (__bf16)av[j];
+      ahi[j] = hi;
+      alo[j] = (__bf16)(av[j] - (float)hi);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(sWblk + b * 2048 + lane * 16);
+      const bf16x8 blo = *reinterpret_cast<const bf16x8*>(sWblk + b * 2048 + 1024 + lane * 16);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[b], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float bv = *reinterpret_cast<const float*>(sWblk + b * 2048 + t * 256 + lane * 4);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[b], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int WT, int RPL, int NB, int PREC>
+__global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* __restrict__ planeX = reinterpret_cast<float*>(smem);
+  float* __restrict__ planeY = planeX + (size_t)a.rmax * FUSED_CH;
+  unsigned char* __restrict__ sW = reinterpret_cast<unsigned char*>(planeY + (size_t)a.rmax * FUSED_CH);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid * 16; i < a.wfrag_bytes; i += FUSED_THREADS * 16)
+    *reinterpret_cast<uint4*>(sW + i) = *reinterpret_cast<const uint4*>(a.wfrag + i);
+
+  // tiles are dealt to XCDs in contiguous ranges (blocks b and b+8 share an XCD): the 32
+  // workgroups of one XCD work on 32 neighbouring tiles at a time and share halos through its L2
+  const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nslots = (G + 7 - xcd) / 8;
+  const int t_begin = (int)((int64_t)a.ntiles * xcd / 8), t_end = (int)((int64_t)a.ntiles * (xcd + 1) / 8);
+  const int D = a.K - 1;
+
+  for (int t = t_begin + slot; t < t_end; t += nslots) {
+    const int off = a.tile_off[t];
+    const int32_t* __restrict__ re = a.ring_end + (size_t)t * (FUSED_DMAX + 1);
+    const int P_t = re[0], E = re[D - 1], R = re[D];
+    const int64_t lbase = a.ell_off[t] * WT;
+    const int64_t row0 = (int64_t)t * FUSED_P;
+
+    // this lane's region rows: ELL values and pre-swizzled byte addresses (slot 0) in registers
+    float val[RPL][WT];
+    unsigned pre[RPL][WT];
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+      const int i = tid + rr * FUSED_THREADS;
+#pragma unroll
+      for (int j = 0; j < WT; ++j) {
+        float v = 0.f;
+        unsigned c = 0;
+        if (i < E) {
+          v = a.lvals[lbase + (int64_t)j * E + i];
+          c = a.lcols[lbase + (int64_t)j * E + i];
+        }
+        val[rr][j] = v;
+        pre[rr][j] = c * (FUSED_CH * 4) + 16u * ((c >> 2) & 3u);
+      }
+    }
+
+    for (int n = 0; n < a.N; ++n) {
+      f32x16 acc[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+
+      for (int c = 0; c < a.nchunks; ++c) {
+        __syncthreads();  // the previous slice's last plane is still being read by MFMA
+        // ---- stage T_0 = x[n, region rows, 16c .. 16c+16) into plane X --------------------
+        for (int idx = tid; idx < R * 4; idx += FUSED_THREADS) {
+          const int row = idx >> 2, q = idx & 3;
+          const int ch = c * FUSED_CH + 4 * q;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ch < a.Fin) {
+            const int64_t g = a.region[off + row];
+            v = *reinterpret_cast<const float4*>(a.x + ((int64_t)n * a.x_rows + g) * a.Fin + ch);
+          }
+          *reinterpret_cast<float4*>(planeX + plane_off(row, q)) = v;
+        }
+        __syncthreads();
+        const unsigned char* __restrict__ wblk = sW + (size_t)c * NB * 2048;
+        const size_t wstride = (size_t)a.nchunks * NB * 2048;  // per order
+        mfma_plane<NB, PREC>(planeX, wblk, wave, lane, acc);
+
+        for (int k = 1; k < a.K; ++k) {
+          const float* __restrict__ pin = (k & 1) ? planeX : planeY;
+          float* __restrict__ pout = (k & 1) ? planeY : planeX;
+          const int nrows = re[D - k];
+          const float alpha = (k == 1) ? 1.f : 2.f;
+          const bool has_prev = k >= 2;
+#pragma unroll
+          for (int rr = 0; rr < RPL; ++rr) {
+            const int i = tid + rr * FUSED_THREADS;
+            if (i < nrows) {
+              const unsigned own = (unsigned)i * (FUSED_CH * 4) + 16u * ((i >> 2) & 3u);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < WT; ++j) {
+                  const float4 v = *reinterpret_cast<const float4*>(
+                      reinterpret_cast<const unsigned char*>(pin) + (pre[rr][j] ^ (unsigned)(q << 4)));
+                  s.x = fmaf(val[rr][j], v.x, s.x);
+                  s.y = fmaf(val[rr][j], v.y, s.y);
+                  s.z = fmaf(val[rr][j], v.z, s.z);
+                  s.w = fmaf(val[rr][j], v.w, s.w);
+                }
+                float4* op = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(pout) +
+                                                       (own ^ (unsigned)(q << 4)));
+                if (has_prev) {
+                  const float4 p = *op;
+                  s.x = alpha * s.x - p.x;
+                  s.y = alpha * s.y - p.y;
+                  s.z = alpha * s.z - p.z;
+                  s.w = alpha * s.w - p.w;
+                }
+                *op = s;
+              }
+            }
+          }
+          __syncthreads();
+          mfma_plane<NB, PREC>(pout, wblk + (size_t)k * wstride, wave, lane, acc);
+        }
+      }
+
+      // ---- epilogue: bias, activation, one store of y ------------------------------------
+      const int li = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int o = 32 * b + li;
+        if (o >= a.Fout) continue;
+        const float bv = a.bias ? a.bias[o] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (row < P_t)
+            a.y[((int64_t)n * a.y_rows + row0 + row) * a.Fout + o] = apply_act(acc[b][q] + bv, a.act);
+        }
+      }
+    }
+  }
+}
+
+template <int WT, int RPL, int NB, int PREC>
+static int launch_variant(const FusedArgs& args, int grid, size_t lds, hipStream_t stream) {
+  auto kern = cheb_fused_kernel<WT, RPL, NB, PREC>;
+  DSPH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), lds, stream, args);
+  DSPH_HIP(hipGetLastError());
+  return DSPH_OK;
+}
+
+template <int WT, int RPL>
+static int dispatch_nb_prec(const FusedArgs& args, int nb, int prec, int grid, size_t lds,
+                            hipStream_t stream) {
+  if (nb == 1) {
+    if (prec == DSPH_PREC_BF16X3) return launch_variant<WT, RPL, 1, DSPH_PREC_BF16X3>(args, grid, lds, stream);
+    return launch_variant<WT, RPL, 1, DSPH_PREC_FP32>(args, grid, lds, stream);
+  }
+  if (prec == DSPH_PREC_BF16X3) return launch_variant<WT, RPL, 2, DSPH_PREC_BF16X3>(args, grid, lds, stream);
+  return launch_variant<WT, RPL, 2, DSPH_PREC_FP32>(args, grid, lds, stream);
+}
+
+int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
+                      float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
+                      int32_t precision, void* workspace, size_t workspace_bytes,
+                      hipStream_t stream) {
+  if (!fused_supported(plan, Fin, Fout, K)) {
+    set_error("cheb_fused: plan/shape not supported");
+    return DSPH_E_UNSUPPORTED;
+  }
+  const FusedTiles& ft = get_tiles(plan, K - 1);
+  const size_t wb = wfrag_bytes(Fin, Fout, K);
+  if (!workspace || workspace_bytes < wb) {
+    set_error("cheb_fused: workspace %zu < %zu", workspace_bytes, wb);
+    return DSPH_E_WORKSPACE;
+  }
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) {
+    set_error("cheb_fused: x and workspace must be 16-byte aligned");
+    return DSPH_E_BADARG;
+  }
+  const int C = (Fin + FUSED_CH - 1) / FUSED_CH, NB = (Fout + 31) / 32;
+  hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,
+                     static_cast<unsigned char*>(workspace), (int)Fin, (int)Fout, (int)K, C, NB,
+                     (int)precision);
+  DSPH_HIP(hipGetLastError());
+
+  FusedArgs args;
+  args.x = x;
+  args.bias = bias;
+  args.y = y;
+  args.wfrag = static_cast<const unsigned char*>(workspace);
+  args.tile_off = ft.d_tile_off;
+  args.ring_end = ft.d_ring_end;
+  args.ell_off = ft.d_ell_off;
+  args.region = ft.d_region;
+  args.lcols = ft.d_lcols;
+  args.lvals = ft.d_lvals;
+  args.x_rows = plan->n_cols;
+  args.y_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
+  args.N = (int)N;
+  args.Fin = Fin;
+  args.Fout = Fout;
+  args.K = K;
+  args.ntiles = ft.ntiles;
+  args.rmax = ft.rmax;
+  args.nchunks = C;
+  args.act = act;
+  args.wfrag_bytes = (int)wb;
+  const size_t lds = (size_t)2 * ft.rmax * FUSED_CH * 4 + wb;
+  const int grid = std::max(8, std::min(plan->fused->num_cu, (ft.ntiles + 7) / 8 * 8));
+  if (ft.width == 9) {
+    if (ft.rpl <= 1) return dispatch_nb_prec<9, 1>(args, NB, precision, grid, lds, stream);
+    return dispatch_nb_prec<9, 2>(args, NB, precision, grid, lds, stream);
+  }
+  if (ft.rpl <= 1) return dispatch_nb_prec<12, 1>(args, NB, precision, grid, lds, stream);
+  return dispatch_nb_prec<12, 2>(args, NB, precision, grid, lds, stream);
 }
 
 }  // namespace dsph

@@ -94,6 +94,50 @@ def test_odd_shapes(Fin, Fout, K, N):
         assert rel_err(y.cpu().numpy(), ref) < TOL_FP32
 
 
+@pytest.mark.parametrize("prec,tol", [(_native.PREC_FP32, TOL_FP32), (_native.PREC_BF16X3, TOL_BF16X3)])
+@pytest.mark.parametrize("graph,nside,N,Fin,Fout,K", [
+    ("grid", 16, 2, 64, 64, 5),   # headline channel counts, 12 tiles
+    ("grid", 32, 1, 32, 32, 8),   # BASELINE config 4 shape: 7-ring halo, two region rows per lane
+    ("knn", 16, 2, 16, 32, 5),    # symmetrised k-NN: ELL width 11 -> width-12 variant
+    ("grid", 16, 3, 8, 5, 2),     # smallest slice, Fout not a multiple of 32
+    ("grid", 16, 1, 40, 64, 3),   # Fin not a multiple of the 16-channel slice
+    ("cap", 16, 2, 32, 64, 5),    # partial sky: ragged last tile, border rows with few neighbours
+])
+def test_fused_kernel(graph, nside, N, Fin, Fout, K, prec, tol):
+    if graph == "cap":
+        idx = healpix.extend_indices(healpix.cap_indices(nside, fraction=0.3), nside, 4)[:-37]
+        L = healpix.healpix_laplacian(nside, indices=idx, mode="grid")
+    else:
+        L = healpix.healpix_laplacian(nside, mode=graph)
+    Lt, _ = orc.prepare_L(L)
+    plan = _plan(Lt)
+    assert plan.fused_ok(Fin, Fout, K), "the fused kernel must cover this shape"
+    rng = np.random.default_rng(nside + Fin + K)
+    x = rng.standard_normal((N, Lt.shape[0], Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    ref = orc.chebyshev_forward(Lt, x, W, K, bias=b, activation="relu")
+    y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=prec,
+                                algo=_native.ALGO_FUSED)
+    err = rel_err(y.cpu().numpy(), ref)
+    print(f"fused {graph} nside={nside} {Fin}->{Fout} K={K} prec={prec}: rel err {err:.2e}")
+    assert err < tol
+    # fused and unfused agree to rounding, and the fused kernel is deterministic
+    yu, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, algo=_native.ALGO_UNFUSED)
+    assert rel_err(y.cpu().numpy(), yu.cpu().numpy()) < 2 * tol
+    y2, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=prec,
+                                 algo=_native.ALGO_FUSED)
+    assert torch.equal(y, y2)
+
+
+def test_fused_refuses_what_it_cannot_tile():
+    c = load_case("dense3")
+    plan = _plan(c["Lt"])
+    assert not plan.fused_ok(7, 3, 4)
+    with pytest.raises(RuntimeError):
+        _native.cheb_forward(plan, _dev(c["x"]), _dev(c["kernel"]), None, c["K"], algo=_native.ALGO_FUSED)
+
+
 def test_bitwise_determinism():
     c = load_case("n8_k5")
     plan = _plan(c["Lt"])
@@ -174,7 +218,7 @@ def test_levels_shrinking_schedule():
     # every step evaluated only where it is still needed, equals the whole-graph result
     L = healpix.healpix_laplacian(8, mode="knn")
     Lt, _ = orc.prepare_L(L)
-    M, K, Fin, Fout = Lt.shape[0], 5, 6, 4
+    M, K, Fin, Fout = Lt.shape[0], 5, 8, 4
     own = np.arange(128, 384)
     level = np.full(M, -1)
     level[own] = 0
@@ -199,9 +243,10 @@ def test_levels_shrinking_schedule():
     x = rng.standard_normal((2, M, Fin)).astype(np.float32)
     W = rng.standard_normal((Fin * K, Fout)).astype(np.float32)
     ref = orc.chebyshev_forward(Lt, x, W, K)[:, own]
-    y, _ = _native.cheb_forward(plan, _dev(x[:, perm]), _dev(W), None, K)
-    assert tuple(y.shape) == (2, len(own), Fout)
-    assert rel_err(y.cpu().numpy(), ref) < TOL_FP32
+    for algo in (_native.ALGO_UNFUSED, _native.ALGO_AUTO):
+        y, _ = _native.cheb_forward(plan, _dev(x[:, perm]), _dev(W), None, K, algo=algo)
+        assert tuple(y.shape) == (2, len(own), Fout)
+        assert rel_err(y.cpu().numpy(), ref) < TOL_FP32
 
 
 def test_rows_pack_unpack():
@@ -257,8 +302,9 @@ def _patch_reference(cols, vals, x_dev, W, K, centres):
     return y[:, pos]
 
 
-@pytest.mark.parametrize("nside,N,Fin,Fout,K", [(256, 8, 16, 32, 5), (1024, 1, 64, 64, 5)])
-def test_full_size_properties(nside, N, Fin, Fout, K):
+@pytest.mark.parametrize("nside,N,Fin,Fout,K,algo", [(256, 8, 16, 32, 5, "unfused"), (256, 8, 16, 32, 5, "fused"),
+                                                         (1024, 1, 64, 64, 5, "fused")])
+def test_full_size_properties(nside, N, Fin, Fout, K, algo):
     # BASELINE configs 2 and 3 (one map of it): patch oracle + linearity, sizes the oracle cannot run whole
     dev = torch.device("cuda", 0)
     cols_t, vals_t = healpix.grid_laplacian_ell_torch(nside, device=dev)
@@ -274,14 +320,15 @@ def test_full_size_properties(nside, N, Fin, Fout, K):
     W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
     Wd = _dev(W)
     ws = None
-    y1, ws = _native.cheb_forward(plan, x1, Wd, None, K, workspace=ws)
+    algo = {"unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}[algo]
+    y1, ws = _native.cheb_forward(plan, x1, Wd, None, K, workspace=ws, algo=algo)
     centres = np.array([0, 1, M // 3 + 5, nside * nside - 1, nside * nside, 5 * nside * nside + 77, M - 1])
     ref = _patch_reference(cols, vals, x1, W, K, centres)
     got = y1[:, torch.as_tensor(centres).cuda()].cpu().numpy()
     assert rel_err(got, ref) < TOL_FP32
-    y2, ws = _native.cheb_forward(plan, x2, Wd, None, K, workspace=ws)
+    y2, ws = _native.cheb_forward(plan, x2, Wd, None, K, workspace=ws, algo=algo)
     x3 = 0.5 * x1 - 2.0 * x2
-    y3, ws = _native.cheb_forward(plan, x3, Wd, None, K, workspace=ws)
+    y3, ws = _native.cheb_forward(plan, x3, Wd, None, K, workspace=ws, algo=algo)
     lin = 0.5 * y1 - 2.0 * y2
     err = (y3 - lin).abs().max().item() / lin.abs().max().item()
     assert err < 2e-5
