@@ -31,15 +31,10 @@
 #include <mutex>
 #include <vector>
 
-#include "dsphere_common.h"
+#include "cheb_fused_kernel.h"
 
 namespace dsph {
 
-constexpr int FUSED_P = 256;       // rows per tile
-constexpr int FUSED_CH = 16;       // channels per slice
-constexpr int FUSED_DMAX = 8;      // deepest halo supported (K <= 9)
-constexpr int FUSED_THREADS = 512; // 8 waves, 2 per SIMD
-constexpr int LDS_BYTES = 160 * 1024;
 
 struct FusedTiles {
   int D = 0;
@@ -223,6 +218,7 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
 static int plane_rows_for(int rmax, int emax) {
   if (rmax <= 576 && emax <= 512) return 576;
   if (rmax <= 768 && emax <= 768) return 768;
+  if (rmax <= 928 && emax <= 928) return 928;
   return (rmax <= 1024 && emax <= 1024) ? 1024 : 0;
 }
 
@@ -248,27 +244,8 @@ size_t fused_workspace_bytes(const dsph_plan*, int64_t, int32_t Fin, int32_t Fou
 }
 
 // ------------------------------------------------------------------------------------------
-// device code
+// weight preparation + launch
 // ------------------------------------------------------------------------------------------
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct FusedArgs {
-  const float* x;
-  const float* bias;
-  float* y;
-  const unsigned char* wfrag;
-  const int32_t* tile_off;
-  const int32_t* ring_end;
-  const int64_t* ell_off;
-  const int32_t* region;
-  const uint16_t* lcols;
-  const float* lvals;
-  int64_t x_rows, y_rows;
-  int N, Fin, Fout, K, ntiles, nchunks, act, wfrag_bytes;
-  int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no MFMA, 4 no x loads, 8 no y store
-};
 
 // Weight fragments in MFMA operand order, one 2 KiB block per (order k, slice c, column block nb):
 //   bf16x3: lane l, element j  <- w[(c*16 + 8*(l>>5) + j)*K + k][32*nb + (l&31)], hi at +0, lo at +1024
@@ -292,358 +269,6 @@ __global__ __launch_bounds__(256) void fused_wprep_kernel(const float* __restric
       reinterpret_cast<float*>(base)[j * 64 + l] = v;
     }
   }
-}
-
-// byte offset of 16-byte slot `slot` (0..3) of region row `row` inside a [rows][16] fp32 plane
-__device__ __forceinline__ unsigned plane_byte(unsigned row, unsigned slot) {
-  return row * (FUSED_CH * 4) + 16u * (slot ^ ((row >> 2) & 3u));
-}
-
-// MFMA operands of one plane T_k for this wave's 32 tile rows: A from the LDS plane (converted
-// to split bf16 when PREC says so), B (the weight fragments) from LDS.
-template <int NB, int PREC>
-struct PlaneFrags {
-  float av[8];
-  bf16x8 ahi, alo, bhi[NB], blo[NB];
-  const unsigned char* wb;
-  int lane;
-
-  __device__ __forceinline__ void load(const unsigned char* __restrict__ plane,
-                                       const unsigned char* __restrict__ sWblk, int wave, int lane_) {
-    lane = lane_;
-    wb = sWblk;
-    const unsigned r = lane & 31, h = lane >> 5;
-    const unsigned row = wave * 32 + r;
-    const float4 a0 = *reinterpret_cast<const float4*>(plane + plane_byte(row, 2 * h));
-    const float4 a1 = *reinterpret_cast<const float4*>(plane + plane_byte(row, 2 * h + 1));
-    av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w;
-    av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
-    if (PREC == DSPH_PREC_BF16X3) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        bhi[b] = *reinterpret_cast<const bf16x8*>(sWblk + b * 2048 + lane * 16);
-        blo[b] = *reinterpret_cast<const bf16x8*>(sWblk + b * 2048 + 1024 + lane * 16);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const __bf16 hi = (__bf16)av[j];
-        ahi[j] = hi;
-        alo[j] = (__bf16)(av[j] - (float)hi);
-      }
-    }
-  }
-
-  // the contraction is cut into PARTS pieces so that each can be issued in front of one pass of
-  // the recurrence: the matrix pipe then works in the shadow of that pass's LDS gathers and FMAs
-  template <int PART, int PARTS>
-  __device__ __forceinline__ void issue(f32x16 (&acc)[NB]) const {
-    if (PREC == DSPH_PREC_BF16X3) {
-      // 3 products per column block, small terms first; product s goes out in part min(s, PARTS-1)
-#pragma unroll
-      for (int sidx = 0; sidx < 3; ++sidx) {
-        const int part = sidx < PARTS ? sidx : PARTS - 1;
-        if (part != PART) continue;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          if (sidx == 0) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[b], acc[b], 0, 0, 0);
-          if (sidx == 1) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[b], acc[b], 0, 0, 0);
-          if (sidx == 2) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[b], acc[b], 0, 0, 0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int part = (t * PARTS) / 8;
-        if (part != PART) continue;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const float bv = *reinterpret_cast<const float*>(wb + b * 2048 + t * 256 + lane * 4);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[b], 0, 0, 0);
-        }
-      }
-    }
-  }
-};
-
-template <int NB, int PREC>
-__device__ __forceinline__ void mfma_plane(const unsigned char* __restrict__ plane,
-                                           const unsigned char* __restrict__ sWblk, int wave, int lane,
-                                           f32x16 (&acc)[NB]) {
-  PlaneFrags<NB, PREC> f;
-  f.load(plane, sWblk, wave, lane);
-  f.template issue<0, 1>(acc);
-}
-
-// One sub-pass of a recurrence step: 16-byte slot Q of this lane's RR-th region row.
-template <int WT, int RPL, bool HAS_PREV, int RR, int Q>
-__device__ __forceinline__ void gather_pass(const unsigned char* __restrict__ pin,
-                                            unsigned char* __restrict__ pout, int nrows, int tid,
-                                            const float (&val)[RPL][WT], const unsigned (&pre)[RPL][WT],
-                                            const unsigned (&own)[RPL]) {
-  if (tid + RR * FUSED_THREADS < nrows) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < WT; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(pin + (pre[RR][j] ^ (unsigned)(Q << 4)));
-      s.x = fmaf(val[RR][j], v.x, s.x);
-      s.y = fmaf(val[RR][j], v.y, s.y);
-      s.z = fmaf(val[RR][j], v.z, s.z);
-      s.w = fmaf(val[RR][j], v.w, s.w);
-    }
-    float4* op = reinterpret_cast<float4*>(pout + (own[RR] ^ (unsigned)(Q << 4)));
-    if (HAS_PREV) {
-      const float4 q = *op;
-      s.x = 2.f * s.x - q.x;
-      s.y = 2.f * s.y - q.y;
-      s.z = 2.f * s.z - q.z;
-      s.w = 2.f * s.w - q.w;
-    }
-    *op = s;
-  }
-}
-
-template <int WT, int RPL, bool HAS_PREV, int NB, int PREC, int P>
-struct StepLoop {
-  static __device__ __forceinline__ void run(const PlaneFrags<NB, PREC>& f, f32x16 (&acc)[NB], bool do_m,
-                                             bool do_g, const unsigned char* __restrict__ pin,
-                                             unsigned char* __restrict__ pout, int nrows, int tid,
-                                             const float (&val)[RPL][WT], const unsigned (&pre)[RPL][WT],
-                                             const unsigned (&own)[RPL]) {
-    constexpr int PARTS = PREC == DSPH_PREC_BF16X3 ? 3 : 4;
-    if (P < PARTS && do_m) f.template issue<(P < PARTS ? P : 0), PARTS>(acc);
-#ifdef DSPH_PIN_SCHED
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    if (do_g) gather_pass<WT, RPL, HAS_PREV, P / 4, P % 4>(pin, pout, nrows, tid, val, pre, own);
-#ifdef DSPH_PIN_SCHED
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    StepLoop<WT, RPL, HAS_PREV, NB, PREC, P + 1>::run(f, acc, do_m, do_g, pin, pout, nrows, tid, val, pre, own);
-  }
-};
-template <int WT, int RPL, bool HAS_PREV, int NB, int PREC>
-struct StepLoop<WT, RPL, HAS_PREV, NB, PREC, 4 * RPL> {
-  static __device__ __forceinline__ void run(const PlaneFrags<NB, PREC>&, f32x16 (&)[NB], bool, bool,
-                                             const unsigned char* __restrict__, unsigned char* __restrict__, int,
-                                             int, const float (&)[RPL][WT], const unsigned (&)[RPL][WT],
-                                             const unsigned (&)[RPL]) {}
-};
-
-// Contract plane `pin` (= T_{k-1}) into the accumulators while computing T_k = alpha L~ T_{k-1} - T_{k-2}
-// from it into `pout`: the MFMAs of the former are issued between the gather passes of the latter.
-template <int WT, int RPL, bool HAS_PREV, int NB, int PREC>
-__device__ __forceinline__ void fused_step(const unsigned char* __restrict__ pin, unsigned char* __restrict__ pout,
-                                           const unsigned char* __restrict__ wblk, int wave, int lane,
-                                           f32x16 (&acc)[NB], bool do_m, bool do_g, int nrows, int tid,
-                                           const float (&val)[RPL][WT], const unsigned (&pre)[RPL][WT],
-                                           const unsigned (&own)[RPL]) {
-  PlaneFrags<NB, PREC> f;
-  f.load(pin, wblk, wave, lane);
-#ifdef DSPH_PIN_SCHED
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-  StepLoop<WT, RPL, HAS_PREV, NB, PREC, 0>::run(f, acc, do_m, do_g, pin, pout, nrows, tid, val, pre, own);
-}
-
-// PR: rows each LDS plane is sized for; RPL: recurrence rows per lane (PR <= 512*RPL + ring D);
-// WT: ELL width; NB: 32-column output blocks; PREC: contraction arithmetic.
-template <int PR, int WT, int RPL, int NB, int PREC>
-__global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs a) {
-  constexpr int PLANE_BYTES = PR * FUSED_CH * 4;
-  constexpr int NS = (PR * 4 + FUSED_THREADS - 1) / FUSED_THREADS;  // staging float4 per lane
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const planeX = smem;
-  unsigned char* const planeY = smem + PLANE_BYTES;
-  unsigned char* const sW = smem + 2 * PLANE_BYTES;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid * 16; i < a.wfrag_bytes; i += FUSED_THREADS * 16)
-    *reinterpret_cast<uint4*>(sW + i) = *reinterpret_cast<const uint4*>(a.wfrag + i);
-
-  // tiles are dealt to XCDs in contiguous ranges (blocks b and b+8 share an XCD): the 32
-  // workgroups of one XCD work on 32 neighbouring tiles at a time and share halos through its L2
-  const int G = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
-  const int nslots = (G + 7 - xcd) / 8;
-  const int t_begin = (int)((int64_t)a.ntiles * xcd / 8), t_end = (int)((int64_t)a.ntiles * (xcd + 1) / 8);
-  const int D = a.K - 1;
-  const int items = a.N * a.nchunks;    // (map, slice) pairs per tile
-
-  // ---- software prefetch of the next (tile, map, slice): region row ids and x in registers ----
-  int rid[NS];
-  float4 pf[NS];
-  auto load_rids = [&](int t) {
-    const int off = a.tile_off[t];
-    const int R = a.ring_end[(size_t)t * (FUSED_DMAX + 1) + D];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int row = (tid + s * FUSED_THREADS) >> 2;
-      rid[s] = row < R ? a.region[off + row] : -1;
-    }
-  };
-  auto issue_loads = [&](int item) {
-    const int n = item / a.nchunks, c = item - n * a.nchunks;
-    const int ch = c * FUSED_CH + 4 * (tid & 3);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rid[s] >= 0 && ch < a.Fin && !(a.dbg & 4))
-        v = *reinterpret_cast<const float4*>(a.x + ((int64_t)n * a.x_rows + rid[s]) * a.Fin + ch);
-      pf[s] = v;
-    }
-  };
-
-  int t = t_begin + slot0;
-  if (t < t_end) {
-    load_rids(t);
-    issue_loads(0);
-  }
-  for (; t < t_end; t += nslots) {
-    const int32_t* __restrict__ re = a.ring_end + (size_t)t * (FUSED_DMAX + 1);
-    const int P_t = re[0], E = re[D - 1];
-    const int64_t lbase = a.ell_off[t] * WT;
-    const int64_t row0 = (int64_t)t * FUSED_P;
-
-    // this lane's recurrence rows: ELL values and swizzled LDS byte addresses stay in registers
-    float val[RPL][WT];
-    unsigned pre[RPL][WT], own[RPL];
-#pragma unroll
-    for (int p = 0; p < RPL; ++p) {
-      const int i = tid + p * FUSED_THREADS;
-      own[p] = plane_byte((unsigned)i, 0);
-#pragma unroll
-      for (int j = 0; j < WT; ++j) {
-        float v = 0.f;
-        unsigned c = 0;
-        if (i < E) {
-          v = a.lvals[lbase + (int64_t)j * E + i];
-          c = a.lcols[lbase + (int64_t)j * E + i];
-        }
-        val[p][j] = v;
-        pre[p][j] = plane_byte(c, 0);
-      }
-    }
-
-    f32x16 acc[NB];
-    for (int item = 0; item < items; ++item) {
-      const int n = item / a.nchunks, c = item - n * a.nchunks;
-      if (c == 0) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
-      }
-      __syncthreads();  // the previous slice's last plane is still being read by MFMA
-      // ---- T_0: the prefetched x slice goes to plane X; fetch the next slice meanwhile -------
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const unsigned idx = tid + s * FUSED_THREADS;
-        if (idx < (unsigned)PR * 4) *reinterpret_cast<float4*>(planeX + plane_byte(idx >> 2, idx & 3)) = pf[s];
-      }
-      if (item + 1 < items) {
-        issue_loads(item + 1);
-      } else if (t + nslots < t_end) {
-        load_rids(t + nslots);
-        issue_loads(0);
-      }
-      __syncthreads();
-      const unsigned char* __restrict__ wblk = sW + (size_t)c * NB * 2048;
-      const size_t wstride = (size_t)a.nchunks * NB * 2048;  // per order
-      const bool do_g = !(a.dbg & 1), do_m = !(a.dbg & 2);
-      // ---- recurrence + contraction, two steps per trip so that the plane roles are static ----
-      fused_step<WT, RPL, false, NB, PREC>(planeX, planeY, wblk, wave, lane, acc, do_m, do_g, re[D - 1], tid, val,
-                                          pre, own);
-      __syncthreads();
-      int k = 2;
-      for (; k + 1 < a.K; k += 2) {
-        fused_step<WT, RPL, true, NB, PREC>(planeY, planeX, wblk + (size_t)(k - 1) * wstride, wave, lane, acc, do_m,
-                                           do_g, re[D - k], tid, val, pre, own);
-        __syncthreads();
-        fused_step<WT, RPL, true, NB, PREC>(planeX, planeY, wblk + (size_t)k * wstride, wave, lane, acc, do_m, do_g,
-                                           re[D - k - 1], tid, val, pre, own);
-        __syncthreads();
-      }
-      if (k < a.K) {  // K odd: one more step, the last plane ends up in X
-        fused_step<WT, RPL, true, NB, PREC>(planeY, planeX, wblk + (size_t)(k - 1) * wstride, wave, lane, acc, do_m,
-                                           do_g, re[D - k], tid, val, pre, own);
-        __syncthreads();
-        if (do_m) mfma_plane<NB, PREC>(planeX, wblk + (size_t)k * wstride, wave, lane, acc);
-      } else {
-        if (do_m) mfma_plane<NB, PREC>(planeY, wblk + (size_t)(k - 1) * wstride, wave, lane, acc);
-      }
-
-      // ---- epilogue after the last slice of a map: bias, activation, one store of y ---------
-      // The accumulator tile (column per lane, rows in registers) goes through LDS so that every
-      // store instruction writes whole 256-byte pixel rows (16 bytes per lane) instead of 128-byte
-      // fragments: a row-per-lane dword epilogue is store-issue bound (it cost 8 of 28 ms).
-      if (c == a.nchunks - 1 && !(a.dbg & 8)) {
-        constexpr int T_LD = 32 * NB + 4;  // padded row (floats) of a wave's 32 x (32*NB) tile
-        __syncthreads();                   // every wave is done reading the planes
-        float* __restrict__ tw = reinterpret_cast<float*>(smem) + wave * (32 * T_LD);
-        const int li = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int q = 0; q < 16; ++q)
-            tw[((q & 3) + 8 * (q >> 2) + 4 * h) * T_LD + 32 * b + li] = acc[b][q];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        constexpr int LPR = 8 * NB;       // lanes per output row (float4 each)
-        constexpr int RPI = 64 / LPR;     // rows per store instruction
-        const int cq = (lane % LPR) * 4, rsub = lane / LPR;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) {
-          bv.x = cq + 0 < a.Fout ? a.bias[cq + 0] : 0.f;
-          bv.y = cq + 1 < a.Fout ? a.bias[cq + 1] : 0.f;
-          bv.z = cq + 2 < a.Fout ? a.bias[cq + 2] : 0.f;
-          bv.w = cq + 3 < a.Fout ? a.bias[cq + 3] : 0.f;
-        }
-        const bool vec_ok = (a.Fout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
-#pragma unroll
-        for (int i = 0; i < 32 / RPI; ++i) {
-          const int row = i * RPI + rsub;
-          float4 v = *reinterpret_cast<const float4*>(tw + row * T_LD + cq);
-          v.x = apply_act(v.x + bv.x, a.act);
-          v.y = apply_act(v.y + bv.y, a.act);
-          v.z = apply_act(v.z + bv.z, a.act);
-          v.w = apply_act(v.w + bv.w, a.act);
-          const int grow = wave * 32 + row;
-          if (grow < P_t) {
-            float* __restrict__ yp = a.y + ((int64_t)n * a.y_rows + row0 + grow) * a.Fout + cq;
-            if (vec_ok && cq + 3 < a.Fout) {
-              *reinterpret_cast<float4*>(yp) = v;
-            } else {
-              if (cq + 0 < a.Fout) yp[0] = v.x;
-              if (cq + 1 < a.Fout) yp[1] = v.y;
-              if (cq + 2 < a.Fout) yp[2] = v.z;
-              if (cq + 3 < a.Fout) yp[3] = v.w;
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
-template <int PR, int WT, int RPL, int NB, int PREC>
-static int launch_variant(const FusedArgs& args, int grid, size_t lds, hipStream_t stream) {
-  auto kern = cheb_fused_kernel<PR, WT, RPL, NB, PREC>;
-  DSPH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), lds, stream, args);
-  DSPH_HIP(hipGetLastError());
-  return DSPH_OK;
-}
-
-template <int PR, int WT, int RPL>
-static int dispatch_nb_prec(const FusedArgs& args, int nb, int prec, int grid, size_t lds,
-                            hipStream_t stream) {
-  if (nb == 1) {
-    if (prec == DSPH_PREC_BF16X3) return launch_variant<PR, WT, RPL, 1, DSPH_PREC_BF16X3>(args, grid, lds, stream);
-    return launch_variant<PR, WT, RPL, 1, DSPH_PREC_FP32>(args, grid, lds, stream);
-  }
-  if (prec == DSPH_PREC_BF16X3) return launch_variant<PR, WT, RPL, 2, DSPH_PREC_BF16X3>(args, grid, lds, stream);
-  return launch_variant<PR, WT, RPL, 2, DSPH_PREC_FP32>(args, grid, lds, stream);
 }
 
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
@@ -696,14 +321,19 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wb;
   const int grid = std::max(8, std::min(plan->fused->num_cu, (ft.ntiles + 7) / 8 * 8));
-  if (ft.width == 9) {
-    if (pr == 576) return dispatch_nb_prec<576, 9, 1>(args, NB, precision, grid, lds, stream);
-    if (pr == 768) return dispatch_nb_prec<768, 9, 2>(args, NB, precision, grid, lds, stream);
-    return dispatch_nb_prec<1024, 9, 2>(args, NB, precision, grid, lds, stream);
-  }
-  if (pr == 576) return dispatch_nb_prec<576, 12, 1>(args, NB, precision, grid, lds, stream);
-  if (pr == 768) return dispatch_nb_prec<768, 12, 2>(args, NB, precision, grid, lds, stream);
-  return dispatch_nb_prec<1024, 12, 2>(args, NB, precision, grid, lds, stream);
+#define DSPH_FUSED_CASE(PR, WT) \
+  if (pr == PR && ft.width == WT) return launch_fused_##PR##_##WT(args, NB, precision, grid, lds, stream);
+  DSPH_FUSED_CASE(576, 9)
+  DSPH_FUSED_CASE(768, 9)
+  DSPH_FUSED_CASE(928, 9)
+  DSPH_FUSED_CASE(1024, 9)
+  DSPH_FUSED_CASE(576, 12)
+  DSPH_FUSED_CASE(768, 12)
+  DSPH_FUSED_CASE(928, 12)
+  DSPH_FUSED_CASE(1024, 12)
+#undef DSPH_FUSED_CASE
+  set_error("cheb_fused: no kernel for plane rows %d, width %d", pr, ft.width);
+  return DSPH_E_UNSUPPORTED;
 }
 
 }  // namespace dsph

@@ -1,0 +1,331 @@
+// Device side of the fused Chebyshev forward (see cheb_fused.hip for the design notes).
+// Included by cheb_fused.hip (host: tile tables, dispatch) and by cheb_fused_inst.hip, which is
+// compiled once per (plane rows, ELL width) pair so that the instantiations build in parallel.
+#pragma once
+
+#include "dsphere_common.h"
+
+namespace dsph {
+
+constexpr int FUSED_P = 256;        // rows per tile
+constexpr int FUSED_CH = 16;        // channels per slice
+constexpr int FUSED_DMAX = 8;       // deepest halo supported (K <= 9)
+constexpr int FUSED_THREADS = 512;  // 8 waves, 2 per SIMD
+constexpr int LDS_BYTES = 160 * 1024;
+constexpr int G_ROWS = FUSED_THREADS / 4;  // recurrence: four lanes share a region row, 128 rows per pass
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct FusedArgs {
+  const float* x;
+  const float* bias;
+  float* y;
+  const unsigned char* wfrag;
+  const int32_t* tile_off;
+  const int32_t* ring_end;
+  const int64_t* ell_off;
+  const int32_t* region;
+  const uint16_t* lcols;
+  const float* lvals;
+  int64_t x_rows, y_rows;
+  int N, Fin, Fout, K, ntiles, nchunks, act, wfrag_bytes;
+  int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no MFMA, 4 no x loads, 8 no y store
+};
+
+// Byte offset of 16-byte slot `slot` (0..3) of region row `row` inside a [rows][16] fp32 plane.
+// A row is 64 B, so four consecutive rows fill the 256-byte LDS bank row; XOR-ing the slot with
+// bits 2..3 of the row makes 16 lanes that read one slot of 16 consecutive rows (the MFMA operand
+// read) hit 16 different 16-byte bank groups.  The recurrence reads with four lanes per row (one
+// slot each), which is conflict-free whenever the four rows of a 16-lane group differ mod 4.
+__device__ __forceinline__ unsigned plane_byte(unsigned row, unsigned slot) {
+  return row * (FUSED_CH * 4) + 16u * (slot ^ ((row >> 2) & 3u));
+}
+
+// One plane T_k (tile rows 32*wave .. +32, all 16 channels of the slice) into the MFMA
+// accumulators: A from the LDS plane, converted on the fly to split bf16 when PREC says so; B (the
+// weight fragments of (order k, slice c), already in operand order) from LDS.
+template <int NB, int PREC>
+__device__ __forceinline__ void mfma_plane(const unsigned char* __restrict__ plane,
+                                           const unsigned char* __restrict__ wblk, int wave, int lane,
+                                           f32x16 (&acc)[NB]) {
+  const unsigned r = lane & 31, h = lane >> 5;
+  const unsigned row = wave * 32 + r;
+  const float4 a0 = *reinterpret_cast<const float4*>(plane + plane_byte(row, 2 * h));
+  const float4 a1 = *reinterpret_cast<const float4*>(plane + plane_byte(row, 2 * h + 1));
+  const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  if (PREC == DSPH_PREC_BF16X3) {
+    bf16x8 ahi, alo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const __bf16 hi = (__bf16)av[j];
+      ahi[j] = hi;
+      alo[j] = (__bf16)(av[j] - (float)hi);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(wblk + b * 2048 + lane * 16);
+      const bf16x8 blo = *reinterpret_cast<const bf16x8*>(wblk + b * 2048 + 1024 + lane * 16);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[b], 0, 0, 0);  // small terms first
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[b], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float bv = *reinterpret_cast<const float*>(wblk + b * 2048 + t * 256 + lane * 4);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[b], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// One recurrence step: out = (HAS_PREV ? 2 : 1) * (L~ in) - (HAS_PREV ? out : 0) on rows [0, nrows).
+// Lane (row_l, slot) owns rows row_l + 128 p, p = 0..RP-1, and one 16-byte slot (4 channels) of them;
+// the ELL values and the swizzled LDS addresses of those rows' neighbours live in registers.  The
+// summation order (slot j ascending, fused multiply-add) is the unfused kernel's.
+template <int WT, int RP, bool HAS_PREV>
+__device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pin,
+                                            unsigned char* __restrict__ pout, int nrows, int row_l,
+                                            const float (&val)[RP][WT], const unsigned (&pre)[RP][WT],
+                                            const unsigned (&own)[RP]) {
+#pragma unroll
+  for (int p = 0; p < RP; ++p) {
+    if (row_l + p * G_ROWS < nrows) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < WT; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(pin + pre[p][j]);
+        s.x = fmaf(val[p][j], v.x, s.x);
+        s.y = fmaf(val[p][j], v.y, s.y);
+        s.z = fmaf(val[p][j], v.z, s.z);
+        s.w = fmaf(val[p][j], v.w, s.w);
+      }
+      float4* op = reinterpret_cast<float4*>(pout + own[p]);
+      if (HAS_PREV) {
+        const float4 q = *op;
+        s.x = 2.f * s.x - q.x;
+        s.y = 2.f * s.y - q.y;
+        s.z = 2.f * s.z - q.z;
+        s.w = 2.f * s.w - q.w;
+      }
+      *op = s;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the passes apart: 9 gathers in flight, not 9*RP
+  }
+}
+
+// PR: rows each LDS plane is sized for; RP: recurrence rows per lane (rows with an ELL row <= 128*RP);
+// WT: ELL width; NB: 32-column output blocks; PREC: contraction arithmetic.
+template <int PR, int WT, int RP, int NB, int PREC>
+__global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs a) {
+  constexpr int PLANE_BYTES = PR * FUSED_CH * 4;
+  constexpr int NS = (PR * 4 + FUSED_THREADS - 1) / FUSED_THREADS;  // staging float4 per lane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const planeX = smem;
+  unsigned char* const planeY = smem + PLANE_BYTES;
+  unsigned char* const sW = smem + 2 * PLANE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid * 16; i < a.wfrag_bytes; i += FUSED_THREADS * 16)
+    *reinterpret_cast<uint4*>(sW + i) = *reinterpret_cast<const uint4*>(a.wfrag + i);
+
+  // tiles are dealt to XCDs in contiguous ranges (blocks b and b+8 share an XCD): the 32
+  // workgroups of one XCD work on 32 neighbouring tiles at a time and share halos through its L2
+  const int G = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+  const int nslots = (G + 7 - xcd) / 8;
+  const int t_begin = (int)((int64_t)a.ntiles * xcd / 8), t_end = (int)((int64_t)a.ntiles * (xcd + 1) / 8);
+  const int D = a.K - 1;
+  const int row_l = tid >> 2;      // recurrence: this lane's row within a pass
+  const unsigned qslot = tid & 3;  //             and its 16-byte slot
+  const int items = a.N * a.nchunks;  // (map, slice) pairs per tile
+  const size_t wstride = (size_t)a.nchunks * NB * 2048;  // weight blocks: per order
+  const bool do_g = !(a.dbg & 1), do_m = !(a.dbg & 2);
+
+  // ---- software prefetch of the next (tile, map, slice): region row ids and x in registers ----
+  int rid[NS];
+  float4 pf[NS];
+  auto load_rids = [&](int t) {
+    const int off = a.tile_off[t];
+    const int R = a.ring_end[(size_t)t * (FUSED_DMAX + 1) + D];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int row = (tid + s * FUSED_THREADS) >> 2;
+      rid[s] = row < R ? a.region[off + row] : -1;
+    }
+  };
+  auto issue_loads = [&](int item) {
+    const int n = item / a.nchunks, c = item - n * a.nchunks;
+    const int ch = c * FUSED_CH + 4 * (tid & 3);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rid[s] >= 0 && ch < a.Fin && !(a.dbg & 4))
+        v = *reinterpret_cast<const float4*>(a.x + ((int64_t)n * a.x_rows + rid[s]) * a.Fin + ch);
+      pf[s] = v;
+    }
+  };
+
+  int t = t_begin + slot0;
+  if (t < t_end) {
+    load_rids(t);
+    issue_loads(0);
+  }
+  for (; t < t_end; t += nslots) {
+    const int32_t* __restrict__ re = a.ring_end + (size_t)t * (FUSED_DMAX + 1);
+    const int P_t = re[0], E = re[D - 1];
+    const int64_t lbase = a.ell_off[t] * WT;
+    const int64_t row0 = (int64_t)t * FUSED_P;
+
+    // this lane's recurrence rows: ELL values and swizzled LDS byte addresses stay in registers
+    float val[RP][WT];
+    unsigned pre[RP][WT], own[RP];
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      const int i = row_l + p * G_ROWS;
+      own[p] = plane_byte((unsigned)(i < PR ? i : 0), qslot);
+#pragma unroll
+      for (int j = 0; j < WT; ++j) {
+        float v = 0.f;
+        unsigned c = 0;
+        if (i < E) {
+          v = a.lvals[lbase + (int64_t)j * E + i];
+          c = a.lcols[lbase + (int64_t)j * E + i];
+        }
+        val[p][j] = v;
+        pre[p][j] = plane_byte(c, qslot);
+      }
+    }
+
+    f32x16 acc[NB];
+    for (int item = 0; item < items; ++item) {
+      const int n = item / a.nchunks, c = item - n * a.nchunks;
+      if (c == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+      }
+      __syncthreads();  // the previous slice's last plane (or the y transposition) is still being read
+      // ---- T_0: the prefetched x slice goes to plane X; fetch the next slice meanwhile -------
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const unsigned idx = tid + s * FUSED_THREADS;
+        if (idx < (unsigned)PR * 4) *reinterpret_cast<float4*>(planeX + plane_byte(idx >> 2, idx & 3)) = pf[s];
+      }
+      if (item + 1 < items) {
+        issue_loads(item + 1);
+      } else if (t + nslots < t_end) {
+        load_rids(t + nslots);
+        issue_loads(0);
+      }
+      __syncthreads();
+      const unsigned char* __restrict__ wblk = sW + (size_t)c * NB * 2048;
+      if (do_m) mfma_plane<NB, PREC>(planeX, wblk, wave, lane, acc);
+
+      // ---- recurrence, two steps per trip so that the plane roles are compile-time ----------
+      if (do_g) gather_step<WT, RP, false>(planeX, planeY, re[D - 1], row_l, val, pre, own);
+      __syncthreads();
+      if (do_m) mfma_plane<NB, PREC>(planeY, wblk + wstride, wave, lane, acc);
+      for (int k = 2; k < a.K; k += 2) {
+        if (do_g) gather_step<WT, RP, true>(planeY, planeX, re[D - k], row_l, val, pre, own);
+        __syncthreads();
+        if (do_m) mfma_plane<NB, PREC>(planeX, wblk + (size_t)k * wstride, wave, lane, acc);
+        if (k + 1 < a.K) {
+          if (do_g) gather_step<WT, RP, true>(planeX, planeY, re[D - k - 1], row_l, val, pre, own);
+          __syncthreads();
+          if (do_m) mfma_plane<NB, PREC>(planeY, wblk + (size_t)(k + 1) * wstride, wave, lane, acc);
+        }
+      }
+
+      // ---- epilogue after the last slice of a map: bias, activation, one store of y ---------
+      // The accumulator tile (column per lane, rows in registers) goes through LDS so that every
+      // store instruction writes whole 256-byte pixel rows (16 bytes per lane) instead of 128-byte
+      // fragments: a row-per-lane dword epilogue is store-issue bound (it cost 8 of 28 ms).
+      if (c == a.nchunks - 1 && !(a.dbg & 8)) {
+        constexpr int T_LD = 32 * NB + 4;  // padded row (floats) of a wave's 32 x (32*NB) tile
+        __syncthreads();                   // every wave is done reading the planes
+        float* __restrict__ tw = reinterpret_cast<float*>(smem) + wave * (32 * T_LD);
+        const int li = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            tw[((q & 3) + 8 * (q >> 2) + 4 * h) * T_LD + 32 * b + li] = acc[b][q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        constexpr int LPR = 8 * NB;    // lanes per output row (float4 each)
+        constexpr int RPI = 64 / LPR;  // rows per store instruction
+        const int cq = (lane % LPR) * 4, rsub = lane / LPR;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) {
+          bv.x = cq + 0 < a.Fout ? a.bias[cq + 0] : 0.f;
+          bv.y = cq + 1 < a.Fout ? a.bias[cq + 1] : 0.f;
+          bv.z = cq + 2 < a.Fout ? a.bias[cq + 2] : 0.f;
+          bv.w = cq + 3 < a.Fout ? a.bias[cq + 3] : 0.f;
+        }
+        const bool vec_ok = (a.Fout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+          const int row = i * RPI + rsub;
+          float4 v = *reinterpret_cast<const float4*>(tw + row * T_LD + cq);
+          v.x = apply_act(v.x + bv.x, a.act);
+          v.y = apply_act(v.y + bv.y, a.act);
+          v.z = apply_act(v.z + bv.z, a.act);
+          v.w = apply_act(v.w + bv.w, a.act);
+          const int grow = wave * 32 + row;
+          if (grow < P_t) {
+            float* __restrict__ yp = a.y + ((int64_t)n * a.y_rows + row0 + grow) * a.Fout + cq;
+            if (vec_ok && cq + 3 < a.Fout) {
+              *reinterpret_cast<float4*>(yp) = v;
+            } else {
+              if (cq + 0 < a.Fout) yp[0] = v.x;
+              if (cq + 1 < a.Fout) yp[1] = v.y;
+              if (cq + 2 < a.Fout) yp[2] = v.z;
+              if (cq + 3 < a.Fout) yp[3] = v.w;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int PR, int WT, int RPL, int NB, int PREC>
+static int launch_variant(const FusedArgs& args, int grid, size_t lds, hipStream_t stream) {
+  auto kern = cheb_fused_kernel<PR, WT, RPL, NB, PREC>;
+  DSPH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), lds, stream, args);
+  DSPH_HIP(hipGetLastError());
+  return DSPH_OK;
+}
+
+template <int PR, int WT, int RPL>
+static int dispatch_nb_prec(const FusedArgs& args, int nb, int prec, int grid, size_t lds,
+                            hipStream_t stream) {
+  if (nb == 1) {
+    if (prec == DSPH_PREC_BF16X3) return launch_variant<PR, WT, RPL, 1, DSPH_PREC_BF16X3>(args, grid, lds, stream);
+    return launch_variant<PR, WT, RPL, 1, DSPH_PREC_FP32>(args, grid, lds, stream);
+  }
+  if (prec == DSPH_PREC_BF16X3) return launch_variant<PR, WT, RPL, 2, DSPH_PREC_BF16X3>(args, grid, lds, stream);
+  return launch_variant<PR, WT, RPL, 2, DSPH_PREC_FP32>(args, grid, lds, stream);
+}
+
+// one per (plane rows, ELL width): defined in cheb_fused_inst.hip
+#define DSPH_FUSED_DECL(PR, WT) \
+  int launch_fused_##PR##_##WT(const FusedArgs& args, int nb, int prec, int grid, size_t lds, hipStream_t stream);
+DSPH_FUSED_DECL(576, 9)
+DSPH_FUSED_DECL(768, 9)
+DSPH_FUSED_DECL(928, 9)
+DSPH_FUSED_DECL(1024, 9)
+DSPH_FUSED_DECL(576, 12)
+DSPH_FUSED_DECL(768, 12)
+DSPH_FUSED_DECL(928, 12)
+DSPH_FUSED_DECL(1024, 12)
+#undef DSPH_FUSED_DECL
+
+}  // namespace dsph
