@@ -190,8 +190,8 @@ int dsph_cheb_forward(const dsph_plan* p, const float* x, const float* w, const 
   }
   if (act < DSPH_ACT_NONE || act > DSPH_ACT_TANH) { set_error("cheb_forward: unknown activation %d", act); return DSPH_E_BADARG; }
   if (precision != DSPH_PREC_FP32 && precision != DSPH_PREC_BF16X3) { set_error("cheb_forward: unknown precision %d", precision); return DSPH_E_BADARG; }
-  if (!p->levels.empty() && (int)p->levels.size() < K) {
-    set_error("cheb_forward: plan has %d levels, K = %d needs %d", (int)p->levels.size(), K, K);
+  if (!p->levels.empty() && (int)p->levels.size() < K - 1) {
+    set_error("cheb_forward: plan has %d levels, K = %d needs %d", (int)p->levels.size(), K, K - 1);
     return DSPH_E_BADARG;
   }
   if (N == 0) return DSPH_OK;

@@ -1,0 +1,207 @@
+"""Pixel-range sharding of one Chebyshev layer over the GPUs of a node (one process per GPU).
+
+The reference has no distributed code at all; this is the multi-GPU form of the
+same forward (``gnn_layers.py:106-161``).  Rows (pixels) are split into ``world`` contiguous
+ranges -- in NEST order that is whole HEALPix base pixels (or quarters of them at 8 GPUs).  A
+rank needs T_0 = x on every row within K-1 hops of its range to evaluate all K planes on its
+own rows, so the exchange step is: every rank sends the x rows the others need (packed by a HIP
+gather kernel), receives its own halo rows (point-to-point over RCCL/xGMI; no all-reduce is
+involved anywhere), and then runs the ordinary single-GPU forward on a local plan whose rows are
+ordered by hop distance (``dsph_plan_set_levels``): step k is evaluated only on the rows still
+needed.  One exchange of the (K-1)-ring halo per forward instead of K-1 one-ring exchanges: the
+same bytes in one message round, and the fused single-launch kernel keeps working.
+
+Every rank holds the whole (prepared, padded-ELL) Laplacian on the host and derives all send
+and receive lists from it deterministically, so no set-up communication is needed.
+"""
+
+import numpy as np
+import torch
+
+from . import _native
+
+__all__ = ["row_ranges", "ShardLayout", "ShardedChebyshev"]
+
+
+def row_ranges(M, world):
+    """Contiguous, balanced row ranges [(begin, end)] * world."""
+    return [(M * r // world, M * (r + 1) // world) for r in range(world)]
+
+
+class ShardLayout:
+    """What one rank needs to know: its rows, its halo by hop distance, who sends what to whom.
+
+    All index arrays are numpy int64 of *global* row ids unless called ``*_local``.
+    """
+
+    def __init__(self, ell_cols, ell_vals, K, rank, world):
+        cols = np.asarray(ell_cols)
+        vals = np.asarray(ell_vals)
+        M = cols.shape[0]
+        self.M, self.K, self.rank, self.world = M, int(K), int(rank), int(world)
+        self.ranges = row_ranges(M, world)
+        depth = max(self.K - 1, 0)
+        # hop levels of every rank's range (cheap: after the first hop only boundaries are touched)
+        self.halo = []  # per rank: list over levels 1..depth of sorted global ids
+        for (a, b) in self.ranges:
+            self.halo.append(self._levels(cols, vals, a, b, depth))
+        a, b = self.ranges[rank]
+        self.own = (a, b)
+        self.n_own = b - a
+        my = self.halo[rank]
+        self.halo_ids = np.concatenate(my) if my else np.zeros(0, np.int64)
+        # local order: own rows, then level 1, level 2, ... (each ascending)
+        self.local_ids = np.concatenate([np.arange(a, b, dtype=np.int64), self.halo_ids])
+        self.n_cols = int(self.local_ids.shape[0])
+        counts = np.cumsum([self.n_own] + [len(l) for l in my])  # rows within j hops, j = 0..depth
+        self.rows_within = counts
+        # rows that carry an ELL row: everything within K-2 hops (the outermost ring is input only)
+        self.n_rows = int(counts[depth - 1]) if depth >= 1 else self.n_own
+        # plan levels: rows_at_level[j] for j = 0..K-2 (step k is evaluated on level K-1-k)
+        self.levels = counts[:depth].astype(np.int64) if depth >= 1 else np.array([self.n_own], np.int64)
+        # local ELL with remapped columns
+        lut = np.full(M, -1, dtype=np.int64)
+        lut[self.local_ids] = np.arange(self.n_cols, dtype=np.int64)
+        rows = self.local_ids[: self.n_rows]
+        lc = lut[cols[rows]]
+        lv = vals[rows].astype(np.float32)
+        if depth == 0:  # K = 1: no product with L~ is ever taken, the local matrix is a placeholder
+            lv = np.zeros_like(lv)
+        dead = lv == 0
+        lc = np.where(dead, np.arange(self.n_rows, dtype=np.int64)[:, None], lc)
+        if (lc < 0).any():
+            raise RuntimeError("a row within K-2 hops has a neighbour outside the K-1 hop halo")
+        self.local_cols = lc.astype(np.int32)
+        self.local_vals = lv
+        # exchange lists: what I send to p = halo(p) ∩ own(me); what I receive from p = halo(me) ∩ own(p)
+        self.send_local = {}  # p -> local row indices (into my own rows) to pack, ascending global id
+        self.recv_local = {}  # p -> local positions (>= n_own) the rows from p land in
+        for p in range(world):
+            if p == rank:
+                continue
+            hp = np.concatenate(self.halo[p]) if self.halo[p] else np.zeros(0, np.int64)
+            mine = np.sort(hp[(hp >= a) & (hp < b)])
+            if mine.size:
+                self.send_local[p] = (mine - a).astype(np.int64)
+            pa, pb = self.ranges[p]
+            theirs = np.sort(self.halo_ids[(self.halo_ids >= pa) & (self.halo_ids < pb)])
+            if theirs.size:
+                self.recv_local[p] = lut[theirs]
+
+    @staticmethod
+    def _levels(cols, vals, a, b, depth):
+        M = cols.shape[0]
+        seen = np.zeros(M, dtype=bool)
+        seen[a:b] = True
+        out = []
+        frontier = np.arange(a, b, dtype=np.int64)
+        for _ in range(depth):
+            if frontier.size == 0:
+                out.append(np.zeros(0, np.int64))
+                continue
+            c = cols[frontier]
+            nb = np.unique(c[vals[frontier] != 0])
+            new = nb[~seen[nb]].astype(np.int64)
+            seen[new] = True
+            out.append(new)
+            frontier = new
+        return out
+
+
+def _pack(src, idx):
+    """buf[n, i, :] = src[n, idx[i], :].  HIP gather kernel on the GPU; plain indexing on CPU tensors
+    (reached only by the gloo tests: it moves bytes, it computes nothing)."""
+    if src.is_cuda:
+        return _native.rows_pack(src, idx)
+    return src[:, idx.long()].contiguous()
+
+
+def _unpack(dst, idx, buf):
+    if dst.is_cuda:
+        return _native.rows_unpack(dst, idx, buf)
+    dst[:, idx.long()] = buf
+    return dst
+
+
+class ShardedChebyshev:
+    """One rank's share of a Chebyshev layer whose map is split over ``world`` processes.
+
+    ``ell_cols`` / ``ell_vals``: the whole prepared Laplacian in padded ELL form (every rank passes
+    the same arrays).  ``kernel``: the layer's [Fin*K, Fout] weights (same on every rank).
+    Call with this rank's rows ``x_local`` of shape (N, own_rows, Fin); returns (N, own_rows, Fout).
+    ``group``: a torch.distributed process group (default: the world group).
+    ``_compute``: test seam -- a callable ``(layout, x_ext, kernel) -> y`` replacing the HIP forward so
+    that the exchange logic can be exercised under gloo on CPU; never set by product code.
+    """
+
+    def __init__(self, ell_cols, ell_vals, K, Fout=None, rank=0, world=1, device=None, precision="fp32",
+                 algo="auto", kernel=None, bias=None, act=_native.ACT_NONE, group=None, _compute=None):
+        self.layout = ShardLayout(ell_cols, ell_vals, K, rank, world)
+        self.K, self.rank, self.world = int(K), int(rank), int(world)
+        self.own_rows = self.layout.n_own
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.group = group
+        self._compute = _compute
+        self.precision = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3}[precision]
+        self.algo = {"auto": _native.ALGO_AUTO, "unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}[algo]
+        self.act = act
+        self.kernel = None if kernel is None else torch.as_tensor(np.asarray(kernel), dtype=torch.float32).to(self.device)
+        self.bias = None if bias is None else torch.as_tensor(np.asarray(bias), dtype=torch.float32).reshape(-1).to(self.device)
+        self.Fout = Fout if Fout is not None else (None if self.kernel is None else int(self.kernel.shape[1]))
+        lay = self.layout
+        self._send_idx = {p: torch.as_tensor(v.astype(np.int32)).to(self.device) for p, v in lay.send_local.items()}
+        self._recv_idx = {p: torch.as_tensor(v.astype(np.int32)).to(self.device) for p, v in lay.recv_local.items()}
+        self.plan = None
+        self.fused = False
+        if _compute is None:
+            if self.device.type != "cuda":
+                raise RuntimeError("ShardedChebyshev computes on a HIP device only; there is no CPU fallback")
+            self.plan = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols,
+                                              device=self.device.index, levels=lay.levels)
+        self._x_ext = None
+        self._workspace = None
+
+    def exchange(self, x_local):
+        """(N, own, F) -> (N, n_cols, F): own rows followed by the halo rows fetched from their owners."""
+        import torch.distributed as dist
+
+        lay = self.layout
+        N, own, F = x_local.shape
+        if own != lay.n_own:
+            raise ValueError(f"this rank owns {lay.n_own} rows, got {own}")
+        if self._x_ext is None or tuple(self._x_ext.shape) != (N, lay.n_cols, F):
+            self._x_ext = torch.empty((N, lay.n_cols, F), dtype=torch.float32, device=x_local.device)
+        x_ext = self._x_ext
+        x_ext[:, :own].copy_(x_local)
+        if self.world == 1 or not (self._send_idx or self._recv_idx):
+            return x_ext
+        ops, recv_bufs, keep = [], {}, []
+        for p, idx in self._send_idx.items():
+            buf = _pack(x_ext, idx)
+            keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, self._peer(p), group=self.group))
+        for p, idx in self._recv_idx.items():
+            buf = torch.empty((N, idx.numel(), F), dtype=torch.float32, device=x_local.device)
+            recv_bufs[p] = buf
+            ops.append(dist.P2POp(dist.irecv, buf, self._peer(p), group=self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for p, buf in recv_bufs.items():
+            _unpack(x_ext, self._recv_idx[p], buf)
+        return x_ext
+
+    def _peer(self, p):
+        import torch.distributed as dist
+
+        return p if self.group is None else dist.get_global_rank(self.group, p)
+
+    def __call__(self, x_local):
+        x_ext = self.exchange(x_local)
+        if self._compute is not None:
+            return self._compute(self.layout, x_ext, self.kernel)
+        y, self._workspace = _native.cheb_forward(self.plan, x_ext, self.kernel, self.bias, self.K, act=self.act,
+                                                  precision=self.precision, algo=self.algo,
+                                                  workspace=self._workspace)
+        Fin = x_local.shape[2]
+        self.fused = self.plan.fused_ok(Fin, int(self.kernel.shape[1]), self.K) and self.algo != _native.ALGO_UNFUSED
+        return y

@@ -69,8 +69,9 @@ void dsph_plan_destroy(dsph_plan* plan);
  * rows it owns (sharded, deep-halo mode): rows_at_level[j] = number of leading rows within j
  * hops of the owned rows, j = 0..n_levels-1, non-decreasing, rows_at_level[0] = owned rows,
  * rows_at_level[n_levels-1] <= n_rows.  With a schedule, recurrence step k of a K-term forward
- * is evaluated on rows_at_level[K-1-k] rows and y is written for rows_at_level[0] rows.
- * Without one every step covers n_rows rows.  Host array, copied. */
+ * is evaluated on rows_at_level[K-1-k] rows (so a K-term forward needs n_levels >= K-1) and y
+ * is written for rows_at_level[0] rows.  Without one every step covers n_rows rows.
+ * Host array, copied. */
 int dsph_plan_set_levels(dsph_plan* plan, int32_t n_levels, const int64_t* rows_at_level);
 
 int64_t dsph_plan_rows(const dsph_plan* plan);

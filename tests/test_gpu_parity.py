@@ -332,3 +332,41 @@ def test_full_size_properties(nside, N, Fin, Fout, K, algo):
     lin = 0.5 * y1 - 2.0 * y2
     err = (y3 - lin).abs().max().item() / lin.abs().max().item()
     assert err < 2e-5
+
+
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("algo", ["unfused", "fused"])
+def test_sharded_plans_on_one_gpu(world, algo):
+    # every rank's local plan (rows ordered by hop distance, shrinking schedule) run one after the
+    # other on this GPU, the halo taken from the global map by indexing: stitched == unsharded
+    from deepsphere import sharding
+
+    L = healpix.healpix_laplacian(16, mode="grid")
+    Lt, _ = orc.prepare_L(L)
+    cols, vals = utils.csr_to_ell(Lt)
+    M, K, Fin, Fout, N = cols.shape[0], 5, 16, 32, 2
+    rng = np.random.default_rng(world)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    a_code = {"unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}[algo]
+    full, _ = _native.cheb_forward(_plan(Lt), _dev(x), _dev(W), None, K, algo=a_code)
+    ref = orc.chebyshev_forward(Lt, x, W, K)
+    assert rel_err(full.cpu().numpy(), ref) < TOL_FP32
+    for r in range(world):
+        lay = sharding.ShardLayout(cols, vals, K, r, world)
+        plan = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols, device=0, levels=lay.levels)
+        y, _ = _native.cheb_forward(plan, _dev(x[:, lay.local_ids]), _dev(W), None, K, algo=a_code)
+        a, b = lay.own
+        assert tuple(y.shape) == (N, b - a, Fout)
+        assert rel_err(y.cpu().numpy(), ref[:, a:b]) < TOL_FP32
+        assert torch.equal(y, full[:, a:b]), "a shard must reproduce the unsharded rows bit for bit"
+
+
+def test_sharded_layer_world_one():
+    from deepsphere import sharding
+
+    c = load_case("n8_k5")
+    cols, vals = utils.csr_to_ell(c["Lt"])
+    sh = sharding.ShardedChebyshev(cols, vals, c["K"], rank=0, world=1, device="cuda:0", kernel=c["kernel"])
+    y = sh(_dev(c["x"]))
+    assert rel_err(y.cpu().numpy(), c["y"]) < TOL_FP32
