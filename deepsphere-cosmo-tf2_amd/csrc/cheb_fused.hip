@@ -14,7 +14,8 @@
 //
 // Data layout (device):
 //   region_rows[tile_off[t] ..]   row ids of tile t's region, ring 0 (the tile's own rows, in
-//                                 order) first, then ring 1, ... ring D, each ring ascending
+//                                 order) first, then ring 1, ... ring D, each ring ordered so that
+//                                 (local index & 3) == (row id & 3) where the ring's mix allows
 //   ring_end[t][r]                number of region entries within r hops (r = 0..D)
 //   lcols/lvals                   tile-local ELL of the rows within D-1 hops, column = index into
 //                                 the region list (uint16), stored [slot][row] per tile so that
@@ -151,6 +152,30 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
         }
       }
       std::sort(next.begin(), next.end());
+      // Emit the ring so that (local index & 3) == (row id & 3) wherever possible.  On a HEALPix map
+      // the low two NEST bits are the pixel's (x, y) parity; the recurrence reads the j-th neighbours
+      // of four rows with four different parities in one LDS access group, and those neighbours then
+      // sit in four different bank quarters -- halo rows included, not only the tile's own rows.
+      {
+        std::vector<int32_t> bucket[4];
+        for (int32_t r : next) bucket[r & 3].push_back(r);
+        size_t head[4] = {0, 0, 0, 0};
+        size_t left = next.size();
+        next.clear();
+        while (left > 0) {
+          const int want = (int)((region.size() - base + next.size()) & 3);
+          int take = want;
+          if (head[take] >= bucket[take].size()) {  // that parity is used up: take from the fullest
+            size_t best = 0;
+            for (int q = 0; q < 4; ++q) {
+              const size_t rem = bucket[q].size() - head[q];
+              if (rem > best) { best = rem; take = q; }
+            }
+          }
+          next.push_back(bucket[take][head[take]++]);
+          --left;
+        }
+      }
       for (int32_t r : next) {
         local[r] = (int32_t)(region.size() - base);
         region.push_back(r);

@@ -123,7 +123,9 @@ template <int PR, int WT, int RP, int NB, int PREC>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs a) {
   constexpr int PLANE_BYTES = PR * FUSED_CH * 4;
   constexpr int NS = (PR * 4 + FUSED_THREADS - 1) / FUSED_THREADS;  // staging float4 per lane
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // all of the CU's LDS, statically: the base is then a compile-time constant that folds into the
+  // ds_read/ds_write offset fields (a dynamic LDS symbol costs one v_add per access)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
   unsigned char* const planeX = smem;
   unsigned char* const planeY = smem + PLANE_BYTES;
   unsigned char* const sW = smem + 2 * PLANE_BYTES;
@@ -297,9 +299,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
 template <int PR, int WT, int RPL, int NB, int PREC>
 static int launch_variant(const FusedArgs& args, int grid, size_t lds, hipStream_t stream) {
   auto kern = cheb_fused_kernel<PR, WT, RPL, NB, PREC>;
-  DSPH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), lds, stream, args);
+  (void)lds;  // the kernel declares the whole LDS statically
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), 0, stream, args);
   DSPH_HIP(hipGetLastError());
   return DSPH_OK;
 }
