@@ -82,14 +82,32 @@ __device__ __forceinline__ void mfma_plane(const unsigned char* __restrict__ pla
   }
 }
 
+// The four lanes that share a region row keep that row's ELL values spread over the quad: register g
+// of lane q holds val[4g + q].  A quad-broadcast DPP move fetches val[j] for all four lanes, so a row
+// costs ceil(WT/4) value registers per lane instead of WT.
+__device__ __forceinline__ float quad_bcast(float v, int lane_in_quad) {
+  // dpp_ctrl quad_perm:[b,b,b,b] = b * 0x55; all rows and banks enabled
+  const int iv = __builtin_bit_cast(int, v);
+  int r;
+  switch (lane_in_quad) {
+    case 0: r = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xf, 0xf, false); break;
+    case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xf, 0xf, false); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xf, 0xf, false); break;
+    default: r = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xf, 0xf, false); break;
+  }
+  return __builtin_bit_cast(float, r);
+}
+
 // One recurrence step: out = (HAS_PREV ? 2 : 1) * (L~ in) - (HAS_PREV ? out : 0) on rows [0, nrows).
 // Lane (row_l, slot) owns rows row_l + 128 p, p = 0..RP-1, and one 16-byte slot (4 channels) of them;
-// the ELL values and the swizzled LDS addresses of those rows' neighbours live in registers.  The
-// summation order (slot j ascending, fused multiply-add) is the unfused kernel's.
+// the ELL values (quad-packed) and the swizzled LDS addresses of those rows' neighbours live in
+// registers.  The summation order (slot j ascending, fused multiply-add) is the unfused kernel's.
+// Every lane of a quad must execute the broadcasts, so the row guard covers whole quads (it does:
+// the four lanes of a quad share the row).
 template <int WT, int RP, bool HAS_PREV>
 __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pin,
                                             unsigned char* __restrict__ pout, int nrows, int row_l,
-                                            const float (&val)[RP][WT], const unsigned (&pre)[RP][WT],
+                                            const float (&valc)[RP][(WT + 3) / 4], const unsigned (&pre)[RP][WT],
                                             const unsigned (&own)[RP]) {
 #pragma unroll
   for (int p = 0; p < RP; ++p) {
@@ -98,10 +116,11 @@ __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pi
 #pragma unroll
       for (int j = 0; j < WT; ++j) {
         const float4 v = *reinterpret_cast<const float4*>(pin + pre[p][j]);
-        s.x = fmaf(val[p][j], v.x, s.x);
-        s.y = fmaf(val[p][j], v.y, s.y);
-        s.z = fmaf(val[p][j], v.z, s.z);
-        s.w = fmaf(val[p][j], v.w, s.w);
+        const float w = quad_bcast(valc[p][j >> 2], j & 3);
+        s.x = fmaf(w, v.x, s.x);
+        s.y = fmaf(w, v.y, s.y);
+        s.z = fmaf(w, v.z, s.z);
+        s.w = fmaf(w, v.w, s.w);
       }
       float4* op = reinterpret_cast<float4*>(pout + own[p]);
       if (HAS_PREV) {
@@ -182,21 +201,20 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     const int64_t row0 = (int64_t)t * FUSED_P;
 
     // this lane's recurrence rows: ELL values and swizzled LDS byte addresses stay in registers
-    float val[RP][WT];
+    float val[RP][(WT + 3) / 4];  // quad-packed: register g of lane q holds the row's value 4g + q
     unsigned pre[RP][WT], own[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
       const int i = row_l + p * G_ROWS;
       own[p] = plane_byte((unsigned)(i < PR ? i : 0), qslot);
 #pragma unroll
+      for (int g = 0; g < (WT + 3) / 4; ++g) {
+        const int j = 4 * g + (int)qslot;
+        val[p][g] = (i < E && j < WT) ? a.lvals[lbase + (int64_t)j * E + i] : 0.f;
+      }
+#pragma unroll
       for (int j = 0; j < WT; ++j) {
-        float v = 0.f;
-        unsigned c = 0;
-        if (i < E) {
-          v = a.lvals[lbase + (int64_t)j * E + i];
-          c = a.lcols[lbase + (int64_t)j * E + i];
-        }
-        val[p][j] = v;
+        const unsigned c = i < E ? a.lcols[lbase + (int64_t)j * E + i] : 0u;
         pre[p][j] = plane_byte(c, qslot);
       }
     }
