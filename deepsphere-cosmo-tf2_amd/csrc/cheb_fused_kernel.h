@@ -189,14 +189,86 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     }
   };
 
+  // ---- y store of a finished map, deferred into the next item's slot 0 ---------------------------
+  // The accumulator tile (column per lane, rows in registers) goes through LDS so that a store
+  // instruction writes whole 128-byte row halves, 16 bytes per lane (a row-per-lane dword epilogue is
+  // store-issue bound: it cost 8 of 28 ms).  It runs after the next slice has been staged and the
+  // prefetch after that has been issued, in plane Y (free during slot 0), 32 columns at a time: the
+  // stores then have a whole item to drain before the next wait on the memory counter, instead of
+  // stalling the staging that follows them.
+  f32x16 acc[NB];
+  bool pend = false;
+  int pend_n = 0, pend_Pt = 0;
+  int64_t pend_row0 = 0;
+  auto store_pending = [&]() {
+    constexpr int T_LD = 36;  // padded row (floats) of a wave's 32 x 32 block; 8 waves fill plane Y exactly
+    float* __restrict__ tw = reinterpret_cast<float*>(planeY) + wave * (32 * T_LD);
+    const int li = lane & 31, h = lane >> 5;
+    const int cq0 = (lane & 7) * 4, rsub = lane >> 3;
+    const bool vec_ok = (a.Fout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tw[((q & 3) + 8 * (q >> 2) + 4 * h) * T_LD + li] = acc[b][q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int cq = 32 * b + cq0;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias) {
+        bv.x = cq + 0 < a.Fout ? a.bias[cq + 0] : 0.f;
+        bv.y = cq + 1 < a.Fout ? a.bias[cq + 1] : 0.f;
+        bv.z = cq + 2 < a.Fout ? a.bias[cq + 2] : 0.f;
+        bv.w = cq + 3 < a.Fout ? a.bias[cq + 3] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + rsub;
+        float4 v = *reinterpret_cast<const float4*>(tw + row * T_LD + cq0);
+        v.x = apply_act(v.x + bv.x, a.act);
+        v.y = apply_act(v.y + bv.y, a.act);
+        v.z = apply_act(v.z + bv.z, a.act);
+        v.w = apply_act(v.w + bv.w, a.act);
+        const int grow = wave * 32 + row;
+        if (grow < pend_Pt) {
+          float* __restrict__ yp = a.y + ((int64_t)pend_n * a.y_rows + pend_row0 + grow) * a.Fout + cq;
+          if (vec_ok && cq + 3 < a.Fout) {
+            *reinterpret_cast<float4*>(yp) = v;
+          } else {
+            if (cq + 0 < a.Fout) yp[0] = v.x;
+            if (cq + 1 < a.Fout) yp[1] = v.y;
+            if (cq + 2 < a.Fout) yp[2] = v.z;
+            if (cq + 3 < a.Fout) yp[3] = v.w;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    pend = false;
+  };
+
   int t = t_begin + slot0;
   if (t < t_end) {
     load_rids(t);
     issue_loads(0);
   }
   for (; t < t_end; t += nslots) {
-    const int32_t* __restrict__ re = a.ring_end + (size_t)t * (FUSED_DMAX + 1);
-    const int P_t = re[0], E = re[D - 1];
+    // ring sizes of this tile, 11 bits each, in two scalar registers (re-reading them from memory
+    // in every step would put a dependent scalar load in front of each recurrence step)
+    const int32_t* __restrict__ re_mem = a.ring_end + (size_t)t * (FUSED_DMAX + 1);
+    unsigned long long re_lo = 0, re_hi = 0;
+#pragma unroll
+    for (int r = 0; r <= FUSED_DMAX; ++r) {
+      const unsigned long long v = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(re_mem[r]) & 0x7ffull;
+      if (r < 5) re_lo |= v << (11 * r);
+      else re_hi |= v << (11 * (r - 5));
+    }
+    auto re = [&](int r) -> int {
+      return (int)(((r < 5 ? re_lo >> (11 * r) : re_hi >> (11 * (r - 5)))) & 0x7ffull);
+    };
+    const int P_t = re(0), E = re(D - 1);
     const int64_t lbase = a.ell_off[t] * WT;
     const int64_t row0 = (int64_t)t * FUSED_P;
 
@@ -219,16 +291,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       }
     }
 
-    f32x16 acc[NB];
     for (int item = 0; item < items; ++item) {
       const int n = item / a.nchunks, c = item - n * a.nchunks;
-      if (c == 0) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
-      }
-      __syncthreads();  // the previous slice's last plane (or the y transposition) is still being read
+      __syncthreads();  // the previous slice's last plane is still being read
       // ---- T_0: the prefetched x slice goes to plane X; fetch the next slice meanwhile -------
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -241,76 +306,43 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
         load_rids(t + nslots);
         issue_loads(0);
       }
+      if (pend && !(a.dbg & 8)) store_pending();
+      if (c == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+      }
       __syncthreads();
       const unsigned char* __restrict__ wblk = sW + (size_t)c * NB * 2048;
       if (do_m) mfma_plane<NB, PREC>(planeX, wblk, wave, lane, acc);
 
       // ---- recurrence, two steps per trip so that the plane roles are compile-time ----------
-      if (do_g) gather_step<WT, RP, false>(planeX, planeY, re[D - 1], row_l, val, pre, own);
+      if (do_g) gather_step<WT, RP, false>(planeX, planeY, re(D - 1), row_l, val, pre, own);
       __syncthreads();
       if (do_m) mfma_plane<NB, PREC>(planeY, wblk + wstride, wave, lane, acc);
       for (int k = 2; k < a.K; k += 2) {
-        if (do_g) gather_step<WT, RP, true>(planeY, planeX, re[D - k], row_l, val, pre, own);
+        if (do_g) gather_step<WT, RP, true>(planeY, planeX, re(D - k), row_l, val, pre, own);
         __syncthreads();
         if (do_m) mfma_plane<NB, PREC>(planeX, wblk + (size_t)k * wstride, wave, lane, acc);
         if (k + 1 < a.K) {
-          if (do_g) gather_step<WT, RP, true>(planeX, planeY, re[D - k - 1], row_l, val, pre, own);
+          if (do_g) gather_step<WT, RP, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
           __syncthreads();
           if (do_m) mfma_plane<NB, PREC>(planeY, wblk + (size_t)(k + 1) * wstride, wave, lane, acc);
         }
       }
 
-      // ---- epilogue after the last slice of a map: bias, activation, one store of y ---------
-      // The accumulator tile (column per lane, rows in registers) goes through LDS so that every
-      // store instruction writes whole 256-byte pixel rows (16 bytes per lane) instead of 128-byte
-      // fragments: a row-per-lane dword epilogue is store-issue bound (it cost 8 of 28 ms).
-      if (c == a.nchunks - 1 && !(a.dbg & 8)) {
-        constexpr int T_LD = 32 * NB + 4;  // padded row (floats) of a wave's 32 x (32*NB) tile
-        __syncthreads();                   // every wave is done reading the planes
-        float* __restrict__ tw = reinterpret_cast<float*>(smem) + wave * (32 * T_LD);
-        const int li = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int q = 0; q < 16; ++q)
-            tw[((q & 3) + 8 * (q >> 2) + 4 * h) * T_LD + 32 * b + li] = acc[b][q];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        constexpr int LPR = 8 * NB;    // lanes per output row (float4 each)
-        constexpr int RPI = 64 / LPR;  // rows per store instruction
-        const int cq = (lane % LPR) * 4, rsub = lane / LPR;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) {
-          bv.x = cq + 0 < a.Fout ? a.bias[cq + 0] : 0.f;
-          bv.y = cq + 1 < a.Fout ? a.bias[cq + 1] : 0.f;
-          bv.z = cq + 2 < a.Fout ? a.bias[cq + 2] : 0.f;
-          bv.w = cq + 3 < a.Fout ? a.bias[cq + 3] : 0.f;
-        }
-        const bool vec_ok = (a.Fout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
-#pragma unroll
-        for (int i = 0; i < 32 / RPI; ++i) {
-          const int row = i * RPI + rsub;
-          float4 v = *reinterpret_cast<const float4*>(tw + row * T_LD + cq);
-          v.x = apply_act(v.x + bv.x, a.act);
-          v.y = apply_act(v.y + bv.y, a.act);
-          v.z = apply_act(v.z + bv.z, a.act);
-          v.w = apply_act(v.w + bv.w, a.act);
-          const int grow = wave * 32 + row;
-          if (grow < P_t) {
-            float* __restrict__ yp = a.y + ((int64_t)n * a.y_rows + row0 + grow) * a.Fout + cq;
-            if (vec_ok && cq + 3 < a.Fout) {
-              *reinterpret_cast<float4*>(yp) = v;
-            } else {
-              if (cq + 0 < a.Fout) yp[0] = v.x;
-              if (cq + 1 < a.Fout) yp[1] = v.y;
-              if (cq + 2 < a.Fout) yp[2] = v.z;
-              if (cq + 3 < a.Fout) yp[3] = v.w;
-            }
-          }
-        }
+      if (c == a.nchunks - 1) {  // this map's accumulators are complete: store them in the next slot 0
+        pend = true;
+        pend_n = n;
+        pend_row0 = row0;
+        pend_Pt = P_t;
       }
     }
+  }
+  if (pend && !(a.dbg & 8)) {  // the last map of this workgroup
+    __syncthreads();
+    store_pending();
   }
 }
 
