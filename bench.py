@@ -131,7 +131,9 @@ def main():
         )
         gen = torch.Generator(device=device).manual_seed(11)
         x = torch.randn((N, M, Fin), device=device, generator=gen)
-        run = lambda: layer(x)  # noqa: E731
+        def run():
+            with torch.no_grad():  # inference forward: bias/activation fused in the kernel epilogue
+                return layer(x)
         fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
         kernel_name = "cheb_fused_kernel" if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
     else:

@@ -10,6 +10,7 @@ forward raises; there is no CPU path in this package.
 
 import numpy as np
 import torch
+from scipy import sparse
 
 from . import _native
 from . import utils
@@ -55,6 +56,62 @@ def _resolve_activation(activation):
     if isinstance(activation, str) and activation in _ACT_BY_NAME:
         return _ACT_BY_NAME[activation]
     raise ValueError(f"Could not find activation <{activation}> in tf.keras.activations...")
+
+
+class _ChebConvFunction(torch.autograd.Function):
+    """y = sum_k T_k(L~) x W_k as a differentiable op (no bias, no activation).
+
+    The reference defines no custom gradient -- TensorFlow differentiates the op sequence of
+    ``gnn_layers.py:131-150``.  Here the backward is assembled from the same HIP kernels:
+
+    * dx = sum_k T_k(L~)^T (dy W_k^T) is the *forward* of the layer on dy with the plan of L~^T (the
+      same plan when L~ is symmetric, as every graph Laplacian is) and the weights re-indexed as
+      kernel_T[o*K + k, f] = kernel[f*K + k, o];
+    * dkernel[f*K + k, o] = sum_{n,m} (T_k x)[n,m,f] dy[n,m,o]: the planes are rebuilt one at a time
+      with ``dsph_cheb_step`` (three alive at any moment) and contracted against dy by a plain
+      library GEMM (rocBLAS through torch.matmul).
+    """
+
+    @staticmethod
+    def forward(ctx, x, kernel, layer):
+        plan = layer._get_plan()
+        y, layer._workspace = _native.cheb_forward(
+            plan, x, kernel.detach(), None, layer.K, act=_native.ACT_NONE,
+            precision=_PRECISIONS[layer.precision], algo=_ALGOS[layer.algo], workspace=layer._workspace)
+        ctx.layer = layer
+        ctx.save_for_backward(x, kernel)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer = ctx.layer
+        x, kernel = ctx.saved_tensors
+        K = layer.K
+        N, M, Fin = x.shape
+        Fout = kernel.shape[1]
+        dy = dy.contiguous()
+        dx = dk = None
+        if ctx.needs_input_grad[0]:
+            plan_t = layer._get_plan(transposed=True)
+            kernel_t = kernel.detach().reshape(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()
+            dx, layer._workspace_t = _native.cheb_forward(
+                plan_t, dy, kernel_t, None, K, act=_native.ACT_NONE, precision=_PRECISIONS[layer.precision],
+                algo=_ALGOS[layer.algo], workspace=layer._workspace_t)
+        if ctx.needs_input_grad[1]:
+            plan = layer._get_plan()
+            dyf = dy.reshape(N * M, Fout)
+            dk = torch.empty((Fin, K, Fout), dtype=torch.float32, device=x.device)
+            p_prev2, p_prev = None, x
+            dk[:, 0] = torch.matmul(x.reshape(N * M, Fin).t(), dyf)
+            for k in range(1, K):
+                if k == 1:
+                    p = _native.cheb_step(plan, p_prev, None, 1.0, 0.0)
+                else:
+                    p = _native.cheb_step(plan, p_prev, p_prev2, 2.0, 1.0, out=p_prev2 if k > 2 else None)
+                dk[:, k] = torch.matmul(p.reshape(N * M, Fin).t(), dyf)
+                p_prev2, p_prev = p_prev, p
+            dk = dk.reshape(Fin * K, Fout)
+        return dx, dk, None
 
 
 class Chebyshev(torch.nn.Module):
@@ -124,7 +181,9 @@ class Chebyshev(torch.nn.Module):
         self._ell_cols, self._ell_vals = utils.csr_to_ell(Lt)
         self._nnz = int(Lt.nnz)
         self._plan = None
+        self._plan_t = None
         self._workspace = None
+        self._workspace_t = None
         self.kernel = None
         self.bias = None
         self._built = False
@@ -165,7 +224,7 @@ class Chebyshev(torch.nn.Module):
                 self._device = torch.device("cpu")  # weights can be created; forward will refuse
         return self._device
 
-    def _get_plan(self):
+    def _get_plan(self, transposed=False):
         if self._plan is None:
             _native.require_gpu()
             dev = self._resolve_device(None)
@@ -174,7 +233,23 @@ class Chebyshev(torch.nn.Module):
             index = dev.index if dev.index is not None else torch.cuda.current_device()
             self._device = torch.device("cuda", index)
             self._plan = _native.LaplacianPlan(self._ell_cols, self._ell_vals, device=index)
-        return self._plan
+        if not transposed:
+            return self._plan
+        if getattr(self, "_plan_t", None) is None:
+            # the backward applies T_k(L~)^T; a symmetric L~ (every graph Laplacian) reuses the plan
+            M, W = self._ell_cols.shape
+            rows = np.repeat(np.arange(M, dtype=np.int64), W)
+            A = sparse.csr_matrix((self._ell_vals.reshape(-1), (rows, self._ell_cols.reshape(-1).astype(np.int64))),
+                                  shape=(M, M))
+            A.sum_duplicates()
+            if abs(A - A.T).max() == 0:
+                self._plan_t = self._plan
+            else:
+                At = A.T.tocsr()
+                At.sort_indices()
+                tc, tv = utils.csr_to_ell(At)
+                self._plan_t = _native.LaplacianPlan(tc, tv, device=self._device.index)
+        return self._plan_t
 
     # -- forward --------------------------------------------------------------------------------
     def forward(self, input_tensor, training=None):
@@ -196,6 +271,23 @@ class Chebyshev(torch.nn.Module):
         if Fin != self._Fin:
             raise ValueError(f"layer was built for Fin = {self._Fin}, got {Fin}")
         plan = self._get_plan()
+        wants_grad = torch.is_grad_enabled() and (
+            self.kernel.requires_grad or input_tensor.requires_grad or (self.use_bias and self.bias.requires_grad))
+        if wants_grad:
+            # differentiable path: the linear part through the autograd function above, the epilogue
+            # (BN -> bias -> activation, gnn_layers.py:152-159) as ordinary torch ops
+            x = input_tensor.to(device=self._device, dtype=torch.float32).contiguous()
+            y = _ChebConvFunction.apply(x, self.kernel, self)
+            if self.use_bn:
+                was_training = self.bn.training
+                self.bn.train(self.training if training is None else bool(training))
+                y = self.bn(y.transpose(1, 2)).transpose(1, 2)
+                self.bn.train(was_training)
+            if self.use_bias:
+                y = y + self.bias
+            if self.activation is not None:
+                y = self.activation(y)
+            return y
         x = input_tensor.detach().to(device=self._device, dtype=torch.float32).contiguous()
         bias = self.bias.detach().reshape(-1).contiguous() if self.use_bias else None
 
@@ -255,7 +347,9 @@ class Chebyshev(torch.nn.Module):
         self._ell_cols, self._ell_vals = cols, vals
         self._nnz = int(np.count_nonzero(vals))
         self._plan = None
+        self._plan_t = None
         self._workspace = None
+        self._workspace_t = None
         self.kernel = None
         self.bias = None
         self._built = False

@@ -206,3 +206,33 @@ def chebyshev_forward_closed_form(Lt, x, kernel, K, dtype=np.float64):
 def default_kernel_stddev(Fin, K):
     """Scale of the reference's default TruncatedNormal initialiser (gnn_layers.py:92)."""
     return 1.0 / np.sqrt(Fin * (K + 0.5) / 2.0)
+
+
+# ----------------------------------------------------------------------------------------
+# backward (SURVEY 8 f1).  The reference defines no custom gradient: TensorFlow differentiates the
+# op sequence of gnn_layers.py:131-150.  These are the closed forms of that derivative.
+# ----------------------------------------------------------------------------------------
+
+
+def chebyshev_backward(Lt, x, kernel, K, dy, dtype=np.float64):
+    """Gradients of  y = chebyshev_forward(Lt, x, kernel, K)  (no bias / activation) w.r.t. x and
+    kernel for an upstream gradient dy (N, M, Fout).
+
+        dkernel[f*K + k, o] = sum_{n,m} (T_k(Lt) x)[n,m,f] * dy[n,m,o]
+        dx                  = sum_k T_k(Lt)^T (dy @ kernel[:, k, :]^T)
+
+    Lt need not be symmetric (the layer accepts any L, gnn_layers.py:17)."""
+    x = np.asarray(x, dtype=dtype)
+    dy = np.asarray(dy, dtype=dtype)
+    kernel = np.asarray(kernel, dtype=dtype)
+    N, M, Fin = x.shape
+    Fout = kernel.shape[1]
+    planes = chebyshev_planes(Lt, x, K, dtype=dtype)  # (K, N, M, Fin)
+    dW = np.einsum("knmf,nmo->fko", planes, dy).reshape(Fin * K, Fout)
+    Wr = kernel.reshape(Fin, K, Fout)
+    LtT = sparse.csr_matrix(Lt).T.tocsr()
+    dx = np.zeros_like(x)
+    for k in range(K):
+        g = dy @ Wr[:, k, :].T  # (N, M, Fin)
+        dx += chebyshev_planes(LtT, g, k + 1, dtype=dtype)[k]
+    return dx, dW

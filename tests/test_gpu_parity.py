@@ -148,6 +148,13 @@ def test_bitwise_determinism():
         assert torch.equal(y0, y1)
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    # the layer tests check the forward; the gradient tests below switch autograd back on
+    with torch.no_grad():
+        yield
+
+
 def test_layer_like_reference_tests():
     # tests/test_gnn_layers.py:9-33 shapes, values checked against the oracle
     c = load_case("dense3")
@@ -370,3 +377,63 @@ def test_sharded_layer_world_one():
     sh = sharding.ShardedChebyshev(cols, vals, c["K"], rank=0, world=1, device="cuda:0", kernel=c["kernel"])
     y = sh(_dev(c["x"]))
     assert rel_err(y.cpu().numpy(), c["y"]) < TOL_FP32
+
+
+@pytest.mark.parametrize("graph,use_bias,activation", [("knn", True, "relu"), ("grid", False, None), ("nonsym", True, "tanh")])
+def test_layer_gradients_match_oracle(graph, use_bias, activation):
+    # dx, dkernel (and dbias) from the HIP kernels vs the oracle's closed forms
+    rng = np.random.default_rng(31)
+    if graph == "nonsym":
+        M = 300
+        L = sparse.random(M, M, density=0.03, random_state=rng, format="csr") + sparse.identity(M)
+    else:
+        L = healpix.healpix_laplacian(8, mode=graph)
+        M = L.shape[0]
+    N, Fin, Fout, K = 2, 16, 8, 4
+    x_np = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W_np = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    dy_np = rng.standard_normal((N, M, Fout)).astype(np.float32)
+    with torch.enable_grad():
+        layer = gnn_layers.Chebyshev(L=L, K=K, Fout=Fout, use_bias=use_bias, activation=activation,
+                                     initializer=lambda t: t.copy_(torch.from_numpy(W_np)))
+        x = _dev(x_np).requires_grad_(True)
+        y = layer(x)
+        assert y.requires_grad
+        y.backward(_dev(dy_np))
+    Lt = sparse.csr_matrix(L, dtype=np.float64)
+    Lt = (Lt * (1.5 / layer.lmax) - sparse.identity(M)).tocsr().astype(np.float32)  # the layer's own L~
+    b = layer.bias.detach().cpu().numpy().reshape(-1) if use_bias else None
+    z = orc.chebyshev_forward(Lt, x_np, W_np, K, bias=b)
+    if activation == "relu":
+        dz = dy_np * (z > 0)
+    elif activation == "tanh":
+        dz = dy_np * (1 - np.tanh(z) ** 2)
+    else:
+        dz = dy_np
+    dx_ref, dW_ref = orc.chebyshev_backward(Lt, x_np, W_np, K, dz)
+    assert rel_err(y.detach().cpu().numpy(), orc.chebyshev_forward(Lt, x_np, W_np, K, bias=b, activation=activation)) < 2e-5
+    assert rel_err(x.grad.cpu().numpy(), dx_ref) < 2e-5
+    assert rel_err(layer.kernel.grad.cpu().numpy(), dW_ref) < 2e-5
+    if use_bias:
+        assert rel_err(layer.bias.grad.cpu().numpy().reshape(-1), dz.sum((0, 1))) < 2e-5
+
+
+def test_layer_trains():
+    # a few SGD steps on a regression target reduce the loss (the reference's training loops rely on
+    # TF autodiff of the same ops, examples/advanced_tutorial.ipynb cell 28)
+    L = healpix.healpix_laplacian(8, mode="grid")
+    rng = np.random.default_rng(5)
+    x = _dev(rng.standard_normal((4, L.shape[0], 8)).astype(np.float32))
+    target = _dev(rng.standard_normal((4, L.shape[0], 4)).astype(np.float32))
+    with torch.enable_grad():
+        layer = gnn_layers.Chebyshev(L=L, K=5, Fout=4, use_bias=True)
+        layer(x)  # build
+        opt = torch.optim.SGD(layer.parameters(), lr=0.05)
+        losses = []
+        for _ in range(8):
+            opt.zero_grad()
+            loss = ((layer(x) - target) ** 2).mean()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+    assert losses[-1] < 0.9 * losses[0]

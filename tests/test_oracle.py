@@ -153,3 +153,28 @@ def test_cpu_baseline_port_matches_oracle():
     c = load_case("n8_k5")
     y = cb.forward_fp32(cb.to_torch_csr(c["Lt"]), torch.from_numpy(c["x"]), torch.from_numpy(c["kernel"]), c["K"])
     assert rel_err(y.numpy(), c["y"]) < 1e-5
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_backward_closed_form_matches_finite_differences(symmetric):
+    rng = np.random.default_rng(21)
+    M, N, Fin, Fout, K = 13, 2, 3, 2, 4
+    if symmetric:
+        Lt, _ = orc.prepare_L(_rand_graph_L(M, seed=5))
+    else:
+        Lt = sparse.random(M, M, density=0.3, random_state=rng, format="csr") * 0.3
+    Lt = sparse.csr_matrix(Lt).astype(np.float64)
+    x = rng.standard_normal((N, M, Fin))
+    W = rng.standard_normal((Fin * K, Fout))
+    dy = rng.standard_normal((N, M, Fout))
+    dx, dW = orc.chebyshev_backward(Lt, x, W, K, dy)
+    loss = lambda xx, ww: float((orc.chebyshev_forward(Lt, xx, ww, K) * dy).sum())  # noqa: E731
+    eps = 1e-6
+    for idx in [(0, 0, 0), (1, 7, 2), (0, 12, 1)]:
+        e = np.zeros_like(x)
+        e[idx] = eps
+        assert abs((loss(x + e, W) - loss(x - e, W)) / (2 * eps) - dx[idx]) < 1e-6
+    for idx in [(0, 0), (5, 1), (Fin * K - 1, 0)]:
+        e = np.zeros_like(W)
+        e[idx] = eps
+        assert abs((loss(x, W + e) - loss(x, W - e)) / (2 * eps) - dW[idx]) < 1e-6
