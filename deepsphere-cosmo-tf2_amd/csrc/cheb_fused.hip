@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void fused_wprep_kernel(const float* __restric
 
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
-                      int32_t precision, void* workspace, size_t workspace_bytes,
-                      hipStream_t stream) {
+                      int32_t precision, float alpha_rest, float beta_rest, void* workspace,
+                      size_t workspace_bytes, hipStream_t stream) {
   if (!fused_supported(plan, Fin, Fout, K)) {
     set_error("cheb_fused: plan/shape not supported");
     return DSPH_E_UNSUPPORTED;
@@ -340,6 +340,8 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
   args.ntiles = ft.ntiles;
   args.nchunks = C;
   args.act = act;
+  args.alpha_rest = alpha_rest;
+  args.beta_rest = beta_rest;
   args.wfrag_bytes = (int)wb;
   const char* dbg = getenv("DSPH_FUSED_DEBUG");
   args.dbg = dbg ? atoi(dbg) : 0;

@@ -30,6 +30,7 @@ struct FusedArgs {
   const float* lvals;
   int64_t x_rows, y_rows;
   int N, Fin, Fout, K, ntiles, nchunks, act, wfrag_bytes;
+  float alpha_rest, beta_rest;  // step k >= 2: T_k = alpha * L~ T_{k-1} - beta * T_{k-2} (2,1 Chebyshev; 1,0 monomial)
   int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no MFMA, 4 no x loads, 8 no y store
 };
 
@@ -98,13 +99,14 @@ __device__ __forceinline__ float quad_bcast(float v, int lane_in_quad) {
   return __builtin_bit_cast(float, r);
 }
 
-// One recurrence step: out = (HAS_PREV ? 2 : 1) * (L~ in) - (HAS_PREV ? out : 0) on rows [0, nrows).
+// One recurrence step on rows [0, nrows): out = L~ in (CHEB_STEP false: T_1 of either basis and every
+// monomial step) or out = 2 (L~ in) - out (CHEB_STEP true: Chebyshev steps k >= 2).
 // Lane (row_l, slot) owns rows row_l + 128 p, p = 0..RP-1, and one 16-byte slot (4 channels) of them;
 // the ELL values (quad-packed) and the swizzled LDS addresses of those rows' neighbours live in
 // registers.  The summation order (slot j ascending, fused multiply-add) is the unfused kernel's.
 // Every lane of a quad must execute the broadcasts, so the row guard covers whole quads (it does:
 // the four lanes of a quad share the row).
-template <int WT, int RP, bool HAS_PREV>
+template <int WT, int RP, bool CHEB_STEP>
 __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pin,
                                             unsigned char* __restrict__ pout, int nrows, int row_l,
                                             const float (&valc)[RP][(WT + 3) / 4], const unsigned (&pre)[RP][WT],
@@ -123,7 +125,7 @@ __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pi
         s.w = fmaf(w, v.w, s.w);
       }
       float4* op = reinterpret_cast<float4*>(pout + own[p]);
-      if (HAS_PREV) {
+      if (CHEB_STEP) {
         const float4 q = *op;
         s.x = 2.f * s.x - q.x;
         s.y = 2.f * s.y - q.y;
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   const int items = a.N * a.nchunks;  // (map, slice) pairs per tile
   const size_t wstride = (size_t)a.nchunks * NB * 2048;  // weight blocks: per order
   const bool do_g = !(a.dbg & 1), do_m = !(a.dbg & 2);
+  const bool cheb = a.beta_rest != 0.f;  // Chebyshev (2, 1) or monomial (1, 0) steps from k = 2 on
 
   // ---- software prefetch of the next (tile, map, slice): region row ids and x in registers ----
   int rid[NS];
@@ -322,11 +325,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       __syncthreads();
       if (do_m) mfma_plane<NB, PREC>(planeY, wblk + wstride, wave, lane, acc);
       for (int k = 2; k < a.K; k += 2) {
-        if (do_g) gather_step<WT, RP, true>(planeY, planeX, re(D - k), row_l, val, pre, own);
+        if (do_g) {
+          if (cheb) gather_step<WT, RP, true>(planeY, planeX, re(D - k), row_l, val, pre, own);
+          else gather_step<WT, RP, false>(planeY, planeX, re(D - k), row_l, val, pre, own);
+        }
         __syncthreads();
         if (do_m) mfma_plane<NB, PREC>(planeX, wblk + (size_t)k * wstride, wave, lane, acc);
         if (k + 1 < a.K) {
-          if (do_g) gather_step<WT, RP, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
+          if (do_g) {
+            if (cheb) gather_step<WT, RP, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
+            else gather_step<WT, RP, false>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
+          }
           __syncthreads();
           if (do_m) mfma_plane<NB, PREC>(planeY, wblk + (size_t)(k + 1) * wstride, wave, lane, acc);
         }

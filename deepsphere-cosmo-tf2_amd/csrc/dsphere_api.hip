@@ -184,6 +184,21 @@ int dsph_cheb_forward(const dsph_plan* p, const float* x, const float* w, const 
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, int32_t algo, void* workspace, size_t workspace_bytes,
                       void* hip_stream) {
+  return dsph_poly_forward(p, x, w, bias, y, N, Fin, Fout, K, DSPH_BASIS_CHEBYSHEV, act, precision, algo,
+                           workspace, workspace_bytes, hip_stream);
+}
+
+int dsph_poly_forward(const dsph_plan* p, const float* x, const float* w, const float* bias,
+                      float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t basis,
+                      int32_t act, int32_t precision, int32_t algo, void* workspace,
+                      size_t workspace_bytes, void* hip_stream) {
+  if (basis != DSPH_BASIS_CHEBYSHEV && basis != DSPH_BASIS_MONOMIAL) {
+    set_error("poly_forward: unknown basis %d", basis);
+    return DSPH_E_BADARG;
+  }
+  // coefficients of step k >= 2:  T_k = alpha * L~ T_{k-1} - beta * T_{k-2}
+  const float alpha_rest = basis == DSPH_BASIS_CHEBYSHEV ? 2.f : 1.f;
+  const float beta_rest = basis == DSPH_BASIS_CHEBYSHEV ? 1.f : 0.f;
   if (!p || !x || !w || !y || N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) {
     set_error("cheb_forward: bad arguments (NULL pointer or non-positive size)");
     return DSPH_E_BADARG;
@@ -205,8 +220,8 @@ int dsph_cheb_forward(const dsph_plan* p, const float* x, const float* w, const 
   hipStream_t stream = (hipStream_t)hip_stream;
   DeviceGuard guard(p->device);
   if (a == DSPH_ALGO_FUSED)
-    return launch_cheb_fused(p, x, w, bias, y, N, Fin, Fout, K, act, precision, workspace,
-                             workspace_bytes, stream);
+    return launch_cheb_fused(p, x, w, bias, y, N, Fin, Fout, K, act, precision, alpha_rest, beta_rest,
+                             workspace, workspace_bytes, stream);
 
   // ---- unfused: K-1 SpMM launches into workspace planes, then one contraction ---------------
   if (K > 64) { set_error("cheb_forward: K = %d exceeds 64", K); return DSPH_E_UNSUPPORTED; }
@@ -222,7 +237,8 @@ int dsph_cheb_forward(const dsph_plan* p, const float* x, const float* w, const 
     if (k == 1)
       rc = launch_cheb_step(p, planes[0], p->n_cols, nullptr, p->n_cols, outp, p->n_cols, N, Fin, 1.f, 0.f, rows, stream);
     else
-      rc = launch_cheb_step(p, planes[k - 1], p->n_cols, planes[k - 2], p->n_cols, outp, p->n_cols, N, Fin, 2.f, 1.f, rows, stream);
+      rc = launch_cheb_step(p, planes[k - 1], p->n_cols, beta_rest != 0.f ? planes[k - 2] : nullptr, p->n_cols, outp,
+                            p->n_cols, N, Fin, alpha_rest, beta_rest, rows, stream);
     if (rc != DSPH_OK) return rc;
   }
   return launch_cheb_contract(planes, p->n_cols, w, bias, y, N, out_rows(p), Fin, Fout, K, act,

@@ -57,8 +57,8 @@ void fused_plan_destroy(FusedPlan* fp);
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
-                      int32_t precision, void* workspace, size_t workspace_bytes,
-                      hipStream_t stream);
+                      int32_t precision, float alpha_rest, float beta_rest, void* workspace,
+                      size_t workspace_bytes, hipStream_t stream);
 size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                              int32_t precision);
 

@@ -9,5 +9,5 @@ for gfx950, C ABI in ``include/dsphere.h``).
 __version__ = "0.1.0"
 
 from . import healpix, utils  # noqa: F401
-from .gnn_layers import Chebyshev  # noqa: F401
-from .healpy_layers import HealpyChebyshev  # noqa: F401
+from .gnn_layers import Chebyshev, GCNN_ResidualLayer, Monomial  # noqa: F401
+from .healpy_layers import HealpyChebyshev, HealpyMonomial, Healpy_ResidualLayer  # noqa: F401

@@ -77,7 +77,8 @@ class _ChebConvFunction(torch.autograd.Function):
         plan = layer._get_plan()
         y, layer._workspace = _native.cheb_forward(
             plan, x, kernel.detach(), None, layer.K, act=_native.ACT_NONE,
-            precision=_PRECISIONS[layer.precision], algo=_ALGOS[layer.algo], workspace=layer._workspace)
+            precision=_PRECISIONS[layer.precision], algo=_ALGOS[layer.algo], workspace=layer._workspace,
+            basis=layer._basis)
         ctx.layer = layer
         ctx.save_for_backward(x, kernel)
         return y
@@ -96,7 +97,7 @@ class _ChebConvFunction(torch.autograd.Function):
             kernel_t = kernel.detach().reshape(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()
             dx, layer._workspace_t = _native.cheb_forward(
                 plan_t, dy, kernel_t, None, K, act=_native.ACT_NONE, precision=_PRECISIONS[layer.precision],
-                algo=_ALGOS[layer.algo], workspace=layer._workspace_t)
+                algo=_ALGOS[layer.algo], workspace=layer._workspace_t, basis=layer._basis)
         if ctx.needs_input_grad[1]:
             plan = layer._get_plan()
             dyf = dy.reshape(N * M, Fout)
@@ -104,8 +105,8 @@ class _ChebConvFunction(torch.autograd.Function):
             p_prev2, p_prev = None, x
             dk[:, 0] = torch.matmul(x.reshape(N * M, Fin).t(), dyf)
             for k in range(1, K):
-                if k == 1:
-                    p = _native.cheb_step(plan, p_prev, None, 1.0, 0.0)
+                if k == 1 or layer._basis == _native.BASIS_MONOMIAL:
+                    p = _native.cheb_step(plan, p_prev, None, 1.0, 0.0, out=p_prev2 if k > 2 else None)
                 else:
                     p = _native.cheb_step(plan, p_prev, p_prev2, 2.0, 1.0, out=p_prev2 if k > 2 else None)
                 dk[:, k] = torch.matmul(p.reshape(N * M, Fin).t(), dyf)
@@ -121,6 +122,12 @@ class Chebyshev(torch.nn.Module):
     with T_0 = I, T_1 = L~, T_k = 2 L~ T_{k-1} - T_{k-2} and L~ = 1.5/lmax * L - I,
     lmax = 1.02 * lambda_max(L).
     """
+
+    _basis = _native.BASIS_CHEBYSHEV
+    _scale = 0.75  # rescale_L(L, lmax, scale=0.75), gnn_layers.py:67
+
+    def _default_stddev(self, Fin):
+        return 1.0 / np.sqrt(Fin * (self.K + 0.5) / 2.0)  # gnn_layers.py:92
 
     def __init__(
         self,
@@ -176,7 +183,7 @@ class Chebyshev(torch.nn.Module):
         self._device = torch.device(device) if device is not None else None
 
         # Rescaled Laplacian (host, float64 -> float32), then padded ELL for the kernels.
-        Lt, self.lmax = utils.prepare_L(L, scale=0.75)
+        Lt, self.lmax = utils.prepare_L(L, scale=self._scale)
         self._M = Lt.shape[0]
         self._ell_cols, self._ell_vals = utils.csr_to_ell(Lt)
         self._nnz = int(Lt.nnz)
@@ -196,7 +203,7 @@ class Chebyshev(torch.nn.Module):
         dev = self._resolve_device(None)
         kernel = torch.empty((self.K * Fin, Fout), dtype=torch.float32)
         if self.initializer is None:
-            stddev = 1.0 / np.sqrt(Fin * (self.K + 0.5) / 2.0)
+            stddev = self._default_stddev(Fin)
             torch.nn.init.trunc_normal_(kernel, mean=0.0, std=stddev, a=-2.0 * stddev, b=2.0 * stddev)
         else:
             res = self.initializer(kernel)
@@ -296,6 +303,7 @@ class Chebyshev(torch.nn.Module):
         y, self._workspace = _native.cheb_forward(
             plan, x, self.kernel.detach(), bias if fuse_epilogue else None, self.K, act=act_code,
             precision=_PRECISIONS[self.precision], algo=_ALGOS[self.algo], workspace=self._workspace,
+            basis=self._basis,
         )
         if self.use_bn:  # BN -> bias -> activation, the reference's order (gnn_layers.py:152-159)
             was_training = self.bn.training
@@ -356,4 +364,101 @@ class Chebyshev(torch.nn.Module):
         return self
 
 
-__all__ = ["Chebyshev"]
+class Monomial(Chebyshev):
+    """A graph convolutional layer using monomials: T_k = L~^k with L~ = 2/lmax * L - I.
+
+    Mirror of the reference's ``gnn_layers.Monomial`` (``gnn_layers.py:164-309``): same constructor, same
+    forward structure as ``Chebyshev`` with the recurrence ``x_k = L~ x_{k-1}`` (``:283-286``),
+    ``rescale_L(L, lmax)`` at its default scale 1 (``:219``) and a truncated-normal default
+    initialiser of stddev 0.1 (``:243``).  Runs the same HIP kernels with ``DSPH_BASIS_MONOMIAL``.
+    """
+
+    _basis = _native.BASIS_MONOMIAL
+    _scale = 1.0
+
+    def _default_stddev(self, Fin):
+        return 0.1
+
+
+class GCNN_ResidualLayer(torch.nn.Module):
+    """A generic residual layer:  in -> layer -> [norm] -> layer -> [norm] -> act(out + alpha * in).
+
+    Mirror of the reference's ``gnn_layers.GCNN_ResidualLayer`` (``gnn_layers.py:312-413``), including its
+    quirks: both sub-layers get the same ``layer_kwargs``; with ``activation=None`` the skip is
+    ``x + input`` and ``alpha`` is ignored (``:407-408``); unknown ``layer_type`` raises ``IOError``
+    (``:370``), unknown ``norm_type`` ``ValueError`` (``:379``).
+    """
+
+    def __init__(self, layer_type, layer_kwargs, activation=None, act_before=False, use_bn=False,
+                 norm_type="batch_norm", bn_kwargs=None, alpha=1.0):
+        super().__init__()
+        self.layer_type = layer_type
+        self.layer_kwargs = layer_kwargs
+        self.activation, _ = _resolve_activation(activation)
+        self.act_before = act_before
+        self.use_bn = use_bn
+        self.norm_type = norm_type
+        if bn_kwargs is None:
+            self.bn_kwargs = {"axis": -1}
+        else:
+            self.bn_kwargs = bn_kwargs
+            if "axis" not in self.bn_kwargs and norm_type != "moving_norm":
+                self.bn_kwargs.update({"axis": -1})
+        if self.layer_type == "CHEBY":
+            self.layer1 = Chebyshev(**self.layer_kwargs)
+            self.layer2 = Chebyshev(**self.layer_kwargs)
+        elif self.layer_type == "MONO":
+            self.layer1 = Monomial(**self.layer_kwargs)
+            self.layer2 = Monomial(**self.layer_kwargs)
+        else:
+            raise IOError(f"Layertype not understood: {self.layer_type}")
+        self.bn1 = self.bn2 = None
+        if use_bn and norm_type not in ("layer_norm", "batch_norm"):
+            raise ValueError(f"norm_type <{norm_type}> not understood!")
+        self.alpha = alpha
+
+    def _norm(self, which, x, training):
+        """Keras BatchNormalization (momentum 0.99, eps 1e-3, affine) / LayerNormalization (eps 1e-3) over
+        ``bn_kwargs['axis']`` of a (batch, nodes, channels) tensor, created on first use."""
+        axis = self.bn_kwargs.get("axis", -1)
+        mod = getattr(self, which)
+        if mod is None:
+            if self.norm_type == "batch_norm":
+                mod = torch.nn.BatchNorm1d(x.shape[-1], eps=1e-3, momentum=0.01, affine=True).to(x.device)
+            else:
+                axes = (axis,) if isinstance(axis, int) else tuple(axis)
+                shape = [x.shape[a] for a in axes]
+                mod = torch.nn.LayerNorm(shape, eps=1e-3).to(x.device)
+                mod._axes = axes
+            setattr(self, which, mod)
+        if self.norm_type == "batch_norm":
+            was = mod.training
+            mod.train(self.training if training is None else bool(training))
+            y = mod(x.transpose(1, 2)).transpose(1, 2)
+            mod.train(was)
+            return y
+        axes = [a % x.dim() for a in mod._axes]
+        if axes == list(range(x.dim() - len(axes), x.dim())):
+            return mod(x)
+        raise NotImplementedError("layer_norm over non-trailing axes")
+
+    def forward(self, input_tensor, training=None):
+        if not isinstance(input_tensor, torch.Tensor):
+            input_tensor = torch.as_tensor(np.asarray(input_tensor))
+        x = self.layer1(input_tensor, training=training)
+        inp = input_tensor.to(device=x.device, dtype=torch.float32)
+        if self.use_bn:
+            x = self._norm("bn1", x, training)
+        x = self.layer2(x, training=training)
+        if self.use_bn:
+            x = self._norm("bn2", x, training)
+        if self.activation is None:
+            return x + inp
+        if self.act_before:
+            return self.activation(x) + self.alpha * inp
+        return self.activation(x + self.alpha * inp)
+
+    call = forward
+
+
+__all__ = ["Chebyshev", "Monomial", "GCNN_ResidualLayer"]

@@ -6,7 +6,7 @@ Chebyshev layer that a model builder turns into a real layer once it has compute
 Laplacian of the current resolution (``healpy_networks.py:110-137``).
 """
 
-from .gnn_layers import Chebyshev
+from .gnn_layers import Chebyshev, GCNN_ResidualLayer, Monomial
 
 
 class HealpyChebyshev:
@@ -51,4 +51,37 @@ class HealpyChebyshev:
         )
 
 
-__all__ = ["HealpyChebyshev"]
+class HealpyMonomial(HealpyChebyshev):
+    """Deferred spec of a monomial graph convolution (reference ``healpy_layers.py:267-313``)."""
+
+    def _get_layer(self, L, n_matmul_splits=1):
+        return Monomial(L=L, K=self.K, Fout=self.Fout, initializer=self.initializer, activation=self.activation,
+                        use_bias=self.use_bias, use_bn=self.use_bn, n_matmul_splits=n_matmul_splits, **self.kwargs)
+
+
+class Healpy_ResidualLayer:
+    """Deferred spec of a residual block of two graph convolutions (reference ``healpy_layers.py:316-378``).
+
+    ``layer_kwargs`` lacks ``L``; ``_get_layer`` adds it (and ``n_matmul_splits``) to a copy -- the reference
+    writes them into the caller's dict."""
+
+    def __init__(self, layer_type, layer_kwargs, activation=None, act_before=False, use_bn=False,
+                 norm_type="batch_norm", bn_kwargs=None, alpha=1.0):
+        self.layer_type = layer_type
+        self.layer_kwargs = layer_kwargs
+        self.activation = activation
+        self.act_before = act_before
+        self.use_bn = use_bn
+        self.norm_type = norm_type
+        self.bn_kwargs = bn_kwargs
+        self.alpha = alpha
+
+    def _get_layer(self, L, n_matmul_splits=1):
+        kwargs = dict(self.layer_kwargs)
+        kwargs.update({"L": L, "n_matmul_splits": n_matmul_splits})
+        return GCNN_ResidualLayer(layer_type=self.layer_type, layer_kwargs=kwargs, activation=self.activation,
+                                  act_before=self.act_before, use_bn=self.use_bn, norm_type=self.norm_type,
+                                  bn_kwargs=self.bn_kwargs, alpha=self.alpha)
+
+
+__all__ = ["HealpyChebyshev", "HealpyMonomial", "Healpy_ResidualLayer"]

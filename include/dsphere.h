@@ -41,6 +41,12 @@ extern "C" {
 #define DSPH_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain        */
 #define DSPH_PREC_BF16X3 1 /* hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
 
+/* polynomial basis of the recurrence: T_1 = L~ x in both;
+ *   Chebyshev: T_k = 2 L~ T_{k-1} - T_{k-2}   (reference gnn_layers.Chebyshev, gnn_layers.py:137-143)
+ *   monomial:  T_k = L~ T_{k-1}                (reference gnn_layers.Monomial,  gnn_layers.py:283-286) */
+#define DSPH_BASIS_CHEBYSHEV 0
+#define DSPH_BASIS_MONOMIAL 1
+
 /* which implementation dsph_cheb_forward runs */
 #define DSPH_ALGO_AUTO 0
 #define DSPH_ALGO_UNFUSED 1 /* K-1 ELL SpMM launches into workspace planes + one contraction launch */
@@ -99,6 +105,14 @@ int dsph_cheb_forward(const dsph_plan* plan, const float* x, const float* w, con
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, int32_t algo, void* workspace, size_t workspace_bytes,
                       void* hip_stream);
+
+/* The same forward for either polynomial basis (dsph_cheb_forward is this with
+ * DSPH_BASIS_CHEBYSHEV).  With DSPH_BASIS_MONOMIAL it replaces Monomial.call
+ * (gnn_layers.py:262-309): same layouts, same weight row order f*K + k. */
+int dsph_poly_forward(const dsph_plan* plan, const float* x, const float* w, const float* bias,
+                      float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t basis,
+                      int32_t act, int32_t precision, int32_t algo, void* workspace,
+                      size_t workspace_bytes, void* hip_stream);
 
 /* One recurrence step on (N, n_cols, F) planes:  out = alpha * (L~ @ in) - beta * prev
  * for rows [0, rows) of every map (rows <= n_rows; rows <= 0 means n_rows); prev may be NULL

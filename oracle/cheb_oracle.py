@@ -170,6 +170,36 @@ def chebyshev_forward(
     return y.astype(dtype, copy=False)
 
 
+def monomial_forward(Lt, x, kernel, K, bias=None, activation=None, bn=None, n_matmul_splits=1, dtype=np.float64):
+    """Literal restatement of ``Monomial.call`` (gnn_layers.py:262-309): as ``chebyshev_forward`` with the
+    recurrence x_k = Lt x_{k-1} (:283-286).  Lt comes from ``prepare_L(L, scale=1)`` (:219)."""
+    x = np.asarray(x, dtype=dtype)
+    kernel = np.asarray(kernel, dtype=dtype)
+    Lt = sparse.csr_matrix(Lt).astype(dtype)
+    N, M, Fin = x.shape
+    Fout = kernel.shape[1]
+    x0 = np.reshape(np.transpose(x, (1, 2, 0)), (M, -1))  # (:276-277)
+    stack = [x0]
+    for _k in range(1, K):  # (:283-286)
+        x1 = split_sparse_dense_matmul(Lt, x0, n_matmul_splits)
+        stack.append(x1)
+        x0 = x1
+    xs = np.stack(stack, axis=0)  # (:288)
+    xs = np.reshape(xs, (K, M, Fin, -1))
+    xs = np.transpose(xs, (3, 1, 2, 0))
+    xs = np.reshape(xs, (-1, Fin * K))
+    y = np.reshape(xs @ kernel, (-1, M, Fout))  # (:293-294)
+    if bn is not None:
+        mean, var = bn
+        y = (y - np.asarray(mean, dtype=dtype)) / np.sqrt(np.asarray(var, dtype=dtype) + dtype(1e-5))
+    if bias is not None:
+        y = y + np.reshape(np.asarray(bias, dtype=dtype), (1, 1, Fout))
+    act = _resolve_activation(activation)
+    if act is not None:
+        y = act(y)
+    return y.astype(dtype, copy=False)
+
+
 def chebyshev_planes(Lt, x, K, dtype=np.float64):
     """T_k(Lt) x for k = 0..K-1 in the caller's (N, M, Fin) layout, shape (K, N, M, Fin)."""
     x = np.asarray(x, dtype=dtype)

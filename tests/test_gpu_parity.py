@@ -437,3 +437,62 @@ def test_layer_trains():
             opt.step()
             losses.append(loss.item())
     assert losses[-1] < 0.9 * losses[0]
+
+
+@pytest.mark.parametrize("algo", ["unfused", "fused"])
+def test_monomial_layer(algo):
+    # the monomial basis on the same kernels (reference gnn_layers.py:164-309)
+    L = healpix.healpix_laplacian(16, mode="grid")
+    Lt, _ = orc.prepare_L(L, scale=1.0)
+    rng = np.random.default_rng(8)
+    N, Fin, Fout, K = 2, 32, 64, 5
+    x = rng.standard_normal((N, L.shape[0], Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    ref = orc.monomial_forward(Lt, x, W, K, bias=b, activation="elu")
+    plan = _plan(Lt)
+    a = {"unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}[algo]
+    y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_ELU, algo=a,
+                                basis=_native.BASIS_MONOMIAL)
+    assert rel_err(y.cpu().numpy(), ref) < TOL_FP32
+    # through the layer, and its gradients
+    with torch.enable_grad():
+        layer = gnn_layers.Monomial(L=L, K=K, Fout=Fout, initializer=lambda t: t.copy_(torch.from_numpy(W)),
+                                    algo=algo)
+        xt = _dev(x).requires_grad_(True)
+        out = layer(xt)
+        dy = rng.standard_normal(out.shape).astype(np.float32)
+        out.backward(_dev(dy))
+    assert rel_err(out.detach().cpu().numpy(), orc.monomial_forward(Lt, x, W, K)) < TOL_FP32
+    planes = [x.astype(np.float64)]
+    for _ in range(1, K):
+        planes.append(np.einsum("ij,njf->nif", Lt.toarray().astype(np.float64), planes[-1]))
+    dW_ref = np.einsum("knmf,nmo->fko", np.stack(planes), dy).reshape(Fin * K, Fout)
+    assert rel_err(layer.kernel.grad.cpu().numpy(), dW_ref) < 2e-5
+    Ld = Lt.toarray().astype(np.float64)
+    dx_ref = sum(np.einsum("ji,njf->nif", np.linalg.matrix_power(Ld, k), dy @ W.reshape(Fin, K, Fout)[:, k].T)
+                 for k in range(K))
+    assert rel_err(xt.grad.cpu().numpy(), dx_ref) < 2e-5
+
+
+def test_residual_layer_like_reference_test():
+    # tests/test_gnn_layers.py:92-145 of the reference: L = I_192, K = 5, relu, shapes + value check
+    n_pix = 192
+    rng = np.random.default_rng(11)
+    m_in = rng.normal(size=[3, n_pix, 7])
+    kw = {"L": np.eye(n_pix, dtype=np.float64), "K": 5, "activation": torch.relu, "regularizer": "l1"}
+    res = gnn_layers.GCNN_ResidualLayer(layer_type="CHEBY", layer_kwargs=kw, activation=torch.relu)
+    out = res(m_in)
+    assert tuple(out.shape) == (3, n_pix, 7)
+    t = float(np.float32(1.5 / 1.02 - 1.0))
+    T = np.cos(np.arange(5) * np.arccos(t))
+    W1 = np.einsum("k,fko->fo", T, res.layer1.kernel.detach().cpu().numpy().astype(np.float64).reshape(7, 5, 7))
+    W2 = np.einsum("k,fko->fo", T, res.layer2.kernel.detach().cpu().numpy().astype(np.float64).reshape(7, 5, 7))
+    ref = np.maximum(np.maximum(np.maximum(m_in @ W1, 0) @ W2, 0) + m_in, 0)
+    assert rel_err(out.cpu().numpy(), ref) < 2e-5
+    for extra in ({"use_bn": True}, {"use_bn": True, "norm_type": "layer_norm", "bn_kwargs": {"axis": (1, 2)}}):
+        res = gnn_layers.GCNN_ResidualLayer(layer_type="CHEBY", layer_kwargs=kw, activation=torch.relu, **extra)
+        assert tuple(res(m_in).shape) == (3, n_pix, 7)
+    res = gnn_layers.GCNN_ResidualLayer(layer_type="MONO", layer_kwargs=kw, activation=None, alpha=7.0)
+    lin = res(m_in).cpu().numpy()
+    assert lin.shape == (3, n_pix, 7)

@@ -211,3 +211,30 @@ def test_input_validation():
         cheb(np.zeros((2, 4, 3)))  # wrong node count
     with pytest.raises(ValueError):
         cheb(np.zeros((5, 3)))  # wrong rank
+
+
+def test_monomial_and_residual_api():
+    # reference tests/test_gnn_layers.py:36-62 (Monomial) and :92-145 (GCNN_ResidualLayer)
+    L = np.eye(48)
+    mono = gnn_layers.Monomial(L=L, K=4, Fout=3, device="cpu")
+    mono.build((5, 48, 7))
+    assert tuple(mono.kernel.shape) == (28, 3) and mono.kernel.abs().max().item() <= 0.2 + 1e-6
+    assert abs(mono.lmax - 1.02) < 1e-12
+    # L~ = 2/1.02 * I - I for the monomial layer (scale 1), 1.5/1.02 * I - I for Chebyshev
+    assert np.allclose(mono._ell_vals[:, 0], 2 / 1.02 - 1, atol=1e-6)
+    assert isinstance(healpy_layers.HealpyMonomial(K=3, Fout=2, device="cpu")._get_layer(L), gnn_layers.Monomial)
+    with pytest.raises(IOError):
+        gnn_layers.GCNN_ResidualLayer("juhu", dict())
+    kw = {"L": np.eye(48), "K": 5, "activation": torch.relu, "regularizer": "l1", "device": "cpu"}
+    res = gnn_layers.GCNN_ResidualLayer(layer_type="CHEBY", layer_kwargs=kw, activation=torch.relu)
+    assert isinstance(res.layer1, gnn_layers.Chebyshev) and res.layer1 is not res.layer2
+    res = gnn_layers.GCNN_ResidualLayer(layer_type="MONO", layer_kwargs=kw, activation="relu", use_bn=True,
+                                        norm_type="layer_norm", bn_kwargs={"axis": (1, 2)})
+    assert isinstance(res.layer2, gnn_layers.Monomial)
+    with pytest.raises(ValueError):
+        gnn_layers.GCNN_ResidualLayer(layer_type="CHEBY", layer_kwargs=kw, activation=torch.relu, use_bn=True,
+                                      norm_type="moving_norm")
+    spec = healpy_layers.Healpy_ResidualLayer("CHEBY", {"K": 5, "device": "cpu"}, activation="relu")
+    layer = spec._get_layer(np.eye(48), n_matmul_splits=2)
+    assert isinstance(layer, gnn_layers.GCNN_ResidualLayer) and "L" not in spec.layer_kwargs
+    assert layer.layer1.n_matmul_splits == 2

@@ -178,3 +178,17 @@ def test_backward_closed_form_matches_finite_differences(symmetric):
         e = np.zeros_like(W)
         e[idx] = eps
         assert abs((loss(x, W + e) - loss(x, W - e)) / (2 * eps) - dW[idx]) < 1e-6
+
+
+def test_monomial_literal_against_powers():
+    L = _rand_graph_L(15, seed=12)
+    Lt, _ = orc.prepare_L(L, scale=1.0)
+    ev = np.linalg.eigvalsh(Lt.toarray().astype(np.float64))
+    assert ev.min() >= -1 - 1e-6 and ev.max() <= 2 / 1.02 - 1 + 1e-6  # spectrum in [-1, 0.96]
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 15, 3))
+    W = rng.standard_normal((3 * 4, 2))
+    Ld = Lt.toarray().astype(np.float64)
+    P = [np.linalg.matrix_power(Ld, k) for k in range(4)]
+    ref = np.einsum("kmp,npf,fko->nmo", np.stack(P), x, W.reshape(3, 4, 2))
+    assert rel_err(orc.monomial_forward(Lt, x, W, 4), ref) < 1e-12
