@@ -10,4 +10,6 @@ __version__ = "0.1.0"
 
 from . import healpix, utils  # noqa: F401
 from .gnn_layers import Chebyshev, GCNN_ResidualLayer, Monomial  # noqa: F401
-from .healpy_layers import HealpyChebyshev, HealpyMonomial, Healpy_ResidualLayer  # noqa: F401
+from .healpy_layers import (HealpyChebyshev, HealpyMonomial, HealpyPool, HealpyPseudoConv,  # noqa: F401
+                            HealpyPseudoConv_Transpose, Healpy_ResidualLayer)
+from .healpy_networks import HealpyGCNN  # noqa: F401

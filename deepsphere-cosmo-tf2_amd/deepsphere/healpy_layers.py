@@ -6,7 +6,110 @@ Chebyshev layer that a model builder turns into a real layer once it has compute
 Laplacian of the current resolution (``healpy_networks.py:110-137``).
 """
 
+import numpy as np
+import torch
+
 from .gnn_layers import Chebyshev, GCNN_ResidualLayer, Monomial
+
+
+def _as_tensor(x):
+    return x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x), dtype=torch.float32)
+
+
+class HealpyPool(torch.nn.Module):
+    """Pooling over the 4^p NEST children of a HEALPix pixel (reference ``healpy_layers.py:20-78``: a Keras
+    MaxPool1D / AveragePooling1D with size = stride = 4^p on (batch, pixels, channels)).  A dense strided
+    op on the host framework's side of the boundary; it only works for NEST ordering."""
+
+    def __init__(self, p, pool_type="MAX", **kwargs):
+        super().__init__()
+        if not p >= 1:
+            raise IOError("The reduction factors has to be at least 2!")
+        self.p = p
+        self.filter_size = int(4**p)
+        self.pool_type = pool_type
+        self.kwargs = kwargs
+        if pool_type not in ("MAX", "AVG"):
+            raise IOError(f"Pooling type not understood: {self.pool_type}")
+
+    def forward(self, input_tensor):
+        x = _as_tensor(input_tensor)
+        N, M, F = x.shape
+        if M % self.filter_size != 0:
+            raise IOError(f"Input shape {tuple(x.shape)} not compatible with the filter size {self.filter_size}")
+        x = x.reshape(N, M // self.filter_size, self.filter_size, F)
+        return x.amax(dim=2) if self.pool_type == "MAX" else x.mean(dim=2)
+
+    call = forward
+
+
+class HealpyPseudoConv(torch.nn.Module):
+    """Learnable 4^p -> 1 reduction of NEST children (reference ``healpy_layers.py:81-146``: Conv1D with
+    kernel = stride = 4^p, channels last).  Weights: ``filter.weight`` (Fout, Fin, 4^p), ``filter.bias``."""
+
+    def __init__(self, p, Fout, kernel_initializer=None, **kwargs):
+        super().__init__()
+        if not p >= 1:
+            raise IOError("The reduction factors has to be at least 1!")
+        self.p = p
+        self.filter_size = int(4**p)
+        self.Fout = Fout
+        self.kernel_initializer = kernel_initializer
+        self.kwargs = kwargs
+        self.filter = None
+
+    def build(self, input_shape):
+        if int(input_shape[1]) % self.filter_size != 0:
+            raise IOError(f"Input shape {tuple(input_shape)} not compatible with the filter size {self.filter_size}")
+        self.filter = torch.nn.Conv1d(int(input_shape[-1]), self.Fout, self.filter_size, stride=self.filter_size)
+        torch.nn.init.xavier_uniform_(self.filter.weight)  # Keras default glorot_uniform, zero bias
+        torch.nn.init.zeros_(self.filter.bias)
+        if self.kernel_initializer is not None:
+            self.kernel_initializer(self.filter.weight)
+
+    def forward(self, input_tensor):
+        x = _as_tensor(input_tensor)
+        if self.filter is None:
+            self.build(x.shape)
+            self.filter.to(x.device)
+        return self.filter(x.transpose(1, 2)).transpose(1, 2)
+
+    call = forward
+
+
+class HealpyPseudoConv_Transpose(torch.nn.Module):
+    """Learnable 1 -> 4^p expansion into NEST children (reference ``healpy_layers.py:149-216``: a
+    Conv2DTranspose with kernel = stride = (1, 4^p))."""
+
+    def __init__(self, p, Fout, kernel_initializer=None, **kwargs):
+        super().__init__()
+        if not p >= 1:
+            raise IOError("The boost factors has to be at least 1!")
+        self.p = p
+        self.filter_size = int(4**p)
+        self.Fout = Fout
+        self.kernel_initializer = kernel_initializer
+        self.kwargs = kwargs
+        self.filter = None
+
+    def build(self, input_shape):
+        if int(input_shape[1]) % self.filter_size != 0:  # the reference checks the same thing (:203-204)
+            raise IOError(f"Input shape {tuple(input_shape)} not compatible with the filter size {self.filter_size}")
+        self.filter = torch.nn.ConvTranspose1d(int(input_shape[-1]), self.Fout, self.filter_size,
+                                               stride=self.filter_size)
+        torch.nn.init.xavier_uniform_(self.filter.weight)
+        torch.nn.init.zeros_(self.filter.bias)
+        if self.kernel_initializer is not None:
+            self.kernel_initializer(self.filter.weight)
+
+    def forward(self, input_tensor):
+        x = _as_tensor(input_tensor)
+        if self.filter is None:
+            self.build(x.shape)
+            self.filter.to(x.device)
+        return self.filter(x.transpose(1, 2)).transpose(1, 2)
+
+    call = forward
 
 
 class HealpyChebyshev:
@@ -84,4 +187,5 @@ class Healpy_ResidualLayer:
                                   bn_kwargs=self.bn_kwargs, alpha=self.alpha)
 
 
-__all__ = ["HealpyChebyshev", "HealpyMonomial", "Healpy_ResidualLayer"]
+__all__ = ["HealpyPool", "HealpyPseudoConv", "HealpyPseudoConv_Transpose", "HealpyChebyshev", "HealpyMonomial",
+           "Healpy_ResidualLayer"]

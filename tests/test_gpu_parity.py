@@ -496,3 +496,32 @@ def test_residual_layer_like_reference_test():
     res = gnn_layers.GCNN_ResidualLayer(layer_type="MONO", layer_kwargs=kw, activation=None, alpha=7.0)
     lin = res(m_in).cpu().numpy()
     assert lin.shape == (3, n_pix, 7)
+
+
+def test_healpy_gcnn_forward_and_weight_round_trip():
+    # reference tests/test_healpy_networks.py:91-152: a small model on a partial-sky map, output shape,
+    # save -> new model -> different outputs -> load -> same outputs (atol 1e-6)
+    from deepsphere import healpy_networks
+
+    nside = 16
+    indices = healpix.extend_indices(healpix.cap_indices(nside, fraction=0.25), nside, 4)
+
+    def make():
+        layers = [healpy_layers.HealpyPseudoConv(p=1, Fout=8), healpy_layers.HealpyChebyshev(K=5, Fout=8, activation="elu"),
+                  healpy_layers.HealpyPool(p=1, pool_type="AVG"),
+                  healpy_layers.Healpy_ResidualLayer("CHEBY", {"K": 3, "activation": "relu"}, activation="relu"),
+                  healpy_layers.HealpyMonomial(K=3, Fout=4, use_bias=True)]
+        return healpy_networks.HealpyGCNN(nside=nside, indices=indices, layers=layers)
+
+    rng = np.random.default_rng(3)
+    x = _dev(rng.standard_normal((3, len(indices), 2)).astype(np.float32))
+    torch.manual_seed(11)
+    m1 = make().cuda()
+    y1 = m1(x)
+    assert tuple(y1.shape) == (3, len(indices) // 16, 4)
+    torch.manual_seed(12)
+    m2 = make().cuda()
+    y2 = m2(x)
+    assert not torch.allclose(y1, y2, atol=1e-6)
+    m2.load_state_dict(m1.state_dict())
+    assert torch.allclose(m2(x), y1, atol=1e-6)

@@ -238,3 +238,49 @@ def test_monomial_and_residual_api():
     layer = spec._get_layer(np.eye(48), n_matmul_splits=2)
     assert isinstance(layer, gnn_layers.GCNN_ResidualLayer) and "L" not in spec.layer_kwargs
     assert layer.layer1.n_matmul_splits == 2
+
+
+def test_healpy_pool_and_pseudo_conv_like_reference_tests():
+    # reference tests/test_healpy_layers.py:9-63
+    nside = 16
+    n_pix = healpix.nside2npix(nside)
+    rng = np.random.default_rng(11)
+    m_in = rng.normal(size=n_pix).astype(np.float32)
+    avg = healpy_layers.HealpyPool(p=1, pool_type="AVG")(m_in[None, :, None]).numpy().ravel()
+    # hp.ud_grade(nside -> nside/2) in NEST order is the mean of the 4 children
+    assert np.all(np.abs(avg - m_in.reshape(-1, 4).mean(1)) < 1e-5)
+    mx = healpy_layers.HealpyPool(p=1, pool_type="MAX")(m_in[None, :, None]).numpy().ravel()
+    assert np.all(np.abs(mx - m_in.reshape(-1, 4).max(1)) < 1e-5)
+    with pytest.raises(IOError):
+        healpy_layers.HealpyPool(p=1, pool_type="MEDIAN")
+    with pytest.raises(IOError):
+        healpy_layers.HealpyPool(p=2)(np.zeros((1, 12, 1), np.float32))
+    conv = healpy_layers.HealpyPseudoConv(3, 5)(m_in[None, :, None])
+    assert tuple(conv.shape) == (1, n_pix // 64, 5)
+    up = healpy_layers.HealpyPseudoConv_Transpose(3, 5)(rng.normal(size=(1, 192, 2)).astype(np.float32))
+    assert tuple(up.shape) == (1, 192 * 64, 5)
+
+
+def test_healpy_gcnn_assembly_and_errors():
+    # reference tests/test_healpy_networks.py:91-189 (construction part; the forward needs a GPU)
+    from deepsphere import healpy_networks
+
+    nside = 16
+    indices = healpix.extend_indices(healpix.cap_indices(nside, fraction=0.25), nside, 4)
+    layers = [healpy_layers.HealpyPseudoConv(p=1, Fout=4), healpy_layers.HealpyPool(p=1),
+              healpy_layers.HealpyChebyshev(K=5, Fout=8, device="cpu"),
+              healpy_layers.HealpyMonomial(K=3, Fout=8, device="cpu"),
+              healpy_layers.Healpy_ResidualLayer("CHEBY", {"K": 3, "device": "cpu"}, activation="relu"),
+              healpy_layers.HealpyPseudoConv_Transpose(p=1, Fout=2)]
+    model = healpy_networks.HealpyGCNN(nside=nside, indices=indices, layers=layers, max_batch_size=3, initial_Fin=1)
+    assert model.nside_out == 8 and len(model) == 6
+    cheb = model[2]
+    assert isinstance(cheb, gnn_layers.Chebyshev) and cheb._M == len(indices) // 16
+    assert len(model.indices_out) == len(indices) // 4
+    assert cheb.n_matmul_splits >= 1
+    with pytest.raises(NotImplementedError):
+        healpy_networks.HealpyGCNN(nside=nside, indices=indices, layers=layers, n_neighbors=12)
+    with pytest.raises(ValueError):  # indices not closed under the 4x coarsening
+        healpy_networks.HealpyGCNN(nside=nside, indices=indices[:-3], layers=layers[:3])
+    with pytest.raises(ValueError):  # too many reductions
+        healpy_networks.HealpyGCNN(nside=2, indices=np.arange(48), layers=[healpy_layers.HealpyPool(p=2)])
