@@ -91,10 +91,10 @@ __device__ __forceinline__ float quad_bcast(float v, int lane_in_quad) {
   const int iv = __builtin_bit_cast(int, v);
   int r;
   switch (lane_in_quad) {
-    case 0: r = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xf, 0xf, false); break;
-    case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xf, 0xf, false); break;
-    case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xf, 0xf, false); break;
-    default: r = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xf, 0xf, false); break;
+    case 0: r = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xf, 0xf, true); break;
+    case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xf, 0xf, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xf, 0xf, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xf, 0xf, true); break;
   }
   return __builtin_bit_cast(float, r);
 }
