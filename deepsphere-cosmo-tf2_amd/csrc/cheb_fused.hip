@@ -40,7 +40,6 @@ namespace dsph {
 struct FusedTiles {
   int D = 0;
   int width = 0;     // ELL width of the tile-local table (template width, >= plan width)
-  int rpl = 0;       // region rows per lane
   int ntiles = 0;
   int rmax = 0;      // largest region (rows), rounded up to a multiple of 16, >= FUSED_P
   int emax = 0;      // largest number of rows that carry an ELL row
@@ -93,6 +92,14 @@ void fused_plan_destroy(FusedPlan* fp) {
   if (!fp) return;
   for (auto& kv : fp->by_depth) free_tiles(kv.second);
   delete fp;
+}
+
+// The tile tables depend on which rows are outputs (dsph_plan_set_levels): drop the cached ones.
+void fused_plan_invalidate(FusedPlan* fp) {
+  if (!fp) return;
+  std::lock_guard<std::mutex> lock(fp->mu);
+  for (auto& kv : fp->by_depth) free_tiles(kv.second);
+  fp->by_depth.clear();
 }
 
 // Breadth-first rings of every tile; uploads the tables.  Returns a reference to the cached entry.
@@ -215,7 +222,6 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
   ft.ntiles = ntiles;
   ft.rmax = std::max((rmax + 15) / 16 * 16, FUSED_P);
   ft.emax = emax;
-  ft.rpl = (emax + FUSED_THREADS - 1) / FUSED_THREADS;
 
   auto up = [](void** dst, const void* src, size_t bytes) -> bool {
     if (bytes == 0) bytes = 16;

@@ -127,6 +127,10 @@ int dsph_plan_set_levels(dsph_plan* p, int32_t n_levels, const int64_t* rows_at_
     prev = rows_at_level[i];
   }
   p->levels.assign(rows_at_level, rows_at_level + n_levels);
+  if (p->fused) {
+    DeviceGuard guard(p->device);
+    fused_plan_invalidate(p->fused);
+  }
   return DSPH_OK;
 }
 
@@ -243,6 +247,25 @@ int dsph_poly_forward(const dsph_plan* p, const float* x, const float* w, const 
   }
   return launch_cheb_contract(planes, p->n_cols, w, bias, y, N, out_rows(p), Fin, Fout, K, act,
                               precision, stream);
+}
+
+size_t dsph_wgrad_workspace_bytes(int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K) {
+  if (N <= 0 || rows <= 0 || Fin <= 0 || Fout <= 0 || K <= 0) return 0;
+  return wgrad_workspace_bytes(N, rows, Fin, Fout, K);
+}
+
+int dsph_cheb_wgrad(const float* const* planes, int64_t plane_rows, const float* dy, float* dw,
+                    int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K, void* workspace,
+                    size_t workspace_bytes, int device, void* hip_stream) {
+  if (!planes || !dy || !dw || N <= 0 || rows <= 0 || rows > plane_rows || Fin <= 0 || Fout <= 0 || K <= 0) {
+    set_error("cheb_wgrad: bad arguments");
+    return DSPH_E_BADARG;
+  }
+  for (int k = 0; k < K && k < 64; ++k)
+    if (!planes[k]) { set_error("cheb_wgrad: plane %d is NULL", k); return DSPH_E_BADARG; }
+  DeviceGuard guard(device);
+  return launch_cheb_wgrad(planes, plane_rows, dy, dw, N, rows, Fin, Fout, K, workspace, workspace_bytes,
+                           (hipStream_t)hip_stream);
 }
 
 int dsph_rows_pack(const float* src, int64_t src_rows, const int32_t* idx, int64_t n_idx,

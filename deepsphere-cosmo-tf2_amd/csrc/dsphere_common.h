@@ -48,12 +48,18 @@ int launch_cheb_contract(const float* const* planes, int64_t plane_rows, const f
                          int32_t Fout, int32_t K, int32_t act, int32_t precision,
                          hipStream_t stream);
 
+size_t wgrad_workspace_bytes(int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K);
+int launch_cheb_wgrad(const float* const* planes, int64_t plane_rows, const float* dy, float* dw,
+                      int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K, void* workspace,
+                      size_t workspace_bytes, hipStream_t stream);
+
 int launch_rows_pack(const float* src, int64_t src_rows, const int32_t* idx, int64_t n_idx,
                      float* buf, int64_t N, int32_t F, bool unpack, hipStream_t stream);
 
 // fused path (cheb_fused.hip)
 FusedPlan* fused_plan_build(const dsph_plan* plan, const int32_t* h_cols, const float* h_vals);
 void fused_plan_destroy(FusedPlan* fp);
+void fused_plan_invalidate(FusedPlan* fp);
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,

@@ -55,6 +55,12 @@ SIGNATURES = {
         [_c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, ctypes.c_int,
          _c_vp],
     ),
+    "dsph_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_i64, _c_i64, _c_i32, _c_i32, _c_i32]),
+    "dsph_cheb_wgrad": (
+        ctypes.c_int,
+        [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_vp, ctypes.c_size_t, ctypes.c_int,
+         _c_vp],
+    ),
     "dsph_rows_pack": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_i64, _c_i32, ctypes.c_int, _c_vp]),
     "dsph_rows_unpack": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_i64, _c_i32, ctypes.c_int, _c_vp]),
 }
@@ -229,7 +235,9 @@ def cheb_step(plan, inp, prev, alpha, beta, rows=0, out=None):
     if prev is not None:
         _check_dev(prev, plan, "prev")
     if out is None:
-        out = torch.zeros_like(inp)
+        # rows the step does not produce (halo rows of a shard, rows beyond `rows`) stay zero
+        full = plan.n_cols == plan.n_rows and (rows <= 0 or rows == plan.n_rows)
+        out = torch.empty_like(inp) if full else torch.zeros_like(inp)
     rc = lib().dsph_cheb_step(plan.handle, _ptr(inp), _ptr(prev), _ptr(out), int(N), int(F), float(alpha),
                               float(beta), int(rows), _stream_ptr(inp.device))
     check(rc, "dsph_cheb_step")
@@ -250,6 +258,27 @@ def cheb_contract(planes, w, bias, rows, K, act=ACT_NONE, precision=PREC_FP32):
                                   _stream_ptr(p0.device))
     check(rc, "dsph_cheb_contract")
     return out
+
+
+def cheb_wgrad(planes, dy, rows=None, workspace=None):
+    """dw[f*K + k, o] = sum_{n,m} planes[k][n,m,f] * dy[n,m,o] for a list of K (N, plane_rows, Fin) planes."""
+    import torch
+
+    p0 = planes[0]
+    K = len(planes)
+    N, plane_rows, Fin = p0.shape
+    rows = int(dy.shape[1]) if rows is None else int(rows)
+    Fout = int(dy.shape[2])
+    need = int(lib().dsph_wgrad_workspace_bytes(int(N), rows, int(Fin), Fout, K))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=p0.device)
+    dw = torch.empty((Fin * K, Fout), dtype=torch.float32, device=p0.device)
+    arr = (_c_vp * K)(*[p.data_ptr() for p in planes])
+    rc = lib().dsph_cheb_wgrad(ctypes.cast(arr, _c_vp), int(plane_rows), _ptr(dy), _ptr(dw), int(N), rows, int(Fin),
+                               Fout, K, _ptr(workspace), workspace.numel() * workspace.element_size(),
+                               p0.device.index, _stream_ptr(p0.device))
+    check(rc, "dsph_cheb_wgrad")
+    return dw, workspace
 
 
 def rows_pack(src, idx, out=None):

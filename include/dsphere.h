@@ -131,6 +131,16 @@ int dsph_cheb_contract(const float* const* planes, int64_t plane_rows, const flo
                        int32_t Fout, int32_t K, int32_t act, int32_t precision, int device,
                        void* hip_stream);
 
+/* Weight gradient (training):  dw[f*K + k, o] = sum_{n, m < rows} planes[k][n,m,f] * dy[n,m,o]
+ * for K planes T_k x of shape (N, plane_rows, Fin) (HOST array of K device pointers, e.g. x and the
+ * outputs of dsph_cheb_step) and an upstream gradient dy (N, rows, Fout).  The reference has no
+ * counterpart of its own: TensorFlow differentiates tf.matmul (gnn_layers.py:149).  Deterministic
+ * (fixed-order reduction of per-workgroup partial sums held in `workspace`). */
+size_t dsph_wgrad_workspace_bytes(int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K);
+int dsph_cheb_wgrad(const float* const* planes, int64_t plane_rows, const float* dy, float* dw,
+                    int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K, void* workspace,
+                    size_t workspace_bytes, int device, void* hip_stream);
+
 /* Gather / scatter of boundary rows for the halo exchange of the sharded path:
  *   pack:   buf[n, i, :] = src[n, idx[i], :]       src (N, src_rows, F), buf (N, n_idx, F)
  *   unpack: dst[n, idx[i], :] = buf[n, i, :]

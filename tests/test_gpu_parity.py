@@ -525,3 +525,15 @@ def test_healpy_gcnn_forward_and_weight_round_trip():
     assert not torch.allclose(y1, y2, atol=1e-6)
     m2.load_state_dict(m1.state_dict())
     assert torch.allclose(m2(x), y1, atol=1e-6)
+
+
+@pytest.mark.parametrize("Fin,Fout,K,N,M", [(7, 70, 3, 2, 1000), (64, 64, 5, 1, 5000), (16, 8, 9, 3, 4099), (33, 3, 1, 1, 77)])
+def test_wgrad_kernel(Fin, Fout, K, N, M):
+    rng = np.random.default_rng(Fin + K)
+    planes = rng.standard_normal((K, N, M, Fin)).astype(np.float32)
+    dy = rng.standard_normal((N, M, Fout)).astype(np.float32)
+    ref = np.einsum("knmf,nmo->fko", planes.astype(np.float64), dy.astype(np.float64)).reshape(Fin * K, Fout)
+    dw, _ = _native.cheb_wgrad([_dev(planes[k]) for k in range(K)], _dev(dy))
+    assert rel_err(dw.cpu().numpy(), ref) < 1e-5
+    dw2, _ = _native.cheb_wgrad([_dev(planes[k]) for k in range(K)], _dev(dy))
+    assert torch.equal(dw, dw2)  # fixed-order reduction: bitwise reproducible
