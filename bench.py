@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="contraction arithmetic: bf16x3 = 3-pass split-bf16 MFMA with fp32 accumulate (error 4-6e-6 of max|y|, inside the fp32 tolerance); fp32 = exact fp32 MFMA")
     ap.add_argument("--algo", default="auto", choices=["auto", "unfused", "fused"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = halo rows "
+                         "staged through the host, ranks dealt round-robin over the visible GPUs (debugging on a 1-GPU box)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline; 0 disables it")
     args = ap.parse_args()
 
@@ -107,6 +110,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -114,7 +119,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
 
     from deepsphere import gnn_layers
 
@@ -146,7 +154,8 @@ def main():
         run = lambda: shard(x)  # noqa: E731
         fused = shard.plan.fused_ok(Fin, Fout, K) and args.algo != "unfused"
         kernel_name = ("cheb_fused_kernel" if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \
-            " + rows_pack_kernel + RCCL send/recv of the (K-1)-ring halo"
+            " + rows_pack_kernel + " + \
+            ("RCCL send/recv" if args.backend == "nccl" else "gloo send/recv (host-staged)") + " of the (K-1)-ring halo"
     setup_s = time.time() - t0
 
     def barrier():
@@ -167,7 +176,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     per_fwd_ms = [a.elapsed_time(b) for a, b in ev]  # HIP events on the stream the kernels run on
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

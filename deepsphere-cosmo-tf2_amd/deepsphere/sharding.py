@@ -175,19 +175,26 @@ class ShardedChebyshev:
         x_ext[:, :own].copy_(x_local)
         if self.world == 1 or not (self._send_idx or self._recv_idx):
             return x_ext
+        # RCCL moves device buffers directly (xGMI peer-to-peer).  Under a gloo group (no RCCL: several
+        # ranks sharing one GPU, debugging) the packed rows are staged through host memory instead;
+        # only the transport differs, the pack / unpack kernels and the forward are the same.
+        via_host = x_local.is_cuda and dist.get_backend(self.group) == "gloo"
         ops, recv_bufs, keep = [], {}, []
         for p, idx in self._send_idx.items():
             buf = _pack(x_ext, idx)
+            if via_host:
+                buf = buf.cpu()
             keep.append(buf)
             ops.append(dist.P2POp(dist.isend, buf, self._peer(p), group=self.group))
         for p, idx in self._recv_idx.items():
-            buf = torch.empty((N, idx.numel(), F), dtype=torch.float32, device=x_local.device)
+            buf = torch.empty((N, idx.numel(), F), dtype=torch.float32,
+                              device="cpu" if via_host else x_local.device)
             recv_bufs[p] = buf
             ops.append(dist.P2POp(dist.irecv, buf, self._peer(p), group=self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         for p, buf in recv_bufs.items():
-            _unpack(x_ext, self._recv_idx[p], buf)
+            _unpack(x_ext, self._recv_idx[p], buf.to(x_local.device) if via_host else buf)
         return x_ext
 
     def _peer(self, p):
