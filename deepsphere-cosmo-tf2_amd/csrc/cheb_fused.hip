@@ -266,7 +266,7 @@ bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K
   if (!ft.ok) return false;
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   if (pr == 0) return false;
-  const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wfrag_bytes(Fin, Fout, K);
+  const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wfrag_bytes(Fin, Fout, K) + FUSED_BIAS_BYTES;
   return lds <= (size_t)LDS_BYTES;
 }
 
@@ -354,8 +354,32 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wb;
   const int grid = std::max(8, std::min(plan->fused->num_cu, (ft.ntiles + 7) / 8 * 8));
+#ifdef DSPH_STAMPS
+  static unsigned long long* d_stamps = nullptr;
+  constexpr size_t NST = 8 * 8 * 32;
+  if (!d_stamps) DSPH_HIP(hipMalloc(&d_stamps, NST * 8));
+  DSPH_HIP(hipMemsetAsync(d_stamps, 0, NST * 8, stream));
+  args.stamps = d_stamps;
+  auto dump_stamps = [&](int rc) {
+    if (rc != DSPH_OK || !getenv("DSPH_STAMPS_DUMP")) return rc;
+    std::vector<unsigned long long> h(NST);
+    if (hipStreamSynchronize(stream) != hipSuccess) return rc;
+    if (hipMemcpy(h.data(), d_stamps, NST * 8, hipMemcpyDeviceToHost) != hipSuccess) return rc;
+    for (int w = 0; w < 8; ++w)
+      for (int it = 0; it < 8; ++it) {
+        fprintf(stderr, "STAMP wave %d item %d:", w, it + 4);
+        const unsigned long long* r = &h[((size_t)w * 8 + it) * 32];
+        for (int i = 1; i < 32; ++i) fprintf(stderr, " %lld", r[i] && r[i - 1] ? (long long)(r[i] - r[i - 1]) : -1LL);
+        fprintf(stderr, " | t0 %llu\n", r[0]);
+      }
+    return rc;
+  };
+#define DSPH_FUSED_CASE(PR, WT) \
+  if (pr == PR && ft.width == WT) return dump_stamps(launch_fused_##PR##_##WT(args, NB, precision, grid, lds, stream));
+#else
 #define DSPH_FUSED_CASE(PR, WT) \
   if (pr == PR && ft.width == WT) return launch_fused_##PR##_##WT(args, NB, precision, grid, lds, stream);
+#endif
   DSPH_FUSED_CASE(576, 9)
   DSPH_FUSED_CASE(768, 9)
   DSPH_FUSED_CASE(928, 9)

@@ -3,6 +3,8 @@
 // compiled once per (plane rows, ELL width) pair so that the instantiations build in parallel.
 #pragma once
 
+#include <type_traits>
+
 #include "dsphere_common.h"
 
 namespace dsph {
@@ -12,6 +14,7 @@ constexpr int FUSED_CH = 16;        // channels per slice
 constexpr int FUSED_DMAX = 8;       // deepest halo supported (K <= 9)
 constexpr int FUSED_THREADS = 512;  // 8 waves, 2 per SIMD
 constexpr int LDS_BYTES = 160 * 1024;
+constexpr int FUSED_BIAS_BYTES = 256;  // the bias (<= 64 floats, zero-padded) sits in the last bytes of the LDS
 constexpr int G_ROWS = FUSED_THREADS / 4;  // recurrence: four lanes share a region row, 128 rows per pass
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -31,7 +34,10 @@ struct FusedArgs {
   int64_t x_rows, y_rows;
   int N, Fin, Fout, K, ntiles, nchunks, act, wfrag_bytes;
   float alpha_rest, beta_rest;  // step k >= 2: T_k = alpha * L~ T_{k-1} - beta * T_{k-2} (2,1 Chebyshev; 1,0 monomial)
-  int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no MFMA, 4 no x loads, 8 no y store
+#ifdef DSPH_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: [8 waves][8 items][32 points] s_memtime values
+#endif
+  int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no MFMA, 8 no y store
 };
 
 // Byte offset of 16-byte slot `slot` (0..3) of region row `row` inside a [rows][16] fp32 plane.
@@ -43,13 +49,36 @@ __device__ __forceinline__ unsigned plane_byte(unsigned row, unsigned slot) {
   return row * (FUSED_CH * 4) + 16u * (slot ^ ((row >> 2) & 3u));
 }
 
-// One plane T_k (tile rows 32*wave .. +32, all 16 channels of the slice) into the MFMA
-// accumulators: A from the LDS plane, converted on the fly to split bf16 when PREC says so; B (the
-// weight fragments of (order k, slice c), already in operand order) from LDS.
+// The B operand of one plane's MFMAs: the weight fragments of (order k, slice c), already in operand
+// order in LDS.  Read into registers *before* the barrier that completes the plane (they do not depend
+// on it), so that after the barrier only the A rows stand between the wave and its first MFMA.
 template <int NB, int PREC>
-__device__ __forceinline__ void mfma_plane(const unsigned char* __restrict__ plane,
-                                           const unsigned char* __restrict__ wblk, int wave, int lane,
-                                           f32x16 (&acc)[NB]) {
+struct WFrag {
+  bf16x8 hi[NB], lo[NB];  // PREC == BF16X3
+  float f[8][NB];         // PREC == FP32
+};
+
+template <int NB, int PREC>
+__device__ __forceinline__ void load_wfrag(const unsigned char* __restrict__ wblk, int lane, WFrag<NB, PREC>& w) {
+  if (PREC == DSPH_PREC_BF16X3) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      w.hi[b] = *reinterpret_cast<const bf16x8*>(wblk + b * 2048 + lane * 16);
+      w.lo[b] = *reinterpret_cast<const bf16x8*>(wblk + b * 2048 + 1024 + lane * 16);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) w.f[t][b] = *reinterpret_cast<const float*>(wblk + b * 2048 + t * 256 + lane * 4);
+  }
+}
+
+// One plane T_k (tile rows 32*wave .. +32, all 16 channels of the slice) into the MFMA
+// accumulators: A from the LDS plane, converted on the fly to split bf16 when PREC says so.
+template <int NB, int PREC>
+__device__ __forceinline__ void mfma_plane(const unsigned char* __restrict__ plane, const WFrag<NB, PREC>& w,
+                                           int wave, int lane, f32x16 (&acc)[NB]) {
   const unsigned r = lane & 31, h = lane >> 5;
   const unsigned row = wave * 32 + r;
   const float4 a0 = *reinterpret_cast<const float4*>(plane + plane_byte(row, 2 * h));
@@ -65,22 +94,25 @@ __device__ __forceinline__ void mfma_plane(const unsigned char* __restrict__ pla
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(wblk + b * 2048 + lane * 16);
-      const bf16x8 blo = *reinterpret_cast<const bf16x8*>(wblk + b * 2048 + 1024 + lane * 16);
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[b], 0, 0, 0);  // small terms first
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, w.hi[b], acc[b], 0, 0, 0);  // small terms first
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, w.lo[b], acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, w.hi[b], acc[b], 0, 0, 0);
     }
   } else {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const float bv = *reinterpret_cast<const float*>(wblk + b * 2048 + t * 256 + lane * 4);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[b], 0, 0, 0);
-      }
+      for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], w.f[t][b], acc[b], 0, 0, 0);
     }
   }
+}
+
+// Orders one wave's LDS writes before its own later LDS reads (the block a wave transposes is private
+// to it).  Only the LDS counter is waited on: a workgroup-scope fence here also drains vmcnt, i.e. it
+// stalls on the x prefetch just issued and on the previous block's y stores (7 k cycles per map).
+__device__ __forceinline__ void lds_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // The four lanes that share a region row keep that row's ELL values spread over the quad: register g
@@ -138,6 +170,23 @@ __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pi
   }
 }
 
+// Diagnostic build (make STAMPS=1; never the shipped library): s_memtime at the phase boundaries of a few
+// items of one workgroup, into a buffer nothing else reads.  Read the shares, not the run time.
+#ifdef DSPH_STAMPS
+#define DSPH_STAMP(id)                                                                        \
+  do {                                                                                        \
+    if (stamp_on) {                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
+      unsigned long long t_;                                                                  \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
+      if (lane == 0) a.stamps[((size_t)wave * 8 + (item - 4)) * 32 + (id)] = t_;              \
+    }                                                                                         \
+  } while (0)
+#else
+#define DSPH_STAMP(id)
+#endif
+
 // PR: rows each LDS plane is sized for; RP: recurrence rows per lane (rows with an ELL row <= 128*RP);
 // WT: ELL width; NB: 32-column output blocks; PREC: contraction arithmetic.
 template <int PR, int WT, int RP, int NB, int PREC>
@@ -150,8 +199,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   unsigned char* const planeX = smem;
   unsigned char* const planeY = smem + PLANE_BYTES;
   unsigned char* const sW = smem + 2 * PLANE_BYTES;
+  float* const sBias = reinterpret_cast<float*>(smem + LDS_BYTES - FUSED_BIAS_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the epilogue must not touch vector memory for anything but its stores: a bias load there makes
+  // the compiler wait for vmcnt(0), i.e. for the x prefetch just issued and the previous y stores
+  if (tid < FUSED_BIAS_BYTES / 4) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
   for (int i = tid * 16; i < a.wfrag_bytes; i += FUSED_THREADS * 16)
     *reinterpret_cast<uint4*>(sW + i) = *reinterpret_cast<const uint4*>(a.wfrag + i);
 
@@ -171,25 +224,32 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   // ---- software prefetch of the next (tile, map, slice): region row ids and x in registers ----
   int rid[NS];
   float4 pf[NS];
-  auto load_rids = [&](int t) {
+  // Both are branch-free on purpose: a load under a lane predicate lands in a temporary that is merged
+  // into pf[] by register moves behind an s_waitcnt vmcnt(0), i.e. the "prefetch" then waits for itself
+  // (1.3-2.5 k cycles per slice).  Rows past the region and channels past Fin read a valid address
+  // instead (the former are never used, the latter are zeroed when the slice is staged).
+  auto load_rids = [&](int tv) {
+    const int t = __builtin_amdgcn_readfirstlane(tv);  // uniform: the two table reads below stay scalar loads
     const int off = a.tile_off[t];
     const int R = a.ring_end[(size_t)t * (FUSED_DMAX + 1) + D];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int row = (tid + s * FUSED_THREADS) >> 2;
-      rid[s] = row < R ? a.region[off + row] : -1;
+      rid[s] = a.region[off + (row < R ? row : R - 1)];
     }
   };
-  auto issue_loads = [&](int item) {
+  // Slice `item`'s loads, one float4 per lane and slot s: all of them (slot < 0) or those of one phase.
+  auto issue_loads = [&](int item, int slot) {
     const int n = item / a.nchunks, c = item - n * a.nchunks;
-    const int ch = c * FUSED_CH + 4 * (tid & 3);
+    const int ch0 = c * FUSED_CH + 4 * (tid & 3);
+    const int ch = ch0 < a.Fin ? ch0 : a.Fin - 4;
+    const float* __restrict__ xb = a.x + (int64_t)n * a.x_rows * a.Fin + ch;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rid[s] >= 0 && ch < a.Fin && !(a.dbg & 4))
-        v = *reinterpret_cast<const float4*>(a.x + ((int64_t)n * a.x_rows + rid[s]) * a.Fin + ch);
-      pf[s] = v;
+      if (slot >= 0 && (s < a.K ? s : 0) != slot) continue;
+      pf[s] = *reinterpret_cast<const float4*>(xb + (int64_t)rid[s] * a.Fin);
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   // ---- y store of a finished map, deferred into the next item's slot 0 ---------------------------
@@ -203,40 +263,34 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   bool pend = false;
   int pend_n = 0, pend_Pt = 0;
   int64_t pend_row0 = 0;
-  auto store_pending = [&]() {
+  auto store_impl = [&](auto act_c, auto vec_c) {
+    constexpr int ACT = decltype(act_c)::value;   // compile-time activation, or -1: a.act at run time
+    constexpr bool VEC = decltype(vec_c)::value;  // Fout % 4 == 0 and y 16-byte aligned
     constexpr int T_LD = 36;  // padded row (floats) of a wave's 32 x 32 block; 8 waves fill plane Y exactly
     float* __restrict__ tw = reinterpret_cast<float*>(planeY) + wave * (32 * T_LD);
     const int li = lane & 31, h = lane >> 5;
     const int cq0 = (lane & 7) * 4, rsub = lane >> 3;
-    const bool vec_ok = (a.Fout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+    const int act = ACT >= 0 ? ACT : a.act;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) tw[((q & 3) + 8 * (q >> 2) + 4 * h) * T_LD + li] = acc[b][q];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      lds_wave_sync();
       const int cq = 32 * b + cq0;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.bias) {
-        bv.x = cq + 0 < a.Fout ? a.bias[cq + 0] : 0.f;
-        bv.y = cq + 1 < a.Fout ? a.bias[cq + 1] : 0.f;
-        bv.z = cq + 2 < a.Fout ? a.bias[cq + 2] : 0.f;
-        bv.w = cq + 3 < a.Fout ? a.bias[cq + 3] : 0.f;
-      }
+      const float4 bv = *reinterpret_cast<const float4*>(sBias + cq);
+      float* __restrict__ yp0 = a.y + ((int64_t)pend_n * a.y_rows + pend_row0 + wave * 32 + rsub) * a.Fout + cq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = i * 8 + rsub;
         float4 v = *reinterpret_cast<const float4*>(tw + row * T_LD + cq0);
-        v.x = apply_act(v.x + bv.x, a.act);
-        v.y = apply_act(v.y + bv.y, a.act);
-        v.z = apply_act(v.z + bv.z, a.act);
-        v.w = apply_act(v.w + bv.w, a.act);
-        const int grow = wave * 32 + row;
-        if (grow < pend_Pt) {
-          float* __restrict__ yp = a.y + ((int64_t)pend_n * a.y_rows + pend_row0 + grow) * a.Fout + cq;
-          if (vec_ok && cq + 3 < a.Fout) {
-            *reinterpret_cast<float4*>(yp) = v;
+        v.x = apply_act(v.x + bv.x, act);
+        v.y = apply_act(v.y + bv.y, act);
+        v.z = apply_act(v.z + bv.z, act);
+        v.w = apply_act(v.w + bv.w, act);
+        float* __restrict__ yp = yp0 + (int64_t)(i * 8) * a.Fout;
+        if (wave * 32 + row < pend_Pt) {
+          if (VEC) {
+            if (cq < a.Fout) *reinterpret_cast<float4*>(yp) = v;
           } else {
             if (cq + 0 < a.Fout) yp[0] = v.x;
             if (cq + 1 < a.Fout) yp[1] = v.y;
@@ -245,17 +299,29 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      lds_wave_sync();
     }
     pend = false;
+  };
+  // One uniform switch per map instead of one per element: with the activation switch inlined 128 times
+  // the epilogue was 5 k instructions of branches and took 7 k cycles per map (mostly instruction fetch).
+  const bool vec_ok = (a.Fout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+  auto store_pending = [&]() {
+    using std::integral_constant;
+    if (!vec_ok) return store_impl(integral_constant<int, -1>{}, integral_constant<bool, false>{});
+    switch (a.act) {
+      case DSPH_ACT_NONE: return store_impl(integral_constant<int, DSPH_ACT_NONE>{}, integral_constant<bool, true>{});
+      case DSPH_ACT_RELU: return store_impl(integral_constant<int, DSPH_ACT_RELU>{}, integral_constant<bool, true>{});
+      default: return store_impl(integral_constant<int, -1>{}, integral_constant<bool, true>{});
+    }
   };
 
   int t = t_begin + slot0;
   if (t < t_end) {
     load_rids(t);
-    issue_loads(0);
+    issue_loads(0, -1);
+    // from here on rid[] holds the rows of the tile of the slice after the one being loaded
+    load_rids(items >= 2 || t + nslots >= t_end ? t : t + nslots);
   }
   for (; t < t_end; t += nslots) {
     // ring sizes of this tile, 11 bits each, in two scalar registers (re-reading them from memory
@@ -296,51 +362,97 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
 
     for (int item = 0; item < items; ++item) {
       const int n = item / a.nchunks, c = item - n * a.nchunks;
+#ifdef DSPH_STAMPS
+      const bool stamp_on = blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
+#endif
+      DSPH_STAMP(0);
       __syncthreads();  // the previous slice's last plane is still being read
+      DSPH_STAMP(1);
       // ---- T_0: the prefetched x slice goes to plane X; fetch the next slice meanwhile -------
+      const bool ch_ok = c * FUSED_CH + 4 * (tid & 3) < a.Fin;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const unsigned idx = tid + s * FUSED_THREADS;
-        if (idx < (unsigned)PR * 4) *reinterpret_cast<float4*>(planeX + plane_byte(idx >> 2, idx & 3)) = pf[s];
+        float4 v = pf[s];
+        v.x = ch_ok ? v.x : 0.f;
+        v.y = ch_ok ? v.y : 0.f;
+        v.z = ch_ok ? v.z : 0.f;
+        v.w = ch_ok ? v.w : 0.f;
+        if (idx < (unsigned)PR * 4) *reinterpret_cast<float4*>(planeX + plane_byte(idx >> 2, idx & 3)) = v;
       }
-      if (item + 1 < items) {
-        issue_loads(item + 1);
-      } else if (t + nslots < t_end) {
-        load_rids(t + nslots);
-        issue_loads(0);
-      }
+      // the region rows fetched at the end of the previous slice are "used" here, next to the wait the
+      // staging needed anyway; otherwise each phase's load waits vmcnt(0) for them, i.e. for the load before it
+#pragma unroll
+      for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(rid[s]));
+      DSPH_STAMP(2);
+      // The next slice (of this tile, or the first one of this workgroup's next tile): its loads go out
+      // one per phase, unconditionally -- after the very last slice they re-read valid rows for nothing --
+      // because a conditional load is merged into pf[] by moves behind a vmcnt(0).
+      const int nitem = item + 1 < items ? item + 1 : 0;
+      issue_loads(nitem, 0);
+      DSPH_STAMP(3);
       if (pend && !(a.dbg & 8)) store_pending();
+      DSPH_STAMP(4);
       if (c == 0) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
       }
-      __syncthreads();
+      DSPH_STAMP(5);
       const unsigned char* __restrict__ wblk = sW + (size_t)c * NB * 2048;
-      if (do_m) mfma_plane<NB, PREC>(planeX, wblk, wave, lane, acc);
+      WFrag<NB, PREC> wf;
+      load_wfrag<NB, PREC>(wblk, lane, wf);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      DSPH_STAMP(6);
+      if (do_m) mfma_plane<NB, PREC>(planeX, wf, wave, lane, acc);
+      DSPH_STAMP(7);
 
       // ---- recurrence, two steps per trip so that the plane roles are compile-time ----------
+      issue_loads(nitem, 1);
       if (do_g) gather_step<WT, RP, false>(planeX, planeY, re(D - 1), row_l, val, pre, own);
+      DSPH_STAMP(8);
+      load_wfrag<NB, PREC>(wblk + wstride, lane, wf);
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
-      if (do_m) mfma_plane<NB, PREC>(planeY, wblk + wstride, wave, lane, acc);
+      DSPH_STAMP(9);
+      if (do_m) mfma_plane<NB, PREC>(planeY, wf, wave, lane, acc);
+      DSPH_STAMP(10);
       for (int k = 2; k < a.K; k += 2) {
+        issue_loads(nitem, k);
         if (do_g) {
           if (cheb) gather_step<WT, RP, true>(planeY, planeX, re(D - k), row_l, val, pre, own);
           else gather_step<WT, RP, false>(planeY, planeX, re(D - k), row_l, val, pre, own);
         }
+        DSPH_STAMP(11 + (k - 2) * 3);
+        load_wfrag<NB, PREC>(wblk + (size_t)k * wstride, lane, wf);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        if (do_m) mfma_plane<NB, PREC>(planeX, wblk + (size_t)k * wstride, wave, lane, acc);
+        DSPH_STAMP(12 + (k - 2) * 3);
+        if (do_m) mfma_plane<NB, PREC>(planeX, wf, wave, lane, acc);
+        DSPH_STAMP(13 + (k - 2) * 3);
         if (k + 1 < a.K) {
+          issue_loads(nitem, k + 1);
           if (do_g) {
             if (cheb) gather_step<WT, RP, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
             else gather_step<WT, RP, false>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
           }
+          DSPH_STAMP(14 + (k - 2) * 3);
+          load_wfrag<NB, PREC>(wblk + (size_t)(k + 1) * wstride, lane, wf);
+          __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
-          if (do_m) mfma_plane<NB, PREC>(planeY, wblk + (size_t)(k + 1) * wstride, wave, lane, acc);
+          DSPH_STAMP(15 + (k - 2) * 3);
+          if (do_m) mfma_plane<NB, PREC>(planeY, wf, wave, lane, acc);
+          DSPH_STAMP(16 + (k - 2) * 3);
         }
       }
 
+      {  // all loads of the next slice are out: fetch the region rows of the slice after it
+        const int adv = (item + 2) / items;  // 0: this tile, 1 or 2 (single-slice tiles): tiles ahead
+        const int t2 = t + adv * nslots;
+        load_rids(t2 < t_end ? t2 : t);
+      }
       if (c == a.nchunks - 1) {  // this map's accumulators are complete: store them in the next slot 0
         pend = true;
         pend_n = n;
