@@ -302,31 +302,60 @@ __global__ __launch_bounds__(256) void fused_wprep_kernel(const float* __restric
   }
 }
 
+static int launch_fused_common(const dsph_plan* plan, const float* x, const float* w, const float* bias,
+                               float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
+                               int32_t act, int32_t precision, float alpha_rest, float beta_rest,
+                               void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,
                       size_t workspace_bytes, hipStream_t stream) {
+  return launch_fused_common(plan, x, w, bias, y, nullptr, N, Fin, Fout, K, act, precision, alpha_rest,
+                             beta_rest, workspace, workspace_bytes, stream);
+}
+
+// Planes mode of the same kernel: T_1 .. T_{K-1} of x, each (N, n_cols, Fin), valid on the plan's output rows.
+bool fused_planes_supported(const dsph_plan* plan, int32_t Fin, int32_t K) { return fused_supported(plan, Fin, 1, K); }
+
+int launch_cheb_fused_planes(const dsph_plan* plan, const float* x, float* planes_out, int64_t N, int32_t Fin,
+                             int32_t K, float alpha_rest, float beta_rest, hipStream_t stream) {
+  return launch_fused_common(plan, x, nullptr, nullptr, nullptr, planes_out, N, Fin, 1, K, DSPH_ACT_NONE,
+                             DSPH_PREC_FP32, alpha_rest, beta_rest, nullptr, 0, stream);
+}
+
+static int launch_fused_common(const dsph_plan* plan, const float* x, const float* w, const float* bias,
+                               float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
+                               int32_t act, int32_t precision, float alpha_rest, float beta_rest,
+                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!fused_supported(plan, Fin, Fout, K)) {
     set_error("cheb_fused: plan/shape not supported");
     return DSPH_E_UNSUPPORTED;
   }
+  const bool planes_mode = planes_out != nullptr;
   const FusedTiles& ft = get_tiles(plan, K - 1);
-  const size_t wb = wfrag_bytes(Fin, Fout, K);
-  if (!workspace || workspace_bytes < wb) {
+  const size_t wb = planes_mode ? 0 : wfrag_bytes(Fin, Fout, K);
+  if (!planes_mode && (!workspace || workspace_bytes < wb)) {
     set_error("cheb_fused: workspace %zu < %zu", workspace_bytes, wb);
     return DSPH_E_WORKSPACE;
   }
-  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) {
-    set_error("cheb_fused: x and workspace must be 16-byte aligned");
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15) ||
+      (reinterpret_cast<uintptr_t>(planes_out) & 15)) {
+    set_error("cheb_fused: x, workspace and planes must be 16-byte aligned");
     return DSPH_E_BADARG;
   }
   const int C = (Fin + FUSED_CH - 1) / FUSED_CH, NB = (Fout + 31) / 32;
-  hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,
-                     static_cast<unsigned char*>(workspace), (int)Fin, (int)Fout, (int)K, C, NB,
-                     (int)precision);
-  DSPH_HIP(hipGetLastError());
+  if (!planes_mode) {
+    hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,
+                       static_cast<unsigned char*>(workspace), (int)Fin, (int)Fout, (int)K, C, NB,
+                       (int)precision);
+    DSPH_HIP(hipGetLastError());
+  }
 
   FusedArgs args;
+  args.planes_out = planes_out;
+  args.prow_stride = plan->n_cols;
+  args.plane_stride = N * plan->n_cols * (int64_t)Fin;
   args.x = x;
   args.bias = bias;
   args.y = y;

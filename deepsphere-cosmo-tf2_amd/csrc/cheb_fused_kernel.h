@@ -31,6 +31,9 @@ struct FusedArgs {
   const int32_t* region;
   const uint16_t* lcols;
   const float* lvals;
+  float* planes_out;      // planes mode: T_1 .. T_{K-1}, each (N, prow_stride, Fin), written on the tile rows
+  int64_t plane_stride;   //   elements per plane
+  int64_t prow_stride;    //   rows per map of a plane
   int64_t x_rows, y_rows;
   int N, Fin, Fout, K, ntiles, nchunks, act, wfrag_bytes;
   float alpha_rest, beta_rest;  // step k >= 2: T_k = alpha * L~ T_{k-1} - beta * T_{k-2} (2,1 Chebyshev; 1,0 monomial)
@@ -138,11 +141,14 @@ __device__ __forceinline__ float quad_bcast(float v, int lane_in_quad) {
 // registers.  The summation order (slot j ascending, fused multiply-add) is the unfused kernel's.
 // Every lane of a quad must execute the broadcasts, so the row guard covers whole quads (it does:
 // the four lanes of a quad share the row).
-template <int WT, int RP, bool CHEB_STEP>
+// SAVE: also write the new plane's tile rows (the first two passes: rows < save_rows <= 256) to global
+// memory at `save` (this lane's row_l and channel slot already added; 128 rows = save_pass floats apart).
+template <int WT, int RP, bool CHEB_STEP, bool SAVE = false>
 __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pin,
                                             unsigned char* __restrict__ pout, int nrows, int row_l,
                                             const float (&valc)[RP][(WT + 3) / 4], const unsigned (&pre)[RP][WT],
-                                            const unsigned (&own)[RP]) {
+                                            const unsigned (&own)[RP], float* __restrict__ save = nullptr,
+                                            int64_t save_pass = 0, int save_rows = 0) {
 #pragma unroll
   for (int p = 0; p < RP; ++p) {
     if (row_l + p * G_ROWS < nrows) {
@@ -165,6 +171,8 @@ __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pi
         s.w = 2.f * s.w - q.w;
       }
       *op = s;
+      if (SAVE && p * G_ROWS < FUSED_P && row_l + p * G_ROWS < save_rows)
+        *reinterpret_cast<float4*>(save + p * save_pass) = s;
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the passes apart: 9 gathers in flight, not 9*RP
   }
@@ -189,7 +197,10 @@ __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pi
 
 // PR: rows each LDS plane is sized for; RP: recurrence rows per lane (rows with an ELL row <= 128*RP);
 // WT: ELL width; NB: 32-column output blocks; PREC: contraction arithmetic.
-template <int PR, int WT, int RP, int NB, int PREC>
+// MODE 0: the forward.  MODE 1 ("planes"): no contraction at all -- the recurrence alone, with the tile rows of
+// T_1 .. T_{K-1} written to a.planes_out (the weight gradient's left operand, rebuilt in the backward pass
+// at fused speed instead of by K-1 gather launches that go through L2 for every neighbour).
+template <int PR, int WT, int RP, int NB, int PREC, int MODE = 0>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs a) {
   constexpr int PLANE_BYTES = PR * FUSED_CH * 4;
   constexpr int NS = (PR * 4 + FUSED_THREADS - 1) / FUSED_THREADS;  // staging float4 per lane
@@ -204,9 +215,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the epilogue must not touch vector memory for anything but its stores: a bias load there makes
   // the compiler wait for vmcnt(0), i.e. for the x prefetch just issued and the previous y stores
-  if (tid < FUSED_BIAS_BYTES / 4) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
-  for (int i = tid * 16; i < a.wfrag_bytes; i += FUSED_THREADS * 16)
-    *reinterpret_cast<uint4*>(sW + i) = *reinterpret_cast<const uint4*>(a.wfrag + i);
+  if (MODE == 0 && tid < FUSED_BIAS_BYTES / 4) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
+  if (MODE == 0) {
+    for (int i = tid * 16; i < a.wfrag_bytes; i += FUSED_THREADS * 16)
+      *reinterpret_cast<uint4*>(sW + i) = *reinterpret_cast<const uint4*>(a.wfrag + i);
+  }
 
   // tiles are dealt to XCDs in contiguous ranges (blocks b and b+8 share an XCD): the 32
   // workgroups of one XCD work on 32 neighbouring tiles at a time and share halos through its L2
@@ -391,6 +404,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       const int nitem = item + 1 < items ? item + 1 : 0;
       issue_loads(nitem, 0);
       DSPH_STAMP(3);
+      if (MODE == 0) {
       if (pend && !(a.dbg & 8)) store_pending();
       DSPH_STAMP(4);
       if (c == 0) {
@@ -447,13 +461,37 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
           DSPH_STAMP(16 + (k - 2) * 3);
         }
       }
+      } else {
+        // ---- planes mode: the recurrence alone; every new plane's tile rows also go to planes_out ----
+        const int64_t spass = (int64_t)G_ROWS * a.Fin;
+        float* __restrict__ sp = a.planes_out + ((int64_t)n * a.prow_stride + row0 + row_l) * a.Fin +
+                                 (ch_ok ? c * FUSED_CH + 4 * (int)qslot : 0);
+        const int srows = ch_ok ? P_t : 0;
+        __syncthreads();
+        issue_loads(nitem, 1);
+        gather_step<WT, RP, false, true>(planeX, planeY, re(D - 1), row_l, val, pre, own, sp, spass, srows);
+        for (int k = 2; k < a.K; k += 2) {
+          __syncthreads();
+          issue_loads(nitem, k);
+          sp += a.plane_stride;
+          if (cheb) gather_step<WT, RP, true, true>(planeY, planeX, re(D - k), row_l, val, pre, own, sp, spass, srows);
+          else gather_step<WT, RP, false, true>(planeY, planeX, re(D - k), row_l, val, pre, own, sp, spass, srows);
+          if (k + 1 < a.K) {
+            __syncthreads();
+            issue_loads(nitem, k + 1);
+            sp += a.plane_stride;
+            if (cheb) gather_step<WT, RP, true, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own, sp, spass, srows);
+            else gather_step<WT, RP, false, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own, sp, spass, srows);
+          }
+        }
+      }
 
       {  // all loads of the next slice are out: fetch the region rows of the slice after it
         const int adv = (item + 2) / items;  // 0: this tile, 1 or 2 (single-slice tiles): tiles ahead
         const int t2 = t + adv * nslots;
         load_rids(t2 < t_end ? t2 : t);
       }
-      if (c == a.nchunks - 1) {  // this map's accumulators are complete: store them in the next slot 0
+      if (MODE == 0 && c == a.nchunks - 1) {  // this map's accumulators are complete: store them in the next slot 0
         pend = true;
         pend_n = n;
         pend_row0 = row0;
@@ -461,7 +499,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       }
     }
   }
-  if (pend && !(a.dbg & 8)) {  // the last map of this workgroup
+  if (MODE == 0 && pend && !(a.dbg & 8)) {  // the last map of this workgroup
     __syncthreads();
     store_pending();
   }
@@ -479,6 +517,12 @@ static int launch_variant(const FusedArgs& args, int grid, size_t lds, hipStream
 template <int PR, int WT, int RPL>
 static int dispatch_nb_prec(const FusedArgs& args, int nb, int prec, int grid, size_t lds,
                             hipStream_t stream) {
+  if (args.planes_out != nullptr) {  // planes mode: no contraction, nb and prec do not apply
+    auto kern = cheb_fused_kernel<PR, WT, RPL, 1, DSPH_PREC_FP32, 1>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), 0, stream, args);
+    DSPH_HIP(hipGetLastError());
+    return DSPH_OK;
+  }
   if (nb == 1) {
     if (prec == DSPH_PREC_BF16X3) return launch_variant<PR, WT, RPL, 1, DSPH_PREC_BF16X3>(args, grid, lds, stream);
     return launch_variant<PR, WT, RPL, 1, DSPH_PREC_FP32>(args, grid, lds, stream);

@@ -249,6 +249,47 @@ int dsph_poly_forward(const dsph_plan* p, const float* x, const float* w, const 
                               precision, stream);
 }
 
+int dsph_cheb_planes(const dsph_plan* p, const float* x, float* planes, int64_t N, int32_t Fin, int32_t K,
+                     int32_t basis, int32_t algo, void* hip_stream) {
+  if (basis != DSPH_BASIS_CHEBYSHEV && basis != DSPH_BASIS_MONOMIAL) {
+    set_error("cheb_planes: unknown basis %d", basis);
+    return DSPH_E_BADARG;
+  }
+  if (!p || !x || N < 0 || Fin <= 0 || K <= 0 || (K > 1 && !planes)) {
+    set_error("cheb_planes: bad arguments (NULL pointer or non-positive size)");
+    return DSPH_E_BADARG;
+  }
+  if (!p->levels.empty() && (int)p->levels.size() < K - 1) {
+    set_error("cheb_planes: plan has %d levels, K = %d needs %d", (int)p->levels.size(), K, K - 1);
+    return DSPH_E_BADARG;
+  }
+  if (N == 0 || K == 1) return DSPH_OK;
+  const float alpha_rest = basis == DSPH_BASIS_CHEBYSHEV ? 2.f : 1.f;
+  const float beta_rest = basis == DSPH_BASIS_CHEBYSHEV ? 1.f : 0.f;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  DeviceGuard guard(p->device);
+  const bool can_fuse = fused_planes_supported(p, Fin, K);
+  if (algo == DSPH_ALGO_FUSED && !can_fuse) {
+    set_error("cheb_planes: fused kernel cannot run this plan/shape (Fin=%d K=%d)", Fin, K);
+    return DSPH_E_UNSUPPORTED;
+  }
+  if (can_fuse && algo != DSPH_ALGO_UNFUSED)
+    return launch_cheb_fused_planes(p, x, planes, N, Fin, K, alpha_rest, beta_rest, stream);
+  // one gather launch per step (any L, any Fin)
+  const size_t plane = (size_t)N * (size_t)p->n_cols * (size_t)Fin;
+  for (int k = 1; k < K; ++k) {
+    float* outp = planes + plane * (size_t)(k - 1);
+    const float* in = k == 1 ? x : planes + plane * (size_t)(k - 2);
+    const float* prev = (k >= 2 && beta_rest != 0.f) ? (k == 2 ? x : planes + plane * (size_t)(k - 3)) : nullptr;
+    const int64_t rows = step_rows(p, K, k);
+    const int rc = k == 1 ? launch_cheb_step(p, in, p->n_cols, nullptr, p->n_cols, outp, p->n_cols, N, Fin, 1.f, 0.f, rows, stream)
+                          : launch_cheb_step(p, in, p->n_cols, prev, p->n_cols, outp, p->n_cols, N, Fin, alpha_rest,
+                                             beta_rest, rows, stream);
+    if (rc != DSPH_OK) return rc;
+  }
+  return DSPH_OK;
+}
+
 size_t dsph_wgrad_workspace_bytes(int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K) {
   if (N <= 0 || rows <= 0 || Fin <= 0 || Fout <= 0 || K <= 0) return 0;
   return wgrad_workspace_bytes(N, rows, Fin, Fout, K);

@@ -56,6 +56,10 @@ SIGNATURES = {
          _c_vp],
     ),
     "dsph_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_i64, _c_i64, _c_i32, _c_i32, _c_i32]),
+    "dsph_cheb_planes": (
+        ctypes.c_int,
+        [_c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp],
+    ),
     "dsph_cheb_wgrad": (
         ctypes.c_int,
         [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_vp, ctypes.c_size_t, ctypes.c_int,
@@ -258,6 +262,24 @@ def cheb_contract(planes, w, bias, rows, K, act=ACT_NONE, precision=PREC_FP32):
                                   _stream_ptr(p0.device))
     check(rc, "dsph_cheb_contract")
     return out
+
+
+def cheb_planes(plan, x, K, basis=BASIS_CHEBYSHEV, algo=ALGO_AUTO):
+    """[x, T_1 x, ..., T_{K-1} x]: the recurrence without the contraction (``dsph_cheb_planes``).
+    Every plane has x's shape (N, n_cols, Fin) and is valid on the plan's output rows."""
+    import torch
+
+    _check_dev(x, plan, "x")
+    if x.dim() != 3 or x.shape[1] != plan.n_cols:
+        raise ValueError(f"x must be (N, {plan.n_cols}, Fin), got {tuple(x.shape)}")
+    N, M, Fin = x.shape
+    if K <= 1:
+        return [x]
+    out = torch.empty((K - 1, N, M, Fin), dtype=torch.float32, device=x.device)
+    rc = lib().dsph_cheb_planes(plan.handle, _ptr(x), _ptr(out), int(N), int(Fin), int(K), int(basis), int(algo),
+                                _stream_ptr(x.device))
+    check(rc, "dsph_cheb_planes")
+    return [x] + [out[k] for k in range(K - 1)]
 
 
 def cheb_wgrad(planes, dy, rows=None, workspace=None):

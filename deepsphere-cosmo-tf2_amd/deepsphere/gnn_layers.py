@@ -67,8 +67,9 @@ class _ChebConvFunction(torch.autograd.Function):
     * dx = sum_k T_k(L~)^T (dy W_k^T) is the *forward* of the layer on dy with the plan of L~^T (the
       same plan when L~ is symmetric, as every graph Laplacian is) and the weights re-indexed as
       kernel_T[o*K + k, f] = kernel[f*K + k, o];
-    * dkernel[f*K + k, o] = sum_{n,m} (T_k x)[n,m,f] dy[n,m,o]: the planes are rebuilt with
-      ``dsph_cheb_step`` and reduced against dy by ``dsph_cheb_wgrad`` (a split-over-pixels MFMA
+    * dkernel[f*K + k, o] = sum_{n,m} (T_k x)[n,m,f] dy[n,m,o]: the planes are rebuilt by
+      ``dsph_cheb_planes`` (the fused tile kernel without its contraction; K-1 ``dsph_cheb_step``
+      launches where that kernel does not apply) and reduced against dy by ``dsph_cheb_wgrad`` (a split-over-pixels MFMA
       kernel with a fixed-order second stage: a library GEMM has no split-K for a 64 x 64 result
       reduced over 5e7 rows and took 150 ms here).
     """
@@ -101,12 +102,7 @@ class _ChebConvFunction(torch.autograd.Function):
                 algo=_ALGOS[layer.algo], workspace=layer._workspace_t, basis=layer._basis)
         if ctx.needs_input_grad[1]:
             plan = layer._get_plan()
-            planes = [x]
-            for k in range(1, K):
-                if k == 1 or layer._basis == _native.BASIS_MONOMIAL:
-                    planes.append(_native.cheb_step(plan, planes[-1], None, 1.0, 0.0))
-                else:
-                    planes.append(_native.cheb_step(plan, planes[-1], planes[-2], 2.0, 1.0))
+            planes = _native.cheb_planes(plan, x, K, basis=layer._basis, algo=_ALGOS[layer.algo])
             dk, layer._workspace_w = _native.cheb_wgrad(planes, dy, workspace=getattr(layer, "_workspace_w", None))
         return dx, dk, None
 

@@ -131,6 +131,15 @@ int dsph_cheb_contract(const float* const* planes, int64_t plane_rows, const flo
                        int32_t Fout, int32_t K, int32_t act, int32_t precision, int device,
                        void* hip_stream);
 
+/* The planes T_1 x .. T_{K-1} x alone (T_0 x = x), without the contraction: `planes` receives K-1
+ * arrays of x's shape (N, n_cols, Fin) back to back, valid on the plan's output rows.  This is the left
+ * operand of the weight gradient, rebuilt in the backward pass: the same recurrence as
+ * gnn_layers.py:134-143, run by the fused tile kernel (no MFMA, the tile rows of every plane are
+ * stored from LDS) when the plan/shape allows, else by K-1 dsph_cheb_step launches.
+ * `algo`: DSPH_ALGO_AUTO | UNFUSED | FUSED as in dsph_cheb_forward. */
+int dsph_cheb_planes(const dsph_plan* plan, const float* x, float* planes, int64_t N, int32_t Fin,
+                     int32_t K, int32_t basis, int32_t algo, void* hip_stream);
+
 /* Weight gradient (training):  dw[f*K + k, o] = sum_{n, m < rows} planes[k][n,m,f] * dy[n,m,o]
  * for K planes T_k x of shape (N, plane_rows, Fin) (HOST array of K device pointers, e.g. x and the
  * outputs of dsph_cheb_step) and an upstream gradient dy (N, rows, Fout).  The reference has no

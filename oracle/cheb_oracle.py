@@ -215,6 +215,18 @@ def chebyshev_planes(Lt, x, K, dtype=np.float64):
     return np.transpose(out, (0, 2, 1, 3))
 
 
+def monomial_planes(Lt, x, K, dtype=np.float64):
+    """Lt^k x for k = 0..K-1 (the planes of Monomial.call, gnn_layers.py:262-309), shape (K, N, M, Fin)."""
+    x = np.asarray(x, dtype=dtype)
+    Lt = sparse.csr_matrix(Lt).astype(dtype)
+    N, M, Fin = x.shape
+    planes = [np.transpose(x, (1, 0, 2)).reshape(M, N * Fin)]
+    for _k in range(1, K):
+        planes.append(Lt @ planes[-1])
+    out = np.stack(planes, axis=0).reshape(K, M, N, Fin)
+    return np.transpose(out, (0, 2, 1, 3))
+
+
 def chebyshev_forward_closed_form(Lt, x, kernel, K, dtype=np.float64):
     """Independent second derivation: dense Chebyshev matrices T_k and
     y = einsum('kmp,npf,fko->nmo', T, x, kernel.reshape(Fin, K, Fout)).  Small M only."""

@@ -537,3 +537,29 @@ def test_wgrad_kernel(Fin, Fout, K, N, M):
     assert rel_err(dw.cpu().numpy(), ref) < 1e-5
     dw2, _ = _native.cheb_wgrad([_dev(planes[k]) for k in range(K)], _dev(dy))
     assert torch.equal(dw, dw2)  # fixed-order reduction: bitwise reproducible
+
+
+@pytest.mark.parametrize("basis", ["chebyshev", "monomial"])
+@pytest.mark.parametrize("graph,nside,N,Fin,K", [("grid", 16, 2, 64, 5), ("grid", 16, 1, 40, 3), ("knn", 16, 2, 16, 4),
+                                                  ("cap", 16, 2, 32, 5), ("grid", 32, 1, 8, 8)])
+def test_planes_kernel(graph, nside, N, Fin, K, basis):
+    """dsph_cheb_planes (the fused tile kernel without its contraction) against the oracle's planes and
+    against the per-step gather kernel, which it must equal bit for bit (same summation order)."""
+    if graph == "cap":
+        idx = healpix.extend_indices(healpix.cap_indices(nside, fraction=0.3), nside, 4)[:-37]
+        L = healpix.healpix_laplacian(nside, indices=idx, mode="grid")
+    else:
+        L = healpix.healpix_laplacian(nside, mode=graph)
+    scale = 0.75 if basis == "chebyshev" else 1.0
+    Lt, _ = orc.prepare_L(L, scale=scale)
+    plan = _plan(Lt)
+    bcode = _native.BASIS_CHEBYSHEV if basis == "chebyshev" else _native.BASIS_MONOMIAL
+    rng = np.random.default_rng(nside + Fin + K)
+    x = rng.standard_normal((N, Lt.shape[0], Fin)).astype(np.float32)
+    ref = orc.chebyshev_planes(Lt, x, K) if basis == "chebyshev" else orc.monomial_planes(Lt, x, K)
+    fused = _native.cheb_planes(plan, _dev(x), K, basis=bcode, algo=_native.ALGO_FUSED)
+    unfused = _native.cheb_planes(plan, _dev(x), K, basis=bcode, algo=_native.ALGO_UNFUSED)
+    assert len(fused) == K and len(unfused) == K
+    for k in range(K):
+        assert rel_err(fused[k].cpu().numpy(), ref[k]) < TOL_FP32, f"plane {k}"
+        assert torch.equal(fused[k], unfused[k]), f"plane {k}: fused and per-step kernels differ"
