@@ -305,7 +305,8 @@ __global__ __launch_bounds__(256) void fused_wprep_kernel(const float* __restric
 static int launch_fused_common(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
-                               void* workspace, size_t workspace_bytes, hipStream_t stream);
+                               void* workspace, size_t workspace_bytes, hipStream_t stream,
+                               const float* dy = nullptr, float* dw = nullptr);
 
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
@@ -324,15 +325,71 @@ int launch_cheb_fused_planes(const dsph_plan* plan, const float* x, float* plane
                              DSPH_PREC_FP32, alpha_rest, beta_rest, nullptr, 0, stream);
 }
 
+// ---- weight-gradient mode ------------------------------------------------------------------------------
+static int fused_grid(const dsph_plan* plan, const FusedTiles& ft) {
+  return std::max(8, std::min(plan->fused->num_cu, (ft.ntiles + 7) / 8 * 8));
+}
+
+// slices per launch: as many accumulator tiles (one per slice and order, 8 KiB each) as fit the LDS next to the planes
+static int wgrad_slices_per_launch(const dsph_plan* plan, int32_t K) {
+  const FusedTiles& ft = get_tiles(plan, K - 1);
+  const int pr = plane_rows_for(ft.rmax, ft.emax);
+  if (pr == 0) return 0;
+  const long freeb = (long)LDS_BYTES - 2L * pr * FUSED_CH * 4;
+  return (int)(freeb / ((long)K * WG_TILE_BYTES));
+}
+
+bool fused_wgrad_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
+  return fused_supported(plan, Fin, Fout, K) && wgrad_slices_per_launch(plan, K) >= 1;
+}
+
+size_t fused_wgrad_workspace_bytes(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
+  if (!fused_wgrad_supported(plan, Fin, Fout, K)) return 0;
+  const FusedTiles& ft = get_tiles(plan, K - 1);
+  const int C = (Fin + FUSED_CH - 1) / FUSED_CH;
+  return (size_t)2 * fused_grid(plan, ft) * C * K * 16 * 64 * sizeof(float);
+}
+
+// dw[(f*K + k)*Fout + o] = sum over slabs, in slab order (deterministic)
+__global__ __launch_bounds__(256) void fused_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                 int nslabs, int Fin, int Fout, int K, int C) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= Fin * K * Fout) return;
+  const int o = e % Fout, fk = e / Fout, k = fk % K, f = fk / K;
+  const size_t slab = (size_t)C * K * 16 * 64;
+  const size_t off = ((size_t)((f >> 4) * K + k) * 16 + (f & 15)) * 64 + o;
+  float s = 0.f;
+  for (int i = 0; i < nslabs; ++i) s += slabs[(size_t)i * slab + off];
+  dw[e] = s;
+}
+
+int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* dy, float* dw, int64_t N,
+                            int32_t Fin, int32_t Fout, int32_t K, float alpha_rest, float beta_rest,
+                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!fused_wgrad_supported(plan, Fin, Fout, K)) {
+    set_error("cheb_fused_wgrad: plan/shape not supported");
+    return DSPH_E_UNSUPPORTED;
+  }
+  const size_t need = fused_wgrad_workspace_bytes(plan, Fin, Fout, K);
+  if (!workspace || workspace_bytes < need) {
+    set_error("cheb_fused_wgrad: workspace %zu < %zu", workspace_bytes, need);
+    return DSPH_E_WORKSPACE;
+  }
+  return launch_fused_common(plan, x, nullptr, nullptr, static_cast<float*>(workspace), nullptr, N, Fin, Fout, K,
+                             DSPH_ACT_NONE, DSPH_PREC_FP32, alpha_rest, beta_rest, nullptr, 0, stream, dy, dw);
+}
+
 static int launch_fused_common(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
-                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                               void* workspace, size_t workspace_bytes, hipStream_t stream, const float* dy,
+                               float* dw) {
   if (!fused_supported(plan, Fin, Fout, K)) {
     set_error("cheb_fused: plan/shape not supported");
     return DSPH_E_UNSUPPORTED;
   }
-  const bool planes_mode = planes_out != nullptr;
+  const bool wgrad_mode = dy != nullptr;  // y then carries the slab workspace
+  const bool planes_mode = planes_out != nullptr || wgrad_mode;
   const FusedTiles& ft = get_tiles(plan, K - 1);
   const size_t wb = planes_mode ? 0 : wfrag_bytes(Fin, Fout, K);
   if (!planes_mode && (!workspace || workspace_bytes < wb)) {
@@ -340,7 +397,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     return DSPH_E_WORKSPACE;
   }
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15) ||
-      (reinterpret_cast<uintptr_t>(planes_out) & 15)) {
+      (reinterpret_cast<uintptr_t>(planes_out) & 15) || (wgrad_mode && (reinterpret_cast<uintptr_t>(y) & 15))) {
     set_error("cheb_fused: x, workspace and planes must be 16-byte aligned");
     return DSPH_E_BADARG;
   }
@@ -354,6 +411,10 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
 
   FusedArgs args;
   args.planes_out = planes_out;
+  args.dy = dy;
+  args.slabs = wgrad_mode ? y : nullptr;
+  args.c_begin = 0;
+  args.c_count = C;
   args.prow_stride = plan->n_cols;
   args.plane_stride = N * plan->n_cols * (int64_t)Fin;
   args.x = x;
@@ -382,7 +443,39 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   args.dbg = dbg ? atoi(dbg) : 0;
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wb;
-  const int grid = std::max(8, std::min(plan->fused->num_cu, (ft.ntiles + 7) / 8 * 8));
+  const int grid = fused_grid(plan, ft);
+  if (wgrad_mode) {
+    // as many slices per launch as fit the wave's WG_TILES accumulator tiles; every launch runs the
+    // recurrence for its own slices only, so the split costs nothing but a second read of dy
+    auto launch_one = [&](const FusedArgs& la) -> int {
+#define DSPH_FUSED_CASE(PR, WT) \
+  if (pr == PR && ft.width == WT) return launch_fused_##PR##_##WT(la, NB, precision, grid, lds, stream);
+      DSPH_FUSED_CASE(576, 9)
+      DSPH_FUSED_CASE(768, 9)
+      DSPH_FUSED_CASE(928, 9)
+      DSPH_FUSED_CASE(1024, 9)
+      DSPH_FUSED_CASE(576, 12)
+      DSPH_FUSED_CASE(768, 12)
+      DSPH_FUSED_CASE(928, 12)
+      DSPH_FUSED_CASE(1024, 12)
+#undef DSPH_FUSED_CASE
+      set_error("cheb_fused: no kernel for plane rows %d, width %d", pr, ft.width);
+      return DSPH_E_UNSUPPORTED;
+    };
+    const int per = wgrad_slices_per_launch(plan, K);
+    for (int c0 = 0; c0 < C; c0 += per) {
+      FusedArgs la = args;
+      la.c_begin = c0;
+      la.c_count = std::min(per, C - c0);
+      const int rc = launch_one(la);
+      if (rc != DSPH_OK) return rc;
+    }
+    const int total = Fin * K * Fout;
+    hipLaunchKernelGGL(fused_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, args.slabs, dw,
+                       2 * grid, (int)Fin, (int)Fout, (int)K, C);
+    DSPH_HIP(hipGetLastError());
+    return DSPH_OK;
+  }
 #ifdef DSPH_STAMPS
   static unsigned long long* d_stamps = nullptr;
   constexpr size_t NST = 8 * 8 * 32;

@@ -18,6 +18,8 @@ constexpr int FUSED_BIAS_BYTES = 256;  // the bias (<= 64 floats, zero-padded) s
 constexpr int G_ROWS = FUSED_THREADS / 4;  // recurrence: four lanes share a region row, 128 rows per pass
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int WG_TILE_BYTES = 8 * 1024;  // weight-gradient mode: one 16 x 16 fp32 accumulator tile per wave, in LDS
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct FusedArgs {
@@ -34,6 +36,9 @@ struct FusedArgs {
   float* planes_out;      // planes mode: T_1 .. T_{K-1}, each (N, prow_stride, Fin), written on the tile rows
   int64_t plane_stride;   //   elements per plane
   int64_t prow_stride;    //   rows per map of a plane
+  const float* dy;        // weight-gradient mode: upstream gradient (N, y_rows, Fout)
+  float* slabs;           //   per-(workgroup, pixel half) partial sums [2*grid][nchunks][K][16][64]
+  int c_begin, c_count;   // slices handled by this launch (all modes; forward and planes: 0, nchunks)
   int64_t x_rows, y_rows;
   int N, Fin, Fout, K, ntiles, nchunks, act, wfrag_bytes;
   float alpha_rest, beta_rest;  // step k >= 2: T_k = alpha * L~ T_{k-1} - beta * T_{k-2} (2,1 Chebyshev; 1,0 monomial)
@@ -178,6 +183,36 @@ __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pi
   }
 }
 
+// Weight-gradient mode: dW[f, k, o] += sum_pixels T_k[pixel, f] * dy[pixel, o] for one plane T_k (16 channels)
+// of one tile.  v_mfma_f32_16x16x4_f32 with the pixels as the inner dimension: lane (i = l & 15, kk = l >> 4)
+// supplies A[i][kk] = T_k[pixel(g, kk)][channel i] -- one ds_read_b32 straight from the row-major plane, four
+// consecutive rows per instruction, conflict-free -- and B[kk][j] = dy[pixel(g, kk)][16 nb + j], which the wave
+// keeps in registers for the whole map (32 pixel groups of 4 = its 128-pixel half of the tile).
+// The wave's 16 x 16 accumulator tile of (slice, order) lives in LDS between visits (`tile`: 16 bytes per
+// lane): 40 accumulator registers next to the recurrence's working set spilled.
+__device__ __forceinline__ void wgrad_plane(unsigned char* __restrict__ tile, const unsigned char* __restrict__ smem,
+                                            const unsigned (&la)[4], unsigned plane_off, const float (&dyv)[32]) {
+  // 8 A values in flight while the previous 8 MFMAs run: 16 registers, not 32
+  float av[2][8];
+  f32x4 t = *reinterpret_cast<const f32x4*>(tile);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) av[0][j] = *reinterpret_cast<const float*>(smem + plane_off + la[j & 3] + 256 * j);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < 3) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int g = 8 * (q + 1) + j;
+        av[(q + 1) & 1][j] = *reinterpret_cast<const float*>(smem + plane_off + la[g & 3] + 256 * g);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q & 1][j], dyv[8 * q + j], t, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  *reinterpret_cast<f32x4*>(tile) = t;
+}
+
 // Diagnostic build (make STAMPS=1; never the shipped library): s_memtime at the phase boundaries of a few
 // items of one workgroup, into a buffer nothing else reads.  Read the shares, not the run time.
 #ifdef DSPH_STAMPS
@@ -200,6 +235,9 @@ __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pi
 // MODE 0: the forward.  MODE 1 ("planes"): no contraction at all -- the recurrence alone, with the tile rows of
 // T_1 .. T_{K-1} written to a.planes_out (the weight gradient's left operand, rebuilt in the backward pass
 // at fused speed instead of by K-1 gather launches that go through L2 for every neighbour).
+// MODE 2 ("weight gradient"): the recurrence, and every plane contracted over the tile's pixels against dy
+// (wgrad_batch); the partial sums stay in registers over all tiles of the workgroup and are written once,
+// to a.slabs, for a fixed-order second stage.  No plane ever leaves the LDS.
 template <int PR, int WT, int RP, int NB, int PREC, int MODE = 0>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs a) {
   constexpr int PLANE_BYTES = PR * FUSED_CH * 4;
@@ -215,6 +253,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the epilogue must not touch vector memory for anything but its stores: a bias load there makes
   // the compiler wait for vmcnt(0), i.e. for the x prefetch just issued and the previous y stores
+  if (MODE == 2) {  // rows of a ragged tile that no step writes are multiplied by dy = 0: they must be finite
+    for (int i = tid * 16; i < 2 * PLANE_BYTES; i += FUSED_THREADS * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
+  }
   if (MODE == 0 && tid < FUSED_BIAS_BYTES / 4) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
   if (MODE == 0) {
     for (int i = tid * 16; i < a.wfrag_bytes; i += FUSED_THREADS * 16)
@@ -229,7 +270,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   const int D = a.K - 1;
   const int row_l = tid >> 2;      // recurrence: this lane's row within a pass
   const unsigned qslot = tid & 3;  //             and its 16-byte slot
-  const int items = a.N * a.nchunks;  // (map, slice) pairs per tile
+  const int items = a.N * a.c_count;  // (map, slice) pairs per tile
   const size_t wstride = (size_t)a.nchunks * NB * 2048;  // weight blocks: per order
   const bool do_g = !(a.dbg & 1), do_m = !(a.dbg & 2);
   const bool cheb = a.beta_rest != 0.f;  // Chebyshev (2, 1) or monomial (1, 0) steps from k = 2 on
@@ -253,7 +294,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   };
   // Slice `item`'s loads, one float4 per lane and slot s: all of them (slot < 0) or those of one phase.
   auto issue_loads = [&](int item, int slot) {
-    const int n = item / a.nchunks, c = item - n * a.nchunks;
+    const int n = item / a.c_count, c = a.c_begin + item - n * a.c_count;
     const int ch0 = c * FUSED_CH + 4 * (tid & 3);
     const int ch = ch0 < a.Fin ? ch0 : a.Fin - 4;
     const float* __restrict__ xb = a.x + (int64_t)n * a.x_rows * a.Fin + ch;
@@ -329,6 +370,18 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     }
   };
 
+  // ---- weight-gradient mode: this wave's share is output columns 16 nb .. +16 and pixel half hp ----
+  float dyv[32];
+  unsigned la[4];
+  const int wg_nb = wave & 3, wg_hp = wave >> 2, wg_i = lane & 15, wg_kk = lane >> 4;
+  unsigned char* const sAcc = smem + 2 * PLANE_BYTES + tid * 16;  // tile i of this lane: + i * WG_TILE_BYTES
+  if (MODE == 2) {
+    for (int i = 0; i < a.c_count * a.K; ++i) *reinterpret_cast<f32x4*>(sAcc + i * WG_TILE_BYTES) = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)  // the swizzle term of row 128 hp + 4 g + kk is g & 3
+      la[j] = (unsigned)(wg_hp * 128 + wg_kk) * (FUSED_CH * 4) + 16u * ((unsigned)(wg_i >> 2) ^ (unsigned)j) + 4u * (wg_i & 3);
+  }
+
   int t = t_begin + slot0;
   if (t < t_end) {
     load_rids(t);
@@ -374,7 +427,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     }
 
     for (int item = 0; item < items; ++item) {
-      const int n = item / a.nchunks, c = item - n * a.nchunks;
+      const int n = item / a.c_count, c = a.c_begin + item - n * a.c_count;
 #ifdef DSPH_STAMPS
       const bool stamp_on = blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
 #endif
@@ -461,6 +514,47 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
           DSPH_STAMP(16 + (k - 2) * 3);
         }
       }
+      } else if (MODE == 2) {
+        const int cl = c - a.c_begin;
+        if (cl == 0) {  // a new map: this wave's dy fragments (branch-free loads, zero past the tile / Fout)
+          const int o = 16 * wg_nb + wg_i;
+          const int oc = o < a.Fout ? o : 0;
+          const float* __restrict__ dyb = a.dy + ((int64_t)n * a.y_rows + row0) * a.Fout + oc;
+          // all 32 loads first, the masking after them (a select right behind each load makes it 32 round trips)
+#pragma unroll
+          for (int g = 0; g < 32; ++g) {
+            const int row = wg_hp * 128 + 4 * g + wg_kk;
+            dyv[g] = dyb[(int64_t)(row < P_t ? row : 0) * a.Fout];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (P_t < FUSED_P || o >= a.Fout) {
+#pragma unroll
+            for (int g = 0; g < 32; ++g) {
+              const int row = wg_hp * 128 + 4 * g + wg_kk;
+              dyv[g] = (row < P_t && o < a.Fout) ? dyv[g] : 0.f;
+            }
+          }
+        }
+        __syncthreads();
+        wgrad_plane(sAcc + (cl * a.K) * WG_TILE_BYTES, smem, la, 0u, dyv);
+        issue_loads(nitem, 1);
+        gather_step<WT, RP, false>(planeX, planeY, re(D - 1), row_l, val, pre, own);
+        __syncthreads();
+        wgrad_plane(sAcc + (cl * a.K + 1) * WG_TILE_BYTES, smem, la, (unsigned)PLANE_BYTES, dyv);
+        for (int k = 2; k < a.K; k += 2) {
+          issue_loads(nitem, k);
+          if (cheb) gather_step<WT, RP, true>(planeY, planeX, re(D - k), row_l, val, pre, own);
+          else gather_step<WT, RP, false>(planeY, planeX, re(D - k), row_l, val, pre, own);
+          __syncthreads();
+          wgrad_plane(sAcc + (cl * a.K + k) * WG_TILE_BYTES, smem, la, 0u, dyv);
+          if (k + 1 < a.K) {
+            issue_loads(nitem, k + 1);
+            if (cheb) gather_step<WT, RP, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
+            else gather_step<WT, RP, false>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
+            __syncthreads();
+            wgrad_plane(sAcc + (cl * a.K + k + 1) * WG_TILE_BYTES, smem, la, (unsigned)PLANE_BYTES, dyv);
+          }
+        }
       } else {
         // ---- planes mode: the recurrence alone; every new plane's tile rows also go to planes_out ----
         const int64_t spass = (int64_t)G_ROWS * a.Fin;
@@ -499,6 +593,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       }
     }
   }
+  if (MODE == 2) {  // D[i = 4 (l >> 4) + r][j = l & 15] of tile (slice cl, order k): channel 16 c + i, column 16 nb + j
+    float* __restrict__ sl = a.slabs + (size_t)(blockIdx.x * 2 + wg_hp) * ((size_t)a.nchunks * a.K * 16 * 64);
+    for (int i = 0; i < a.c_count * a.K; ++i) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sAcc + i * WG_TILE_BYTES);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sl[((size_t)(a.c_begin * a.K + i) * 16 + 4 * wg_kk + r) * 64 + 16 * wg_nb + wg_i] = v[r];
+    }
+  }
   if (MODE == 0 && pend && !(a.dbg & 8)) {  // the last map of this workgroup
     __syncthreads();
     store_pending();
@@ -517,6 +620,12 @@ static int launch_variant(const FusedArgs& args, int grid, size_t lds, hipStream
 template <int PR, int WT, int RPL>
 static int dispatch_nb_prec(const FusedArgs& args, int nb, int prec, int grid, size_t lds,
                             hipStream_t stream) {
+  if (args.slabs != nullptr) {  // weight-gradient mode
+    auto kern = cheb_fused_kernel<PR, WT, RPL, 1, DSPH_PREC_FP32, 2>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), 0, stream, args);
+    DSPH_HIP(hipGetLastError());
+    return DSPH_OK;
+  }
   if (args.planes_out != nullptr) {  // planes mode: no contraction, nb and prec do not apply
     auto kern = cheb_fused_kernel<PR, WT, RPL, 1, DSPH_PREC_FP32, 1>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), 0, stream, args);

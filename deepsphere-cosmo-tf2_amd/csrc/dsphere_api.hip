@@ -290,6 +290,66 @@ int dsph_cheb_planes(const dsph_plan* p, const float* x, float* planes, int64_t 
   return DSPH_OK;
 }
 
+static size_t planes_bytes(const dsph_plan* p, int64_t N, int32_t Fin, int32_t K) {
+  return align_up((size_t)(K - 1) * (size_t)N * (size_t)p->n_cols * (size_t)Fin * sizeof(float), 256);
+}
+
+size_t dsph_backward_weights_workspace_bytes(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
+                                             int32_t algo) {
+  if (!p || N <= 0 || Fin <= 0 || Fout <= 0 || K <= 0) return 0;
+  if (algo != DSPH_ALGO_UNFUSED && fused_wgrad_supported(p, Fin, Fout, K)) return fused_wgrad_workspace_bytes(p, Fin, Fout, K);
+  if (algo == DSPH_ALGO_FUSED) return 0;
+  return planes_bytes(p, N, Fin, K) + wgrad_workspace_bytes(N, out_rows(p), Fin, Fout, K);
+}
+
+int dsph_cheb_backward_weights(const dsph_plan* p, const float* x, const float* dy, float* dw, int64_t N,
+                               int32_t Fin, int32_t Fout, int32_t K, int32_t basis, int32_t algo,
+                               void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (basis != DSPH_BASIS_CHEBYSHEV && basis != DSPH_BASIS_MONOMIAL) {
+    set_error("backward_weights: unknown basis %d", basis);
+    return DSPH_E_BADARG;
+  }
+  if (!p || !x || !dy || !dw || N <= 0 || Fin <= 0 || Fout <= 0 || K <= 0) {
+    set_error("backward_weights: bad arguments (NULL pointer or non-positive size)");
+    return DSPH_E_BADARG;
+  }
+  if (!p->levels.empty() && (int)p->levels.size() < K - 1) {
+    set_error("backward_weights: plan has %d levels, K = %d needs %d", (int)p->levels.size(), K, K - 1);
+    return DSPH_E_BADARG;
+  }
+  const float alpha_rest = basis == DSPH_BASIS_CHEBYSHEV ? 2.f : 1.f;
+  const float beta_rest = basis == DSPH_BASIS_CHEBYSHEV ? 1.f : 0.f;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const bool can_fuse = fused_wgrad_supported(p, Fin, Fout, K);
+  if (algo == DSPH_ALGO_FUSED && !can_fuse) {
+    set_error("backward_weights: fused kernel cannot run this plan/shape (Fin=%d Fout=%d K=%d)", Fin, Fout, K);
+    return DSPH_E_UNSUPPORTED;
+  }
+  const size_t need = dsph_backward_weights_workspace_bytes(p, N, Fin, Fout, K, algo);
+  if (need > 0 && (!workspace || workspace_bytes < need)) {
+    set_error("backward_weights: workspace %zu bytes, need %zu", workspace_bytes, need);
+    return DSPH_E_WORKSPACE;
+  }
+  if (can_fuse && algo != DSPH_ALGO_UNFUSED) {
+    DeviceGuard guard(p->device);
+    return launch_cheb_fused_wgrad(p, x, dy, dw, N, Fin, Fout, K, alpha_rest, beta_rest, workspace, workspace_bytes,
+                                   stream);
+  }
+  // any L, any shape: K-1 gather launches into workspace planes, then the split-over-pixels MFMA kernel
+  if (K > 64) { set_error("backward_weights: K = %d exceeds 64", K); return DSPH_E_UNSUPPORTED; }
+  float* planes = static_cast<float*>(workspace);
+  int rc = dsph_cheb_planes(p, x, planes, N, Fin, K, basis, DSPH_ALGO_UNFUSED, hip_stream);
+  if (rc != DSPH_OK) return rc;
+  const size_t plane = (size_t)N * (size_t)p->n_cols * (size_t)Fin;
+  const float* pl[64];
+  pl[0] = x;
+  for (int k = 1; k < K; ++k) pl[k] = planes + plane * (size_t)(k - 1);
+  DeviceGuard guard(p->device);
+  const size_t pb = planes_bytes(p, N, Fin, K);
+  return launch_cheb_wgrad(pl, p->n_cols, dy, dw, N, out_rows(p), Fin, Fout, K, static_cast<char*>(workspace) + pb,
+                           workspace_bytes - pb, stream);
+}
+
 size_t dsph_wgrad_workspace_bytes(int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K) {
   if (N <= 0 || rows <= 0 || Fin <= 0 || Fout <= 0 || K <= 0) return 0;
   return wgrad_workspace_bytes(N, rows, Fin, Fout, K);

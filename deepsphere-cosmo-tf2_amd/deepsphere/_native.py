@@ -60,6 +60,11 @@ SIGNATURES = {
         ctypes.c_int,
         [_c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp],
     ),
+    "dsph_backward_weights_workspace_bytes": (ctypes.c_size_t, [_c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32]),
+    "dsph_cheb_backward_weights": (
+        ctypes.c_int,
+        [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp, ctypes.c_size_t, _c_vp],
+    ),
     "dsph_cheb_wgrad": (
         ctypes.c_int,
         [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_vp, ctypes.c_size_t, ctypes.c_int,
@@ -280,6 +285,28 @@ def cheb_planes(plan, x, K, basis=BASIS_CHEBYSHEV, algo=ALGO_AUTO):
                                 _stream_ptr(x.device))
     check(rc, "dsph_cheb_planes")
     return [x] + [out[k] for k in range(K - 1)]
+
+
+def cheb_backward_weights(plan, x, dy, K, basis=BASIS_CHEBYSHEV, algo=ALGO_AUTO, workspace=None):
+    """dkernel[f*K + k, o] = sum_{n,m} (T_k x)[n,m,f] dy[n,m,o] (``dsph_cheb_backward_weights``).
+    Returns (dkernel, workspace)."""
+    import torch
+
+    _check_dev(x, plan, "x")
+    _check_dev(dy, plan, "dy")
+    N, M, Fin = x.shape
+    if M != plan.n_cols or dy.dim() != 3 or dy.shape[0] != N or dy.shape[1] != plan.out_rows:
+        raise ValueError(f"x must be (N, {plan.n_cols}, Fin) and dy (N, {plan.out_rows}, Fout)")
+    Fout = int(dy.shape[2])
+    need = int(lib().dsph_backward_weights_workspace_bytes(plan.handle, int(N), int(Fin), Fout, int(K), int(algo)))
+    if workspace is None or workspace.numel() * workspace.element_size() < need or workspace.device != x.device:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    dw = torch.empty((Fin * K, Fout), dtype=torch.float32, device=x.device)
+    rc = lib().dsph_cheb_backward_weights(plan.handle, _ptr(x), _ptr(dy), _ptr(dw), int(N), int(Fin), Fout, int(K),
+                                          int(basis), int(algo), _ptr(workspace),
+                                          workspace.numel() * workspace.element_size(), _stream_ptr(x.device))
+    check(rc, "dsph_cheb_backward_weights")
+    return dw, workspace
 
 
 def cheb_wgrad(planes, dy, rows=None, workspace=None):

@@ -67,9 +67,10 @@ class _ChebConvFunction(torch.autograd.Function):
     * dx = sum_k T_k(L~)^T (dy W_k^T) is the *forward* of the layer on dy with the plan of L~^T (the
       same plan when L~ is symmetric, as every graph Laplacian is) and the weights re-indexed as
       kernel_T[o*K + k, f] = kernel[f*K + k, o];
-    * dkernel[f*K + k, o] = sum_{n,m} (T_k x)[n,m,f] dy[n,m,o]: the planes are rebuilt by
-      ``dsph_cheb_planes`` (the fused tile kernel without its contraction; K-1 ``dsph_cheb_step``
-      launches where that kernel does not apply) and reduced against dy by ``dsph_cheb_wgrad`` (a split-over-pixels MFMA
+    * dkernel[f*K + k, o] = sum_{n,m} (T_k x)[n,m,f] dy[n,m,o] by ``dsph_cheb_backward_weights``: the fused
+      tile kernel in weight-gradient mode (the planes never leave the LDS; each tile's T_k is contracted
+      over its pixels against dy by exact-fp32 MFMAs), or, where that kernel does not apply, the planes
+      rebuilt by ``dsph_cheb_planes`` and reduced against dy by ``dsph_cheb_wgrad`` (a split-over-pixels MFMA
       kernel with a fixed-order second stage: a library GEMM has no split-K for a 64 x 64 result
       reduced over 5e7 rows and took 150 ms here).
     """
@@ -102,8 +103,8 @@ class _ChebConvFunction(torch.autograd.Function):
                 algo=_ALGOS[layer.algo], workspace=layer._workspace_t, basis=layer._basis)
         if ctx.needs_input_grad[1]:
             plan = layer._get_plan()
-            planes = _native.cheb_planes(plan, x, K, basis=layer._basis, algo=_ALGOS[layer.algo])
-            dk, layer._workspace_w = _native.cheb_wgrad(planes, dy, workspace=getattr(layer, "_workspace_w", None))
+            dk, layer._workspace_w = _native.cheb_backward_weights(
+                plan, x, dy, K, basis=layer._basis, algo=_ALGOS[layer.algo], workspace=getattr(layer, "_workspace_w", None))
         return dx, dk, None
 
 

@@ -563,3 +563,47 @@ def test_planes_kernel(graph, nside, N, Fin, K, basis):
     for k in range(K):
         assert rel_err(fused[k].cpu().numpy(), ref[k]) < TOL_FP32, f"plane {k}"
         assert torch.equal(fused[k], unfused[k]), f"plane {k}: fused and per-step kernels differ"
+
+
+@pytest.mark.parametrize("basis", ["chebyshev", "monomial"])
+@pytest.mark.parametrize("graph,nside,N,Fin,Fout,K", [("grid", 16, 2, 64, 64, 5), ("grid", 16, 3, 40, 24, 3),
+                                                       ("knn", 16, 2, 16, 7, 4), ("cap", 16, 2, 32, 64, 5),
+                                                       ("grid", 32, 1, 8, 33, 6)])
+def test_backward_weights(graph, nside, N, Fin, Fout, K, basis):
+    """dsph_cheb_backward_weights: the fused tile kernel in weight-gradient mode against the float64 oracle
+    (dW[f*K+k, o] = sum_{n,m} T_k(x)[n,m,f] dy[n,m,o]) and against the planes + wgrad route."""
+    if graph == "cap":
+        idx = healpix.extend_indices(healpix.cap_indices(nside, fraction=0.3), nside, 4)[:-37]
+        L = healpix.healpix_laplacian(nside, indices=idx, mode="grid")
+    else:
+        L = healpix.healpix_laplacian(nside, mode=graph)
+    Lt, _ = orc.prepare_L(L, scale=0.75 if basis == "chebyshev" else 1.0)
+    plan = _plan(Lt)
+    bcode = _native.BASIS_CHEBYSHEV if basis == "chebyshev" else _native.BASIS_MONOMIAL
+    rng = np.random.default_rng(nside + Fin + K + Fout)
+    x = rng.standard_normal((N, Lt.shape[0], Fin)).astype(np.float32)
+    dy = rng.standard_normal((N, Lt.shape[0], Fout)).astype(np.float32)
+    planes = orc.chebyshev_planes(Lt, x, K) if basis == "chebyshev" else orc.monomial_planes(Lt, x, K)
+    ref = np.einsum("knmf,nmo->fko", planes, dy.astype(np.float64)).reshape(Fin * K, Fout)
+    fused, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, basis=bcode, algo=_native.ALGO_FUSED)
+    unfused, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, basis=bcode, algo=_native.ALGO_UNFUSED)
+    assert rel_err(fused.cpu().numpy(), ref) < TOL_FP32
+    assert rel_err(unfused.cpu().numpy(), ref) < TOL_FP32
+    again, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, basis=bcode, algo=_native.ALGO_FUSED)
+    assert torch.equal(fused, again)  # fixed-order reduction of the per-workgroup partial sums
+
+
+def test_backward_weights_falls_back_when_the_accumulators_do_not_fit():
+    """K = 8 needs 7-ring planes (928 rows): no LDS is left for the accumulator tiles, so FUSED is refused
+    loudly and AUTO takes the planes + wgrad route."""
+    nside, N, Fin, Fout, K = 32, 1, 8, 33, 8
+    Lt, _ = orc.prepare_L(healpix.healpix_laplacian(nside, mode="grid"))
+    plan = _plan(Lt)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((N, Lt.shape[0], Fin)).astype(np.float32)
+    dy = rng.standard_normal((N, Lt.shape[0], Fout)).astype(np.float32)
+    with pytest.raises(RuntimeError, match="fused kernel cannot run"):
+        _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, algo=_native.ALGO_FUSED)
+    ref = np.einsum("knmf,nmo->fko", orc.chebyshev_planes(Lt, x, K), dy.astype(np.float64)).reshape(Fin * K, Fout)
+    dw, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K)
+    assert rel_err(dw.cpu().numpy(), ref) < TOL_FP32
