@@ -261,17 +261,17 @@ static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
   if (!plan->fused) return false;
   if (K < 2 || K - 1 > FUSED_DMAX) return false;
-  if (Fin % 4 != 0 || Fin < 8 || Fout > 64 || Fout < 1) return false;
+  if (Fin % 4 != 0 || Fin < 8 || Fout < 1) return false;  // Fout > 64: one launch per 64-column block
   const FusedTiles& ft = get_tiles(plan, K - 1);
   if (!ft.ok) return false;
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   if (pr == 0) return false;
-  const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wfrag_bytes(Fin, Fout, K) + FUSED_BIAS_BYTES;
+  const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wfrag_bytes(Fin, std::min(Fout, 64), K) + FUSED_BIAS_BYTES;
   return lds <= (size_t)LDS_BYTES;
 }
 
 size_t fused_workspace_bytes(const dsph_plan*, int64_t, int32_t Fin, int32_t Fout, int32_t K, int32_t) {
-  return wfrag_bytes(Fin, Fout, K);
+  return wfrag_bytes(Fin, std::min(Fout, 64), K);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -283,13 +283,13 @@ size_t fused_workspace_bytes(const dsph_plan*, int64_t, int32_t Fin, int32_t Fou
 //   fp32  : step t, lane l     <- w[(c*16 + 8*(l>>5) + t)*K + k][32*nb + (l&31)] at t*256 + l*4
 __global__ __launch_bounds__(256) void fused_wprep_kernel(const float* __restrict__ w,
                                                           unsigned char* __restrict__ out, int Fin,
-                                                          int Fout, int K, int C, int NB, int prec) {
+                                                          int Fout, int K, int C, int NB, int prec, int ld) {
   const int blk = blockIdx.x;  // (k*C + c)*NB + nb
   const int nb = blk % NB, c = (blk / NB) % C, k = blk / (NB * C);
   for (int e = threadIdx.x; e < 512; e += 256) {
     const int l = e >> 3, j = e & 7;
     const int ch = c * FUSED_CH + 8 * (l >> 5) + j, col = 32 * nb + (l & 31);
-    const float v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * Fout + col] : 0.f;
+    const float v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
     unsigned char* base = out + (size_t)blk * 2048;
     if (prec == DSPH_PREC_BF16X3) {
       const __bf16 hi = (__bf16)v;
@@ -306,14 +306,21 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream,
-                               const float* dy = nullptr, float* dw = nullptr);
+                               const float* dy = nullptr, float* dw = nullptr, int32_t ld = 0);
 
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,
                       size_t workspace_bytes, hipStream_t stream) {
-  return launch_fused_common(plan, x, w, bias, y, nullptr, N, Fin, Fout, K, act, precision, alpha_rest,
-                             beta_rest, workspace, workspace_bytes, stream);
+  // more than 64 output columns: one launch per 64-column block (the recurrence is repeated; still one pass
+  // over x per block instead of the unfused path's K planes through HBM)
+  for (int32_t cb = 0; cb < Fout; cb += 64) {
+    const int rc = launch_fused_common(plan, x, w + cb, bias ? bias + cb : nullptr, y + cb, nullptr, N, Fin,
+                                       std::min<int32_t>(64, Fout - cb), K, act, precision, alpha_rest, beta_rest,
+                                       workspace, workspace_bytes, stream, nullptr, nullptr, Fout);
+    if (rc != DSPH_OK) return rc;
+  }
+  return DSPH_OK;
 }
 
 // Planes mode of the same kernel: T_1 .. T_{K-1} of x, each (N, n_cols, Fin), valid on the plan's output rows.
@@ -352,7 +359,7 @@ size_t fused_wgrad_workspace_bytes(const dsph_plan* plan, int32_t Fin, int32_t F
 
 // dw[(f*K + k)*Fout + o] = sum over slabs, in slab order (deterministic)
 __global__ __launch_bounds__(256) void fused_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                                 int nslabs, int Fin, int Fout, int K, int C) {
+                                                                 int nslabs, int Fin, int Fout, int K, int C, int ld) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= Fin * K * Fout) return;
   const int o = e % Fout, fk = e / Fout, k = fk % K, f = fk / K;
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(256) void fused_wgrad_reduce_kernel(const float* __
   const size_t off = ((size_t)((f >> 4) * K + k) * 16 + (f & 15)) * 64 + o;
   float s = 0.f;
   for (int i = 0; i < nslabs; ++i) s += slabs[(size_t)i * slab + off];
-  dw[e] = s;
+  dw[(size_t)fk * ld + o] = s;
 }
 
 int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* dy, float* dw, int64_t N,
@@ -375,15 +382,21 @@ int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* 
     set_error("cheb_fused_wgrad: workspace %zu < %zu", workspace_bytes, need);
     return DSPH_E_WORKSPACE;
   }
-  return launch_fused_common(plan, x, nullptr, nullptr, static_cast<float*>(workspace), nullptr, N, Fin, Fout, K,
-                             DSPH_ACT_NONE, DSPH_PREC_FP32, alpha_rest, beta_rest, nullptr, 0, stream, dy, dw);
+  for (int32_t cb = 0; cb < Fout; cb += 64) {
+    const int rc = launch_fused_common(plan, x, nullptr, nullptr, static_cast<float*>(workspace), nullptr, N, Fin,
+                                       std::min<int32_t>(64, Fout - cb), K, DSPH_ACT_NONE, DSPH_PREC_FP32, alpha_rest,
+                                       beta_rest, nullptr, 0, stream, dy + cb, dw + cb, Fout);
+    if (rc != DSPH_OK) return rc;
+  }
+  return DSPH_OK;
 }
 
 static int launch_fused_common(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream, const float* dy,
-                               float* dw) {
+                               float* dw, int32_t ld) {
+  if (ld <= 0) ld = Fout;  // row stride of w, bias-less y / dy / dw: the layer's Fout when this is one column block
   if (!fused_supported(plan, Fin, Fout, K)) {
     set_error("cheb_fused: plan/shape not supported");
     return DSPH_E_UNSUPPORTED;
@@ -405,7 +418,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   if (!planes_mode) {
     hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,
                        static_cast<unsigned char*>(workspace), (int)Fin, (int)Fout, (int)K, C, NB,
-                       (int)precision);
+                       (int)precision, (int)ld);
     DSPH_HIP(hipGetLastError());
   }
 
@@ -432,6 +445,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   args.N = (int)N;
   args.Fin = Fin;
   args.Fout = Fout;
+  args.ld = ld;
   args.K = K;
   args.ntiles = ft.ntiles;
   args.nchunks = C;
@@ -472,7 +486,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     }
     const int total = Fin * K * Fout;
     hipLaunchKernelGGL(fused_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, args.slabs, dw,
-                       2 * grid, (int)Fin, (int)Fout, (int)K, C);
+                       2 * grid, (int)Fin, (int)Fout, (int)K, C, (int)ld);
     DSPH_HIP(hipGetLastError());
     return DSPH_OK;
   }

@@ -41,6 +41,7 @@ struct FusedArgs {
   int c_begin, c_count;   // slices handled by this launch (all modes; forward and planes: 0, nchunks)
   int64_t x_rows, y_rows;
   int N, Fin, Fout, K, ntiles, nchunks, act, wfrag_bytes;
+  int ld;  // row stride (floats) of y, dy: Fout of the whole layer when this launch handles one 64-column block of it
   float alpha_rest, beta_rest;  // step k >= 2: T_k = alpha * L~ T_{k-1} - beta * T_{k-2} (2,1 Chebyshev; 1,0 monomial)
 #ifdef DSPH_STAMPS
   unsigned long long* stamps;  // diagnostic build only: [8 waves][8 items][32 points] s_memtime values
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       lds_wave_sync();
       const int cq = 32 * b + cq0;
       const float4 bv = *reinterpret_cast<const float4*>(sBias + cq);
-      float* __restrict__ yp0 = a.y + ((int64_t)pend_n * a.y_rows + pend_row0 + wave * 32 + rsub) * a.Fout + cq;
+      float* __restrict__ yp0 = a.y + ((int64_t)pend_n * a.y_rows + pend_row0 + wave * 32 + rsub) * a.ld + cq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = i * 8 + rsub;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
         v.y = apply_act(v.y + bv.y, act);
         v.z = apply_act(v.z + bv.z, act);
         v.w = apply_act(v.w + bv.w, act);
-        float* __restrict__ yp = yp0 + (int64_t)(i * 8) * a.Fout;
+        float* __restrict__ yp = yp0 + (int64_t)(i * 8) * a.ld;
         if (wave * 32 + row < pend_Pt) {
           if (VEC) {
             if (cq < a.Fout) *reinterpret_cast<float4*>(yp) = v;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   };
   // One uniform switch per map instead of one per element: with the activation switch inlined 128 times
   // the epilogue was 5 k instructions of branches and took 7 k cycles per map (mostly instruction fetch).
-  const bool vec_ok = (a.Fout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+  const bool vec_ok = (a.Fout % 4 == 0) && (a.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
   auto store_pending = [&]() {
     using std::integral_constant;
     if (!vec_ok) return store_impl(integral_constant<int, -1>{}, integral_constant<bool, false>{});
@@ -519,12 +520,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
         if (cl == 0) {  // a new map: this wave's dy fragments (branch-free loads, zero past the tile / Fout)
           const int o = 16 * wg_nb + wg_i;
           const int oc = o < a.Fout ? o : 0;
-          const float* __restrict__ dyb = a.dy + ((int64_t)n * a.y_rows + row0) * a.Fout + oc;
+          const float* __restrict__ dyb = a.dy + ((int64_t)n * a.y_rows + row0) * a.ld + oc;
           // all 32 loads first, the masking after them (a select right behind each load makes it 32 round trips)
 #pragma unroll
           for (int g = 0; g < 32; ++g) {
             const int row = wg_hp * 128 + 4 * g + wg_kk;
-            dyv[g] = dyb[(int64_t)(row < P_t ? row : 0) * a.Fout];
+            dyv[g] = dyb[(int64_t)(row < P_t ? row : 0) * a.ld];
           }
           __builtin_amdgcn_sched_barrier(0);
           if (P_t < FUSED_P || o >= a.Fout) {

@@ -102,6 +102,7 @@ def test_odd_shapes(Fin, Fout, K, N):
     ("grid", 16, 3, 8, 5, 2),     # smallest slice, Fout not a multiple of 32
     ("grid", 16, 1, 40, 64, 3),   # Fin not a multiple of the 16-channel slice
     ("cap", 16, 2, 32, 64, 5),    # partial sky: ragged last tile, border rows with few neighbours
+    ("grid", 16, 2, 16, 130, 3),  # more than 64 output columns: one launch per 64-column block (64 + 64 + 2)
 ])
 def test_fused_kernel(graph, nside, N, Fin, Fout, K, prec, tol):
     if graph == "cap":
@@ -568,7 +569,7 @@ def test_planes_kernel(graph, nside, N, Fin, K, basis):
 @pytest.mark.parametrize("basis", ["chebyshev", "monomial"])
 @pytest.mark.parametrize("graph,nside,N,Fin,Fout,K", [("grid", 16, 2, 64, 64, 5), ("grid", 16, 3, 40, 24, 3),
                                                        ("knn", 16, 2, 16, 7, 4), ("cap", 16, 2, 32, 64, 5),
-                                                       ("grid", 32, 1, 8, 33, 6)])
+                                                       ("grid", 32, 1, 8, 33, 6), ("grid", 16, 1, 16, 100, 3)])
 def test_backward_weights(graph, nside, N, Fin, Fout, K, basis):
     """dsph_cheb_backward_weights: the fused tile kernel in weight-gradient mode against the float64 oracle
     (dW[f*K+k, o] = sum_{n,m} T_k(x)[n,m,f] dy[n,m,o]) and against the planes + wgrad route."""
