@@ -150,7 +150,10 @@ def main():
         shard = sharding.ShardedChebyshev(cols, vals, K, Fout=Fout, rank=rank, world=world, device=device,
                                           precision=args.precision, algo=args.algo, kernel=w_np)
         gen = torch.Generator(device=device).manual_seed(11 + rank)
-        x = torch.randn((N, shard.own_rows, Fin), device=device, generator=gen)
+        # this rank's rows live in the extended buffer the kernel reads (own rows, then halo rows): a producer
+        # layer would write them there; no per-step copy
+        x = shard.own_rows_view(N, Fin)
+        x.normal_(generator=gen)
         run = lambda: shard(x)  # noqa: E731
         fused = shard.plan.fused_ok(Fin, Fout, K) and args.algo != "unfused"
         kernel_name = ("cheb_fused_kernel" if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \

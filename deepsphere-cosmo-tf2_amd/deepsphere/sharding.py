@@ -161,6 +161,15 @@ class ShardedChebyshev:
         self._x_ext = None
         self._workspace = None
 
+    def own_rows_view(self, N, F):
+        """The (N, own, F) window of the extended input buffer that holds this rank's rows.  A producer that
+        writes its output straight into this view (and then passes the view to ``__call__``) saves the copy of
+        the rank's rows into the buffer -- 2 x |x_local| of HBM traffic per forward."""
+        lay = self.layout
+        if self._x_ext is None or tuple(self._x_ext.shape) != (N, lay.n_cols, F):
+            self._x_ext = torch.empty((N, lay.n_cols, F), dtype=torch.float32, device=self.device)
+        return self._x_ext[:, : lay.n_own]
+
     def exchange(self, x_local):
         """(N, own, F) -> (N, n_cols, F): own rows followed by the halo rows fetched from their owners."""
         import torch.distributed as dist
@@ -169,10 +178,13 @@ class ShardedChebyshev:
         N, own, F = x_local.shape
         if own != lay.n_own:
             raise ValueError(f"this rank owns {lay.n_own} rows, got {own}")
+        in_place = (self._x_ext is not None and tuple(self._x_ext.shape) == (N, lay.n_cols, F)
+                    and x_local.data_ptr() == self._x_ext.data_ptr() and x_local.stride() == self._x_ext.stride())
         if self._x_ext is None or tuple(self._x_ext.shape) != (N, lay.n_cols, F):
             self._x_ext = torch.empty((N, lay.n_cols, F), dtype=torch.float32, device=x_local.device)
         x_ext = self._x_ext
-        x_ext[:, :own].copy_(x_local)
+        if not in_place:
+            x_ext[:, :own].copy_(x_local)
         if self.world == 1 or not (self._send_idx or self._recv_idx):
             return x_ext
         # RCCL moves device buffers directly (xGMI peer-to-peer).  Under a gloo group (no RCCL: several

@@ -88,7 +88,12 @@ def _worker(rank, world, port, K, partial, out):
         W = rng.standard_normal((Fin * K, Fout)).astype(np.float32)
         sh = sharding.ShardedChebyshev(cols, vals, K, rank=rank, world=world, kernel=W, _compute=_oracle_compute)
         a, b = sh.layout.own
-        y_local = sh(torch.from_numpy(x[:, a:b].copy()))
+        if partial:  # second form of the input: written straight into the extended buffer (no copy of own rows)
+            view = sh.own_rows_view(N, Fin)
+            view.copy_(torch.from_numpy(x[:, a:b].copy()))
+            y_local = sh(view)
+        else:
+            y_local = sh(torch.from_numpy(x[:, a:b].copy()))
         ref = orc.chebyshev_forward(Lt, x, W, K)[:, a:b]
         err = float(np.abs(y_local.numpy() - ref).max() / np.abs(ref).max())
         # the halo rows really came over the wire: compare the extended input with the global one
