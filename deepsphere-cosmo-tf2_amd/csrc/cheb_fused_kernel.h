@@ -149,10 +149,11 @@ __device__ __forceinline__ float quad_bcast(float v, int lane_in_quad) {
 // the four lanes of a quad share the row).
 // SAVE: also write the new plane's tile rows (the first two passes: rows < save_rows <= 256) to global
 // memory at `save` (this lane's row_l and channel slot already added; 128 rows = save_pass floats apart).
-template <int WT, int RP, bool CHEB_STEP, bool SAVE = false>
+// VW: value registers per row -- WT (one per neighbour) or ceil(WT / 4) (quad-packed, fetched by DPP broadcast).
+template <int WT, int RP, bool CHEB_STEP, bool SAVE = false, int VW = WT>
 __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pin,
                                             unsigned char* __restrict__ pout, int nrows, int row_l,
-                                            const float (&valc)[RP][(WT + 3) / 4], const unsigned (&pre)[RP][WT],
+                                            const float (&valc)[RP][VW], const unsigned (&pre)[RP][WT],
                                             const unsigned (&own)[RP], float* __restrict__ save = nullptr,
                                             int64_t save_pass = 0, int save_rows = 0) {
 #pragma unroll
@@ -162,7 +163,7 @@ __device__ __forceinline__ void gather_step(const unsigned char* __restrict__ pi
 #pragma unroll
       for (int j = 0; j < WT; ++j) {
         const float4 v = *reinterpret_cast<const float4*>(pin + pre[p][j]);
-        const float w = quad_bcast(valc[p][j >> 2], j & 3);
+        const float w = VW == WT ? valc[p][VW == WT ? j : 0] : quad_bcast(valc[p][VW == WT ? 0 : j >> 2], j & 3);
         s.x = fmaf(w, v.x, s.x);
         s.y = fmaf(w, v.y, s.y);
         s.z = fmaf(w, v.z, s.z);
@@ -409,15 +410,20 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     const int64_t row0 = (int64_t)t * FUSED_P;
 
     // this lane's recurrence rows: ELL values and swizzled LDS byte addresses stay in registers
-    float val[RP][(WT + 3) / 4];  // quad-packed: register g of lane q holds the row's value 4g + q
+    // One value register per neighbour (9 per row) where the registers allow it: the quad-packed form (3 per
+    // row, register g of lane q holds value 4g + q) costs one DPP move per neighbour, 15 % of the kernel's VALU
+    // instructions (17.9 vs 18.3 ms same-box).  The weight-gradient mode keeps it (its dy fragments need the room),
+    // and so do the variants with more passes or wider rows.
+    constexpr int VW = (MODE == 2 || RP * WT > 36) ? (WT + 3) / 4 : WT;  // unpacked only for the 9-wide, 4-pass variant
+    float val[RP][VW];
     unsigned pre[RP][WT], own[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
       const int i = row_l + p * G_ROWS;
       own[p] = plane_byte((unsigned)(i < PR ? i : 0), qslot);
 #pragma unroll
-      for (int g = 0; g < (WT + 3) / 4; ++g) {
-        const int j = 4 * g + (int)qslot;
+      for (int g = 0; g < VW; ++g) {
+        const int j = VW == WT ? g : 4 * g + (int)qslot;
         val[p][g] = (i < E && j < WT) ? a.lvals[lbase + (int64_t)j * E + i] : 0.f;
       }
 #pragma unroll
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
 
       // ---- recurrence, two steps per trip so that the plane roles are compile-time ----------
       issue_loads(nitem, 1);
-      if (do_g) gather_step<WT, RP, false>(planeX, planeY, re(D - 1), row_l, val, pre, own);
+      if (do_g) gather_step<WT, RP, false, false, VW>(planeX, planeY, re(D - 1), row_l, val, pre, own);
       DSPH_STAMP(8);
       load_wfrag<NB, PREC>(wblk + wstride, lane, wf);
       __builtin_amdgcn_sched_barrier(0);
@@ -490,8 +496,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       for (int k = 2; k < a.K; k += 2) {
         issue_loads(nitem, k);
         if (do_g) {
-          if (cheb) gather_step<WT, RP, true>(planeY, planeX, re(D - k), row_l, val, pre, own);
-          else gather_step<WT, RP, false>(planeY, planeX, re(D - k), row_l, val, pre, own);
+          if (cheb) gather_step<WT, RP, true, false, VW>(planeY, planeX, re(D - k), row_l, val, pre, own);
+          else gather_step<WT, RP, false, false, VW>(planeY, planeX, re(D - k), row_l, val, pre, own);
         }
         DSPH_STAMP(11 + (k - 2) * 3);
         load_wfrag<NB, PREC>(wblk + (size_t)k * wstride, lane, wf);
@@ -503,8 +509,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
         if (k + 1 < a.K) {
           issue_loads(nitem, k + 1);
           if (do_g) {
-            if (cheb) gather_step<WT, RP, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
-            else gather_step<WT, RP, false>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
+            if (cheb) gather_step<WT, RP, true, false, VW>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
+            else gather_step<WT, RP, false, false, VW>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
           }
           DSPH_STAMP(14 + (k - 2) * 3);
           load_wfrag<NB, PREC>(wblk + (size_t)(k + 1) * wstride, lane, wf);
@@ -539,19 +545,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
         __syncthreads();
         wgrad_plane(sAcc + (cl * a.K) * WG_TILE_BYTES, smem, la, 0u, dyv);
         issue_loads(nitem, 1);
-        gather_step<WT, RP, false>(planeX, planeY, re(D - 1), row_l, val, pre, own);
+        gather_step<WT, RP, false, false, VW>(planeX, planeY, re(D - 1), row_l, val, pre, own);
         __syncthreads();
         wgrad_plane(sAcc + (cl * a.K + 1) * WG_TILE_BYTES, smem, la, (unsigned)PLANE_BYTES, dyv);
         for (int k = 2; k < a.K; k += 2) {
           issue_loads(nitem, k);
-          if (cheb) gather_step<WT, RP, true>(planeY, planeX, re(D - k), row_l, val, pre, own);
-          else gather_step<WT, RP, false>(planeY, planeX, re(D - k), row_l, val, pre, own);
+          if (cheb) gather_step<WT, RP, true, false, VW>(planeY, planeX, re(D - k), row_l, val, pre, own);
+          else gather_step<WT, RP, false, false, VW>(planeY, planeX, re(D - k), row_l, val, pre, own);
           __syncthreads();
           wgrad_plane(sAcc + (cl * a.K + k) * WG_TILE_BYTES, smem, la, 0u, dyv);
           if (k + 1 < a.K) {
             issue_loads(nitem, k + 1);
-            if (cheb) gather_step<WT, RP, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
-            else gather_step<WT, RP, false>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
+            if (cheb) gather_step<WT, RP, true, false, VW>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
+            else gather_step<WT, RP, false, false, VW>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
             __syncthreads();
             wgrad_plane(sAcc + (cl * a.K + k + 1) * WG_TILE_BYTES, smem, la, (unsigned)PLANE_BYTES, dyv);
           }
@@ -564,19 +570,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
         const int srows = ch_ok ? P_t : 0;
         __syncthreads();
         issue_loads(nitem, 1);
-        gather_step<WT, RP, false, true>(planeX, planeY, re(D - 1), row_l, val, pre, own, sp, spass, srows);
+        gather_step<WT, RP, false, true, VW>(planeX, planeY, re(D - 1), row_l, val, pre, own, sp, spass, srows);
         for (int k = 2; k < a.K; k += 2) {
           __syncthreads();
           issue_loads(nitem, k);
           sp += a.plane_stride;
-          if (cheb) gather_step<WT, RP, true, true>(planeY, planeX, re(D - k), row_l, val, pre, own, sp, spass, srows);
-          else gather_step<WT, RP, false, true>(planeY, planeX, re(D - k), row_l, val, pre, own, sp, spass, srows);
+          if (cheb) gather_step<WT, RP, true, true, VW>(planeY, planeX, re(D - k), row_l, val, pre, own, sp, spass, srows);
+          else gather_step<WT, RP, false, true, VW>(planeY, planeX, re(D - k), row_l, val, pre, own, sp, spass, srows);
           if (k + 1 < a.K) {
             __syncthreads();
             issue_loads(nitem, k + 1);
             sp += a.plane_stride;
-            if (cheb) gather_step<WT, RP, true, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own, sp, spass, srows);
-            else gather_step<WT, RP, false, true>(planeX, planeY, re(D - k - 1), row_l, val, pre, own, sp, spass, srows);
+            if (cheb) gather_step<WT, RP, true, true, VW>(planeX, planeY, re(D - k - 1), row_l, val, pre, own, sp, spass, srows);
+            else gather_step<WT, RP, false, true, VW>(planeX, planeY, re(D - k - 1), row_l, val, pre, own, sp, spass, srows);
           }
         }
       }
