@@ -35,6 +35,8 @@ CONFIGS = {
     "c1": (64, 5, 1, 16, 1),
     "c2": (256, 5, 16, 32, 8),
     "c3": (1024, 5, 64, 64, 4),
+    # configs[3] run on ONE GPU (BASELINE quotes it sharded over 4): the 7-ring-halo variant of the fused kernel
+    "c4": (2048, 8, 32, 32, 1),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
