@@ -59,3 +59,36 @@ def time_forward(Lt, x_np, kernel_np, K, budget_s=20.0, min_reps=1, threads=None
         if len(times) >= 50:
             break
     return {"seconds": float(np.median(times)), "reps": len(times), "threads": torch.get_num_threads(), "y": y}
+
+
+def time_forward_scipy_1thread(Lt, x_np, kernel_np, K, budget_s=10.0):
+    """The same op sequence with scipy CSR @ dense (single-threaded) and a numpy GEMM restricted to the
+    calling thread's BLAS default: the 'scalar port' figure of SURVEY 8(d).  Returns seconds per forward."""
+    import contextlib
+    import time
+
+    try:
+        from threadpoolctl import threadpool_limits
+        one_thread = threadpool_limits(limits=1)
+    except Exception:  # threadpoolctl missing: BLAS keeps its default thread count (reported by the caller)
+        one_thread = contextlib.nullcontext()
+    N, M, Fin = x_np.shape
+    Lc = Lt.tocsr().astype(np.float32)
+    times = []
+    t_all = time.perf_counter()
+    with one_thread:
+      while True:
+        t0 = time.perf_counter()
+        x0 = np.ascontiguousarray(np.transpose(x_np, (1, 2, 0)).reshape(M, Fin * N))
+        planes = [x0]
+        if K > 1:
+            planes.append(Lc @ x0)
+        for _k in range(2, K):
+            planes.append(2 * (Lc @ planes[-1]) - planes[-2])
+        X = np.stack(planes, axis=0).reshape(K, M, Fin, N)
+        X = np.transpose(X, (3, 1, 2, 0)).reshape(N * M, Fin * K)
+        y = (X @ kernel_np).reshape(N, M, -1)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s or len(times) >= 3:
+            break
+    return {"seconds": float(np.median(times)), "reps": len(times), "y": y}
