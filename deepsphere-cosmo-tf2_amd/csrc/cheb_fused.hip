@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void fused_wgrad_reduce_kernel(const float* __
 }
 
 int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* dy, float* dw, int64_t N,
-                            int32_t Fin, int32_t Fout, int32_t K, float alpha_rest, float beta_rest,
+                            int32_t Fin, int32_t Fout, int32_t K, int32_t precision, float alpha_rest, float beta_rest,
                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!fused_wgrad_supported(plan, Fin, Fout, K)) {
     set_error("cheb_fused_wgrad: plan/shape not supported");
@@ -384,7 +384,7 @@ int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* 
   }
   for (int32_t cb = 0; cb < Fout; cb += 64) {
     const int rc = launch_fused_common(plan, x, nullptr, nullptr, static_cast<float*>(workspace), nullptr, N, Fin,
-                                       std::min<int32_t>(64, Fout - cb), K, DSPH_ACT_NONE, DSPH_PREC_FP32, alpha_rest,
+                                       std::min<int32_t>(64, Fout - cb), K, DSPH_ACT_NONE, precision, alpha_rest,
                                        beta_rest, nullptr, 0, stream, dy + cb, dw + cb, Fout);
     if (rc != DSPH_OK) return rc;
   }

@@ -215,6 +215,48 @@ __device__ __forceinline__ void wgrad_plane(unsigned char* __restrict__ tile, co
   *reinterpret_cast<f32x4*>(tile) = t;
 }
 
+// The same contraction on the bf16 matrix pipe: v_mfma_f32_16x16x32_bf16, 32 pixels per MFMA, both operands
+// split hi + lo and three MFMAs per step (lo*hi, hi*lo, hi*hi), fp32 accumulate -- 12 MFMAs of 16 cycles per
+// plane and wave instead of 32 of 32.  Inner index e = 8 q + j of lane (i, q = l >> 4) is pixel 32 st + 4 j + q:
+// the A values are the very ds_read_b32 of the fp32 version (g = 8 st + j), the B values its dyv[g].
+struct DyFrag {
+  bf16x8 hi[4], lo[4];
+};
+
+__device__ __forceinline__ void split_bf16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+
+__device__ __forceinline__ void wgrad_plane_bf16(unsigned char* __restrict__ tile, const unsigned char* __restrict__ smem,
+                                                 const unsigned (&la)[4], unsigned plane_off, const DyFrag& dy) {
+  float av[2][8];
+  f32x4 t = *reinterpret_cast<const f32x4*>(tile);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) av[0][j] = *reinterpret_cast<const float*>(smem + plane_off + la[j & 3] + 256 * j);
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    if (st < 3) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int g = 8 * (st + 1) + j;
+        av[(st + 1) & 1][j] = *reinterpret_cast<const float*>(smem + plane_off + la[g & 3] + 256 * g);
+      }
+    }
+    bf16x8 ahi, alo;
+    split_bf16(av[st & 1], ahi, alo);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, dy.hi[st], t, 0, 0, 0);  // small terms first
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, dy.lo[st], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, dy.hi[st], t, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  *reinterpret_cast<f32x4*>(tile) = t;
+}
+
 // Diagnostic build (make STAMPS=1; never the shipped library): s_memtime at the phase boundaries of a few
 // items of one workgroup, into a buffer nothing else reads.  Read the shares, not the run time.
 #ifdef DSPH_STAMPS
@@ -373,7 +415,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   };
 
   // ---- weight-gradient mode: this wave's share is output columns 16 nb .. +16 and pixel half hp ----
-  float dyv[32];
+  float dyv[32];  // PREC == FP32: this wave's dy values of the current map
+  DyFrag dyf;     // PREC == BF16X3: the same, split
   unsigned la[4];
   const int wg_nb = wave & 3, wg_hp = wave >> 2, wg_i = lane & 15, wg_kk = lane >> 4;
   unsigned char* const sAcc = smem + 2 * PLANE_BYTES + tid * 16;  // tile i of this lane: + i * WG_TILE_BYTES
@@ -541,25 +584,33 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
               dyv[g] = (row < P_t && o < a.Fout) ? dyv[g] : 0.f;
             }
           }
+          if (PREC == DSPH_PREC_BF16X3) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+              const float v8[8] = {dyv[8 * st], dyv[8 * st + 1], dyv[8 * st + 2], dyv[8 * st + 3],
+                                   dyv[8 * st + 4], dyv[8 * st + 5], dyv[8 * st + 6], dyv[8 * st + 7]};
+              split_bf16(v8, dyf.hi[st], dyf.lo[st]);
+            }
+          }
         }
         __syncthreads();
-        wgrad_plane(sAcc + (cl * a.K) * WG_TILE_BYTES, smem, la, 0u, dyv);
+        { if (PREC == DSPH_PREC_BF16X3) wgrad_plane_bf16(sAcc + (cl * a.K) * WG_TILE_BYTES, smem, la, 0u, dyf); else wgrad_plane(sAcc + (cl * a.K) * WG_TILE_BYTES, smem, la, 0u, dyv); }
         issue_loads(nitem, 1);
         gather_step<WT, RP, false, false, VW>(planeX, planeY, re(D - 1), row_l, val, pre, own);
         __syncthreads();
-        wgrad_plane(sAcc + (cl * a.K + 1) * WG_TILE_BYTES, smem, la, (unsigned)PLANE_BYTES, dyv);
+        { if (PREC == DSPH_PREC_BF16X3) wgrad_plane_bf16(sAcc + (cl * a.K + 1) * WG_TILE_BYTES, smem, la, (unsigned)PLANE_BYTES, dyf); else wgrad_plane(sAcc + (cl * a.K + 1) * WG_TILE_BYTES, smem, la, (unsigned)PLANE_BYTES, dyv); }
         for (int k = 2; k < a.K; k += 2) {
           issue_loads(nitem, k);
           if (cheb) gather_step<WT, RP, true, false, VW>(planeY, planeX, re(D - k), row_l, val, pre, own);
           else gather_step<WT, RP, false, false, VW>(planeY, planeX, re(D - k), row_l, val, pre, own);
           __syncthreads();
-          wgrad_plane(sAcc + (cl * a.K + k) * WG_TILE_BYTES, smem, la, 0u, dyv);
+          { if (PREC == DSPH_PREC_BF16X3) wgrad_plane_bf16(sAcc + (cl * a.K + k) * WG_TILE_BYTES, smem, la, 0u, dyf); else wgrad_plane(sAcc + (cl * a.K + k) * WG_TILE_BYTES, smem, la, 0u, dyv); }
           if (k + 1 < a.K) {
             issue_loads(nitem, k + 1);
             if (cheb) gather_step<WT, RP, true, false, VW>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
             else gather_step<WT, RP, false, false, VW>(planeX, planeY, re(D - k - 1), row_l, val, pre, own);
             __syncthreads();
-            wgrad_plane(sAcc + (cl * a.K + k + 1) * WG_TILE_BYTES, smem, la, (unsigned)PLANE_BYTES, dyv);
+            { if (PREC == DSPH_PREC_BF16X3) wgrad_plane_bf16(sAcc + (cl * a.K + k + 1) * WG_TILE_BYTES, smem, la, (unsigned)PLANE_BYTES, dyf); else wgrad_plane(sAcc + (cl * a.K + k + 1) * WG_TILE_BYTES, smem, la, (unsigned)PLANE_BYTES, dyv); }
           }
         }
       } else {
@@ -628,7 +679,8 @@ template <int PR, int WT, int RPL>
 static int dispatch_nb_prec(const FusedArgs& args, int nb, int prec, int grid, size_t lds,
                             hipStream_t stream) {
   if (args.slabs != nullptr) {  // weight-gradient mode
-    auto kern = cheb_fused_kernel<PR, WT, RPL, 1, DSPH_PREC_FP32, 2>;
+    auto kern = prec == DSPH_PREC_BF16X3 ? cheb_fused_kernel<PR, WT, RPL, 1, DSPH_PREC_BF16X3, 2>
+                                         : cheb_fused_kernel<PR, WT, RPL, 1, DSPH_PREC_FP32, 2>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), 0, stream, args);
     DSPH_HIP(hipGetLastError());
     return DSPH_OK;

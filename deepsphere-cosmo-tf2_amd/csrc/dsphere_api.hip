@@ -303,8 +303,12 @@ size_t dsph_backward_weights_workspace_bytes(const dsph_plan* p, int64_t N, int3
 }
 
 int dsph_cheb_backward_weights(const dsph_plan* p, const float* x, const float* dy, float* dw, int64_t N,
-                               int32_t Fin, int32_t Fout, int32_t K, int32_t basis, int32_t algo,
+                               int32_t Fin, int32_t Fout, int32_t K, int32_t basis, int32_t precision, int32_t algo,
                                void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (precision != DSPH_PREC_FP32 && precision != DSPH_PREC_BF16X3) {
+    set_error("backward_weights: unknown precision %d", precision);
+    return DSPH_E_BADARG;
+  }
   if (basis != DSPH_BASIS_CHEBYSHEV && basis != DSPH_BASIS_MONOMIAL) {
     set_error("backward_weights: unknown basis %d", basis);
     return DSPH_E_BADARG;
@@ -332,8 +336,8 @@ int dsph_cheb_backward_weights(const dsph_plan* p, const float* x, const float* 
   }
   if (can_fuse && algo != DSPH_ALGO_UNFUSED) {
     DeviceGuard guard(p->device);
-    return launch_cheb_fused_wgrad(p, x, dy, dw, N, Fin, Fout, K, alpha_rest, beta_rest, workspace, workspace_bytes,
-                                   stream);
+    return launch_cheb_fused_wgrad(p, x, dy, dw, N, Fin, Fout, K, precision, alpha_rest, beta_rest, workspace,
+                                   workspace_bytes, stream);
   }
   // any L, any shape: K-1 gather launches into workspace planes, then the split-over-pixels MFMA kernel
   if (K > 64) { set_error("backward_weights: K = %d exceeds 64", K); return DSPH_E_UNSUPPORTED; }

@@ -71,7 +71,7 @@ int launch_cheb_fused_planes(const dsph_plan* plan, const float* x, float* plane
 bool fused_wgrad_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 size_t fused_wgrad_workspace_bytes(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* dy, float* dw, int64_t N,
-                            int32_t Fin, int32_t Fout, int32_t K, float alpha_rest, float beta_rest,
+                            int32_t Fin, int32_t Fout, int32_t K, int32_t precision, float alpha_rest, float beta_rest,
                             void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                              int32_t precision);

@@ -63,7 +63,8 @@ SIGNATURES = {
     "dsph_backward_weights_workspace_bytes": (ctypes.c_size_t, [_c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32]),
     "dsph_cheb_backward_weights": (
         ctypes.c_int,
-        [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp, ctypes.c_size_t, _c_vp],
+        [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp, ctypes.c_size_t,
+         _c_vp],
     ),
     "dsph_cheb_wgrad": (
         ctypes.c_int,
@@ -287,7 +288,7 @@ def cheb_planes(plan, x, K, basis=BASIS_CHEBYSHEV, algo=ALGO_AUTO):
     return [x] + [out[k] for k in range(K - 1)]
 
 
-def cheb_backward_weights(plan, x, dy, K, basis=BASIS_CHEBYSHEV, algo=ALGO_AUTO, workspace=None):
+def cheb_backward_weights(plan, x, dy, K, basis=BASIS_CHEBYSHEV, algo=ALGO_AUTO, workspace=None, precision=PREC_FP32):
     """dkernel[f*K + k, o] = sum_{n,m} (T_k x)[n,m,f] dy[n,m,o] (``dsph_cheb_backward_weights``).
     Returns (dkernel, workspace)."""
     import torch
@@ -303,7 +304,7 @@ def cheb_backward_weights(plan, x, dy, K, basis=BASIS_CHEBYSHEV, algo=ALGO_AUTO,
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
     dw = torch.empty((Fin * K, Fout), dtype=torch.float32, device=x.device)
     rc = lib().dsph_cheb_backward_weights(plan.handle, _ptr(x), _ptr(dy), _ptr(dw), int(N), int(Fin), Fout, int(K),
-                                          int(basis), int(algo), _ptr(workspace),
+                                          int(basis), int(precision), int(algo), _ptr(workspace),
                                           workspace.numel() * workspace.element_size(), _stream_ptr(x.device))
     check(rc, "dsph_cheb_backward_weights")
     return dw, workspace

@@ -104,7 +104,8 @@ class _ChebConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             plan = layer._get_plan()
             dk, layer._workspace_w = _native.cheb_backward_weights(
-                plan, x, dy, K, basis=layer._basis, algo=_ALGOS[layer.algo], workspace=getattr(layer, "_workspace_w", None))
+                plan, x, dy, K, basis=layer._basis, algo=_ALGOS[layer.algo], workspace=getattr(layer, "_workspace_w", None),
+                precision=_PRECISIONS[layer.precision])
         return dx, dk, None
 
 

@@ -145,13 +145,14 @@ int dsph_cheb_planes(const dsph_plan* plan, const float* x, float* planes, int64
  * from the layer input x (N, n_cols, Fin) and the upstream gradient dy (N, out_rows, Fout).  The reference
  * has no counterpart of its own: TensorFlow differentiates the op sequence of gnn_layers.py:131-150.
  * When the fused tile kernel applies (dsph_plan_fused_ok) the planes never leave the LDS: each tile's T_k
- * is contracted over its pixels against dy on the exact-fp32 MFMA path, per-workgroup partial sums are
- * reduced in a fixed order (deterministic).  Otherwise: dsph_cheb_planes into `workspace`, then
+ * is contracted over its pixels against dy -- `precision` DSPH_PREC_FP32: exact-fp32 MFMAs; DSPH_PREC_BF16X3: both
+ * operands split hi + lo, three bf16 MFMAs per product term, fp32 accumulate (fused path only) -- and the
+ * per-workgroup partial sums are reduced in a fixed order (deterministic).  Otherwise: dsph_cheb_planes into `workspace`, then
  * dsph_cheb_wgrad.  `algo` as in dsph_cheb_forward. */
 size_t dsph_backward_weights_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout,
                                              int32_t K, int32_t algo);
 int dsph_cheb_backward_weights(const dsph_plan* plan, const float* x, const float* dy, float* dw, int64_t N,
-                               int32_t Fin, int32_t Fout, int32_t K, int32_t basis, int32_t algo,
+                               int32_t Fin, int32_t Fout, int32_t K, int32_t basis, int32_t precision, int32_t algo,
                                void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Weight gradient (training):  dw[f*K + k, o] = sum_{n, m < rows} planes[k][n,m,f] * dy[n,m,o]

@@ -592,6 +592,11 @@ def test_backward_weights(graph, nside, N, Fin, Fout, K, basis):
     assert rel_err(unfused.cpu().numpy(), ref) < TOL_FP32
     again, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, basis=bcode, algo=_native.ALGO_FUSED)
     assert torch.equal(fused, again)  # fixed-order reduction of the per-workgroup partial sums
+    split, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, basis=bcode, algo=_native.ALGO_FUSED,
+                                             precision=_native.PREC_BF16X3)
+    err = rel_err(split.cpu().numpy(), ref)
+    print(f"backward weights bf16x3 {graph} nside={nside} {Fin}->{Fout} K={K}: rel err {err:.2e}")
+    assert err < TOL_BF16X3
 
 
 def test_backward_weights_falls_back_when_the_accumulators_do_not_fit():
