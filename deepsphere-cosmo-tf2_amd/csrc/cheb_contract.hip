@@ -12,6 +12,8 @@
 // by 16 B (conflict-free for the four 16-lane groups), B fragments with ds_read_b32.
 // Roofline: reads K planes + writes y once -> HBM-bound for Fin*Fout small, fp32-MFMA-bound
 // (157 TFLOP/s) from about Fin = Fout = 64 up.
+#include <algorithm>
+
 #include "dsphere_common.h"
 
 namespace dsph {
@@ -139,6 +141,70 @@ __global__ __launch_bounds__(256) void cheb_contract_f32_kernel(
   }
 }
 
+// Few input channels (Fin*K <= 64: the first layer of every network has Fin = 1): the MFMA kernel above pads the
+// inner dimension to 32 per order, i.e. does 32x the work at Fin = 1 and was MFMA-bound at 10 % of the
+// roofline.  Here one thread makes four adjacent outputs of one pixel with plain FMAs (order k outer, f inner,
+// the same chain as the MFMA kernel), the weights sit in LDS, the Fin*K plane values of a pixel are read by the
+// threads of its row as broadcasts: HBM-bound on the y write.
+__global__ __launch_bounds__(256) void cheb_contract_small_kernel(PlanePtrs planes, int64_t plane_rows,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, float* __restrict__ y,
+                                                                  int64_t rows, int Fin, int Fout, int K, int act,
+                                                                  int qshift, int iters, int vec_ok) {
+  // LDS: weights [Fin*K][4*Qp] (zero-padded columns), then this workgroup's plane values [K][rows_blk][Fin]:
+  // read from global memory as K contiguous runs (a load per pixel and order would be vector-memory-issue bound)
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Qp = 1 << qshift, FK = Fin * K, ldw = 4 * Qp, rpb = 256 >> qshift, rows_blk = iters * rpb;
+  float* __restrict__ sw = sm;
+  float* __restrict__ sp = sm + FK * ldw;
+  for (int i = threadIdx.x; i < FK * ldw; i += 256) {
+    const int r = i >> (qshift + 2), o = i & (ldw - 1);
+    sw[i] = o < Fout ? w[(int64_t)r * Fout + o] : 0.f;
+  }
+  const int n = blockIdx.y;
+  const int64_t mb = (int64_t)blockIdx.x * rows_blk;
+  const int64_t nrow = rows - mb < rows_blk ? rows - mb : rows_blk;
+  const int run = (int)nrow * Fin;  // floats of one plane that belong to this workgroup
+  for (int k = 0; k < K; ++k) {
+    const float* __restrict__ src = planes.p[k] + ((int64_t)n * plane_rows + mb) * Fin;
+    for (int i = threadIdx.x; i < run; i += 256) sp[k * rows_blk * Fin + i] = src[i];
+  }
+  __syncthreads();
+  const int oq = threadIdx.x & (Qp - 1), rsub = threadIdx.x >> qshift;
+  const int o0 = 4 * oq;
+  if (o0 >= Fout) return;
+  float bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = (bias && o0 + j < Fout) ? bias[o0 + j] : 0.f;
+  for (int it = 0; it < iters; ++it) {
+    const int rl = it * rpb + rsub;
+    if (rl >= nrow) break;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K; ++k) {
+      const float* __restrict__ pl = sp + (k * rows_blk + rl) * Fin;
+      for (int f = 0; f < Fin; ++f) {
+        const float v = pl[f];
+        const float4 wv = *reinterpret_cast<const float4*>(sw + (f * K + k) * ldw + o0);
+        acc.x = fmaf(v, wv.x, acc.x);
+        acc.y = fmaf(v, wv.y, acc.y);
+        acc.z = fmaf(v, wv.z, acc.z);
+        acc.w = fmaf(v, wv.w, acc.w);
+      }
+    }
+    float r[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = apply_act(r[j] + bv[j], act);
+    float* __restrict__ yp = y + ((int64_t)n * rows + mb + rl) * Fout + o0;
+    if (vec_ok && o0 + 3 < Fout) {
+      *reinterpret_cast<float4*>(yp) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (o0 + j < Fout) yp[j] = r[j];
+    }
+  }
+}
+
 int launch_cheb_contract(const float* const* planes, int64_t plane_rows, const float* w,
                          const float* bias, float* y, int64_t N, int64_t rows, int32_t Fin,
                          int32_t Fout, int32_t K, int32_t act, int32_t precision,
@@ -161,6 +227,25 @@ int launch_cheb_contract(const float* const* planes, int64_t plane_rows, const f
   }
   for (int k = K; k < KMAX; ++k) pp.p[k] = nullptr;
   const bool vec_w = (Fout % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+  {
+    const int Q = (Fout + 3) / 4;
+    int qshift = 0;
+    while ((1 << qshift) < Q) ++qshift;
+    const size_t sw_bytes = (size_t)Fin * K * 4 * ((size_t)1 << qshift) * sizeof(float);
+    if (Fin * K <= 64 && qshift <= 6 && sw_bytes <= 24 * 1024) {
+      const int rpb = 256 >> qshift;
+      int iters = (int)((40 * 1024) / ((size_t)rpb * Fin * K * sizeof(float)));  // plane values of the workgroup: <= 40 KiB
+      iters = std::max(1, std::min(16, iters));
+      const size_t lds = sw_bytes + (size_t)iters * rpb * Fin * K * sizeof(float);
+      const int rows_per_blk = iters * rpb;
+      const int64_t nblk = (rows + rows_per_blk - 1) / rows_per_blk;
+      const int vec_ok = (Fout % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+      hipLaunchKernelGGL(cheb_contract_small_kernel, dim3((unsigned)nblk, (unsigned)N), dim3(256), lds, stream, pp,
+                         plane_rows, w, bias, y, rows, (int)Fin, (int)Fout, (int)K, (int)act, qshift, iters, vec_ok);
+      DSPH_HIP(hipGetLastError());
+      return DSPH_OK;
+    }
+  }
   const int nb = Fout > 32 ? 2 : 1;
   const int wn = 32 * nb;
   dim3 grid((unsigned)((rows + TM - 1) / TM), (unsigned)N, (unsigned)((Fout + wn - 1) / wn));
