@@ -261,7 +261,7 @@ static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
   if (!plan->fused) return false;
   if (K < 2 || K - 1 > FUSED_DMAX) return false;
-  if (Fin % 4 != 0 || Fin < 8 || Fout < 1) return false;  // Fout > 64: one launch per 64-column block
+  if (Fin % 4 != 0 || Fin < 4 || Fout < 1) return false;  // Fout > 64: one launch per 64-column block
   const FusedTiles& ft = get_tiles(plan, K - 1);
   if (!ft.ok) return false;
   const int pr = plane_rows_for(ft.rmax, ft.emax);

@@ -103,6 +103,7 @@ def test_odd_shapes(Fin, Fout, K, N):
     ("grid", 16, 1, 40, 64, 3),   # Fin not a multiple of the 16-channel slice
     ("cap", 16, 2, 32, 64, 5),    # partial sky: ragged last tile, border rows with few neighbours
     ("grid", 16, 2, 16, 130, 3),  # more than 64 output columns: one launch per 64-column block (64 + 64 + 2)
+    ("grid", 16, 2, 4, 32, 5),    # four input channels: a quarter-filled slice
 ])
 def test_fused_kernel(graph, nside, N, Fin, Fout, K, prec, tol):
     if graph == "cap":
