@@ -570,7 +570,8 @@ def test_planes_kernel(graph, nside, N, Fin, K, basis):
 @pytest.mark.parametrize("basis", ["chebyshev", "monomial"])
 @pytest.mark.parametrize("graph,nside,N,Fin,Fout,K", [("grid", 16, 2, 64, 64, 5), ("grid", 16, 3, 40, 24, 3),
                                                        ("knn", 16, 2, 16, 7, 4), ("cap", 16, 2, 32, 64, 5),
-                                                       ("grid", 32, 1, 8, 33, 6), ("grid", 16, 1, 16, 100, 3)])
+                                                       ("grid", 32, 1, 8, 33, 6), ("grid", 16, 1, 16, 100, 3),
+                                                       ("grid", 16, 2, 8, 8, 2)])
 def test_backward_weights(graph, nside, N, Fin, Fout, K, basis):
     """dsph_cheb_backward_weights: the fused tile kernel in weight-gradient mode against the float64 oracle
     (dW[f*K+k, o] = sum_{n,m} T_k(x)[n,m,f] dy[n,m,o]) and against the planes + wgrad route."""
@@ -611,6 +612,19 @@ def test_backward_weights_falls_back_when_the_accumulators_do_not_fit():
     dy = rng.standard_normal((N, Lt.shape[0], Fout)).astype(np.float32)
     with pytest.raises(RuntimeError, match="fused kernel cannot run"):
         _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, algo=_native.ALGO_FUSED)
+    ref = np.einsum("knmf,nmo->fko", orc.chebyshev_planes(Lt, x, K), dy.astype(np.float64)).reshape(Fin * K, Fout)
+    dw, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K)
+    assert rel_err(dw.cpu().numpy(), ref) < TOL_FP32
+
+
+@pytest.mark.parametrize("Fin,Fout,K", [(8, 8, 1), (3, 5, 4), (1, 16, 5)])
+def test_backward_weights_unfused_shapes(Fin, Fout, K):
+    """K = 1 (no recurrence at all) and channel counts the tile kernel does not take: planes + wgrad route."""
+    Lt, _ = orc.prepare_L(healpix.healpix_laplacian(8, mode="knn"))
+    plan = _plan(Lt)
+    rng = np.random.default_rng(Fin + Fout + K)
+    x = rng.standard_normal((2, Lt.shape[0], Fin)).astype(np.float32)
+    dy = rng.standard_normal((2, Lt.shape[0], Fout)).astype(np.float32)
     ref = np.einsum("knmf,nmo->fko", orc.chebyshev_planes(Lt, x, K), dy.astype(np.float64)).reshape(Fin * K, Fout)
     dw, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K)
     assert rel_err(dw.cpu().numpy(), ref) < TOL_FP32
