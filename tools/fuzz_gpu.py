@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Randomised cross-check on the GPU: fused vs unfused forward, planes, weight gradient (fp32 and bf16x3) on
+random graphs / shapes.  Usage: fuzz_gpu.py [cases] [seed]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "deepsphere-cosmo-tf2_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from deepsphere import _native, healpix, utils  # noqa: E402
+from oracle import cheb_oracle as orc  # noqa: E402
+
+NSIDES = [int(v) for v in os.environ.get("FUZZ_NSIDES", "8,16,32").split(",")]
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()  # noqa: E731
+rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))  # noqa: E731
+plans = {}
+bad = 0
+for it in range(cases):
+    nside = int(rng.choice(NSIDES))
+    mode = str(rng.choice(["grid", "knn", "cap"]))
+    frac = float(rng.uniform(0.1, 0.9))
+    basis = int(rng.choice([_native.BASIS_CHEBYSHEV, _native.BASIS_MONOMIAL]))
+    key = (nside, mode, round(frac, 1) if mode == "cap" else 0, basis)
+    if key not in plans:
+        if mode == "cap":
+            idx = healpix.extend_indices(healpix.cap_indices(nside, fraction=key[2]), nside, max(1, nside // 4))
+            idx = idx[: len(idx) - int(rng.integers(0, 50))]
+            L = healpix.healpix_laplacian(nside, indices=idx, mode="grid")
+        else:
+            L = healpix.healpix_laplacian(nside, mode=mode)
+        Lt, _ = orc.prepare_L(L, scale=0.75 if basis == _native.BASIS_CHEBYSHEV else 1.0)
+        cols, vals = utils.csr_to_ell(Lt)
+        plans[key] = (Lt, _native.LaplacianPlan(cols, vals, device=0))
+    Lt, plan = plans[key]
+    M = Lt.shape[0]
+    K = int(rng.integers(2, 10))
+    Fin = 4 * int(rng.integers(1, 19))
+    Fout = int(rng.integers(1, 141))
+    N = int(rng.integers(1, 4))
+    if not plan.fused_ok(Fin, Fout, K):
+        continue
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) / np.sqrt(Fin * K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    dy = rng.standard_normal((N, M, Fout)).astype(np.float32)
+    act = int(rng.choice([_native.ACT_NONE, _native.ACT_RELU, _native.ACT_TANH]))
+    xd, Wd, bd, dyd = dev(x), dev(W), dev(b), dev(dy)
+    yu, _ = _native.cheb_forward(plan, xd, Wd, bd, K, act=act, algo=_native.ALGO_UNFUSED, basis=basis)
+    yf, _ = _native.cheb_forward(plan, xd, Wd, bd, K, act=act, algo=_native.ALGO_FUSED, basis=basis, precision=_native.PREC_FP32)
+    yb, _ = _native.cheb_forward(plan, xd, Wd, bd, K, act=act, algo=_native.ALGO_FUSED, basis=basis, precision=_native.PREC_BF16X3)
+    e1, e2 = rel(yf.cpu().numpy(), yu.cpu().numpy()), rel(yb.cpu().numpy(), yu.cpu().numpy())
+    pf = _native.cheb_planes(plan, xd, K, basis=basis, algo=_native.ALGO_FUSED)
+    pu = _native.cheb_planes(plan, xd, K, basis=basis, algo=_native.ALGO_UNFUSED)
+    same = all(torch.equal(a, b2) for a, b2 in zip(pf, pu))
+    du, _ = _native.cheb_backward_weights(plan, xd, dyd, K, basis=basis, algo=_native.ALGO_UNFUSED)
+    e3 = e4 = -1.0
+    try:
+        df, _ = _native.cheb_backward_weights(plan, xd, dyd, K, basis=basis, algo=_native.ALGO_FUSED)
+        dbf, _ = _native.cheb_backward_weights(plan, xd, dyd, K, basis=basis, algo=_native.ALGO_FUSED, precision=_native.PREC_BF16X3)
+        e3, e4 = rel(df.cpu().numpy(), du.cpu().numpy()), rel(dbf.cpu().numpy(), du.cpu().numpy())
+    except RuntimeError as exc:  # accumulators do not fit beside the planes: refused loudly, fine
+        if "cannot run" not in str(exc):
+            raise
+    ok = e1 < 2e-5 and e2 < 1e-4 and same and e3 < 2e-5 and e4 < 1e-4
+    bad += not ok
+    print(f"{'ok ' if ok else 'BAD'} nside={nside} {mode} M={M} K={K} {Fin}->{Fout} N={N} act={act} basis={basis}: fwd {e1:.1e} {e2:.1e} planes {same} dW {e3:.1e} {e4:.1e}",
+          flush=True)
+print("FAILED" if bad else "ALL OK", bad)
+sys.exit(1 if bad else 0)
