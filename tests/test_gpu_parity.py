@@ -628,3 +628,17 @@ def test_backward_weights_unfused_shapes(Fin, Fout, K):
     ref = np.einsum("knmf,nmo->fko", orc.chebyshev_planes(Lt, x, K), dy.astype(np.float64)).reshape(Fin * K, Fout)
     dw, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K)
     assert rel_err(dw.cpu().numpy(), ref) < TOL_FP32
+
+
+def test_fuzz_fused_against_unfused():
+    """A short run of tools/fuzz_gpu.py (random graphs, shapes, bases, activations): fused forward in both
+    precisions, planes (bitwise) and weight gradient against the unfused kernels."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "16", "3"], capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "ALL OK" in res.stdout
