@@ -50,6 +50,10 @@ struct FusedTiles {
   int32_t* d_region = nullptr;
   uint16_t* d_lcols = nullptr;
   float* d_lvals = nullptr;
+  // tiles whose whole region lies in the plan's output rows ("interior": on a sharded plan they need no halo row
+  // of another rank) and the rest ("boundary"); positions [0, n_interior) and [n_interior, ntiles) of d_part
+  int32_t* d_part = nullptr;
+  int n_interior = 0;
 };
 
 struct FusedPlan {
@@ -73,6 +77,7 @@ static void free_tiles(FusedTiles& ft) {
   if (ft.d_region) (void)hipFree(ft.d_region);
   if (ft.d_lcols) (void)hipFree(ft.d_lcols);
   if (ft.d_lvals) (void)hipFree(ft.d_lvals);
+  if (ft.d_part) (void)hipFree(ft.d_part);
   ft = FusedTiles();
 }
 
@@ -126,7 +131,7 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
   std::vector<uint16_t> lcols;
   std::vector<float> lvals;
   region.reserve((size_t)ntiles * 600);
-  std::vector<int32_t> ring, next;
+  std::vector<int32_t> ring, next, interior, boundary;
   int rmax = 0, emax = 0;
   int64_t ell_rows = 0;
   for (int t = 0; t < ntiles; ++t) {
@@ -192,6 +197,11 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
     }
     for (int d = D + 1; d <= FUSED_DMAX; ++d) re[d] = re[D];
     const int R = re[D], E = re[D - 1];
+    {
+      bool inner = true;
+      for (size_t i = base; i < region.size() && inner; ++i) inner = region[i] < out_rows;
+      (inner ? interior : boundary).push_back(t);
+    }
     if (R > 65535) return ft;  // uint16 local columns
     rmax = std::max(rmax, R);
     emax = std::max(emax, E);
@@ -229,12 +239,16 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
   };
   if (lcols.empty()) { lcols.push_back(0); lvals.push_back(0.f); }
+  ft.n_interior = (int)interior.size();
+  interior.insert(interior.end(), boundary.begin(), boundary.end());
+  if (interior.empty()) interior.push_back(0);
   bool good = up((void**)&ft.d_tile_off, tile_off.data(), tile_off.size() * 4) &&
               up((void**)&ft.d_ring_end, ring_end.data(), ring_end.size() * 4) &&
               up((void**)&ft.d_ell_off, ell_off.data(), ell_off.size() * 8) &&
               up((void**)&ft.d_region, region.data(), region.size() * 4) &&
               up((void**)&ft.d_lcols, lcols.data(), lcols.size() * 2) &&
-              up((void**)&ft.d_lvals, lvals.data(), lvals.size() * 4);
+              up((void**)&ft.d_lvals, lvals.data(), lvals.size() * 4) &&
+              up((void**)&ft.d_part, interior.data(), interior.size() * 4);
   if (!good) {
     FusedTiles keep = ft;
     free_tiles(ft);
@@ -306,18 +320,18 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream,
-                               const float* dy = nullptr, float* dw = nullptr, int32_t ld = 0);
+                               const float* dy = nullptr, float* dw = nullptr, int32_t ld = 0, int32_t part = 0);
 
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream) {
+                      size_t workspace_bytes, hipStream_t stream, int32_t part) {
   // more than 64 output columns: one launch per 64-column block (the recurrence is repeated; still one pass
   // over x per block instead of the unfused path's K planes through HBM)
   for (int32_t cb = 0; cb < Fout; cb += 64) {
     const int rc = launch_fused_common(plan, x, w + cb, bias ? bias + cb : nullptr, y + cb, nullptr, N, Fin,
                                        std::min<int32_t>(64, Fout - cb), K, act, precision, alpha_rest, beta_rest,
-                                       workspace, workspace_bytes, stream, nullptr, nullptr, Fout);
+                                       workspace, workspace_bytes, stream, nullptr, nullptr, Fout, part);
     if (rc != DSPH_OK) return rc;
   }
   return DSPH_OK;
@@ -333,8 +347,9 @@ int launch_cheb_fused_planes(const dsph_plan* plan, const float* x, float* plane
 }
 
 // ---- weight-gradient mode ------------------------------------------------------------------------------
-static int fused_grid(const dsph_plan* plan, const FusedTiles& ft) {
-  return std::max(8, std::min(plan->fused->num_cu, (ft.ntiles + 7) / 8 * 8));
+static int fused_grid(const dsph_plan* plan, const FusedTiles& ft, int ntiles = -1) {
+  if (ntiles < 0) ntiles = ft.ntiles;
+  return std::max(8, std::min(plan->fused->num_cu, (ntiles + 7) / 8 * 8));
 }
 
 // slices per launch: as many accumulator tiles (one per slice and order, 8 KiB each) as fit the LDS next to the planes
@@ -395,7 +410,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream, const float* dy,
-                               float* dw, int32_t ld) {
+                               float* dw, int32_t ld, int32_t part) {
   if (ld <= 0) ld = Fout;  // row stride of w, bias-less y / dy / dw: the layer's Fout when this is one column block
   if (!fused_supported(plan, Fin, Fout, K)) {
     set_error("cheb_fused: plan/shape not supported");
@@ -447,7 +462,10 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   args.Fout = Fout;
   args.ld = ld;
   args.K = K;
-  args.ntiles = ft.ntiles;
+  // part: 0 all tiles, 1 interior tiles (no row of another rank in their region), 2 boundary tiles
+  args.tile_list = part == 0 ? nullptr : (part == 1 ? ft.d_part : ft.d_part + ft.n_interior);
+  args.ntiles = part == 0 ? ft.ntiles : (part == 1 ? ft.n_interior : ft.ntiles - ft.n_interior);
+  if (args.ntiles == 0) return DSPH_OK;
   args.nchunks = C;
   args.act = act;
   args.alpha_rest = alpha_rest;
@@ -457,7 +475,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   args.dbg = dbg ? atoi(dbg) : 0;
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wb;
-  const int grid = fused_grid(plan, ft);
+  const int grid = wgrad_mode ? fused_grid(plan, ft) : fused_grid(plan, ft, args.ntiles);
   if (wgrad_mode) {
     // as many slices per launch as fit the wave's WG_TILES accumulator tiles; every launch runs the
     // recurrence for its own slices only, so the split costs nothing but a second read of dy

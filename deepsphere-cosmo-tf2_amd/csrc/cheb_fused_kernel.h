@@ -27,6 +27,7 @@ struct FusedArgs {
   const float* bias;
   float* y;
   const unsigned char* wfrag;
+  const int32_t* tile_list;  // optional indirection: this launch handles tiles tile_list[0 .. ntiles) (NULL: 0 .. ntiles)
   const int32_t* tile_off;
   const int32_t* ring_end;
   const int64_t* ell_off;
@@ -327,7 +328,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   // (1.3-2.5 k cycles per slice).  Rows past the region and channels past Fin read a valid address
   // instead (the former are never used, the latter are zeroed when the slice is staged).
   auto load_rids = [&](int tv) {
-    const int t = __builtin_amdgcn_readfirstlane(tv);  // uniform: the two table reads below stay scalar loads
+    const int pos = __builtin_amdgcn_readfirstlane(tv);  // uniform: the table reads below stay scalar loads
+    const int t = a.tile_list ? a.tile_list[pos] : pos;
     const int off = a.tile_off[t];
     const int R = a.ring_end[(size_t)t * (FUSED_DMAX + 1) + D];
 #pragma unroll
@@ -437,7 +439,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   for (; t < t_end; t += nslots) {
     // ring sizes of this tile, 11 bits each, in two scalar registers (re-reading them from memory
     // in every step would put a dependent scalar load in front of each recurrence step)
-    const int32_t* __restrict__ re_mem = a.ring_end + (size_t)t * (FUSED_DMAX + 1);
+    const int tt = a.tile_list ? a.tile_list[t] : t;  // t: position in this launch's list; tt: the tile
+    const int32_t* __restrict__ re_mem = a.ring_end + (size_t)tt * (FUSED_DMAX + 1);
     unsigned long long re_lo = 0, re_hi = 0;
 #pragma unroll
     for (int r = 0; r <= FUSED_DMAX; ++r) {
@@ -449,8 +452,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       return (int)(((r < 5 ? re_lo >> (11 * r) : re_hi >> (11 * (r - 5)))) & 0x7ffull);
     };
     const int P_t = re(0), E = re(D - 1);
-    const int64_t lbase = a.ell_off[t] * WT;
-    const int64_t row0 = (int64_t)t * FUSED_P;
+    const int64_t lbase = a.ell_off[tt] * WT;
+    const int64_t row0 = (int64_t)tt * FUSED_P;
 
     // this lane's recurrence rows: ELL values and swizzled LDS byte addresses stay in registers
     // One value register per neighbour (9 per row) where the registers allow it: the quad-packed form (3 per

@@ -196,6 +196,18 @@ int dsph_poly_forward(const dsph_plan* p, const float* x, const float* w, const 
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t basis,
                       int32_t act, int32_t precision, int32_t algo, void* workspace,
                       size_t workspace_bytes, void* hip_stream) {
+  return dsph_poly_forward_part(p, x, w, bias, y, N, Fin, Fout, K, basis, act, precision, algo, DSPH_PART_ALL,
+                                workspace, workspace_bytes, hip_stream);
+}
+
+int dsph_poly_forward_part(const dsph_plan* p, const float* x, const float* w, const float* bias,
+                           float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t basis,
+                           int32_t act, int32_t precision, int32_t algo, int32_t part, void* workspace,
+                           size_t workspace_bytes, void* hip_stream) {
+  if (part != DSPH_PART_ALL && part != DSPH_PART_INTERIOR && part != DSPH_PART_BOUNDARY) {
+    set_error("poly_forward: unknown part %d", part);
+    return DSPH_E_BADARG;
+  }
   if (basis != DSPH_BASIS_CHEBYSHEV && basis != DSPH_BASIS_MONOMIAL) {
     set_error("poly_forward: unknown basis %d", basis);
     return DSPH_E_BADARG;
@@ -225,7 +237,11 @@ int dsph_poly_forward(const dsph_plan* p, const float* x, const float* w, const 
   DeviceGuard guard(p->device);
   if (a == DSPH_ALGO_FUSED)
     return launch_cheb_fused(p, x, w, bias, y, N, Fin, Fout, K, act, precision, alpha_rest, beta_rest,
-                             workspace, workspace_bytes, stream);
+                             workspace, workspace_bytes, stream, part);
+  if (part != DSPH_PART_ALL) {
+    set_error("poly_forward: interior / boundary parts exist for the fused kernel only");
+    return DSPH_E_UNSUPPORTED;
+  }
 
   // ---- unfused: K-1 SpMM launches into workspace planes, then one contraction ---------------
   if (K > 64) { set_error("cheb_forward: K = %d exceeds 64", K); return DSPH_E_UNSUPPORTED; }

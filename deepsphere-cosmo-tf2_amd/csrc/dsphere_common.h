@@ -64,7 +64,7 @@ bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream);
+                      size_t workspace_bytes, hipStream_t stream, int32_t part = 0);
 bool fused_planes_supported(const dsph_plan* plan, int32_t Fin, int32_t K);
 int launch_cheb_fused_planes(const dsph_plan* plan, const float* x, float* planes_out, int64_t N, int32_t Fin,
                              int32_t K, float alpha_rest, float beta_rest, hipStream_t stream);

@@ -17,6 +17,7 @@ OK = 0
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 PREC_FP32, PREC_BF16X3 = 0, 1
 ALGO_AUTO, ALGO_UNFUSED, ALGO_FUSED = 0, 1, 2
+PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
 BASIS_CHEBYSHEV, BASIS_MONOMIAL = 0, 1
 
 _c_i64 = ctypes.c_int64
@@ -45,6 +46,11 @@ SIGNATURES = {
         ctypes.c_int,
         [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp,
          ctypes.c_size_t, _c_vp],
+    ),
+    "dsph_poly_forward_part": (
+        ctypes.c_int,
+        [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32,
+         _c_vp, ctypes.c_size_t, _c_vp],
     ),
     "dsph_cheb_step": (
         ctypes.c_int,
@@ -199,8 +205,10 @@ def _check_dev(t, plan, name):
 
 
 def cheb_forward(plan, x, w, bias, K, act=ACT_NONE, precision=PREC_FP32, algo=ALGO_AUTO, workspace=None, out=None,
-                 basis=BASIS_CHEBYSHEV):
-    """y = dsph_poly_forward(...) on torch CUDA tensors; x (N, n_cols, Fin), w (Fin*K, Fout)."""
+                 basis=BASIS_CHEBYSHEV, part=PART_ALL):
+    """y = dsph_poly_forward(...) on torch CUDA tensors; x (N, n_cols, Fin), w (Fin*K, Fout).
+    ``part``: PART_ALL, or PART_INTERIOR / PART_BOUNDARY (fused kernel only) to write only the tiles that do not /
+    do touch halo rows -- pass the same ``out`` to both calls."""
     import torch
 
     _check_dev(x, plan, "x")
@@ -225,12 +233,12 @@ def cheb_forward(plan, x, w, bias, K, act=ACT_NONE, precision=PREC_FP32, algo=AL
         _check_dev(out, plan, "out")
         if tuple(out.shape) != (N, orows, Fout):
             raise ValueError("out has the wrong shape")
-    rc = lib().dsph_poly_forward(
+    rc = lib().dsph_poly_forward_part(
         plan.handle, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), int(N), int(Fin), Fout, int(K), int(basis), int(act),
-        int(precision), int(algo), _ptr(workspace) if need > 0 else _c_vp(),
+        int(precision), int(algo), int(part), _ptr(workspace) if need > 0 else _c_vp(),
         (workspace.numel() * workspace.element_size()) if need > 0 else 0, _stream_ptr(x.device),
     )
-    check(rc, "dsph_poly_forward")
+    check(rc, "dsph_poly_forward_part")
     return out, workspace
 
 

@@ -172,6 +172,13 @@ class ShardedChebyshev:
 
     def exchange(self, x_local):
         """(N, own, F) -> (N, n_cols, F): own rows followed by the halo rows fetched from their owners."""
+        x_ext, finish = self.exchange_start(x_local)
+        finish()
+        return x_ext
+
+    def exchange_start(self, x_local):
+        """Starts the halo exchange and returns ``(x_ext, finish)``: the transfers are in flight until ``finish()``
+        (wait + unpack into the halo rows of ``x_ext``) -- work that touches no halo row can be issued in between."""
         import torch.distributed as dist
 
         lay = self.layout
@@ -186,7 +193,7 @@ class ShardedChebyshev:
         if not in_place:
             x_ext[:, :own].copy_(x_local)
         if self.world == 1 or not (self._send_idx or self._recv_idx):
-            return x_ext
+            return x_ext, (lambda: None)
         # RCCL moves device buffers directly (xGMI peer-to-peer).  Under a gloo group (no RCCL: several
         # ranks sharing one GPU, debugging) the packed rows are staged through host memory instead;
         # only the transport differs, the pack / unpack kernels and the forward are the same.
@@ -203,11 +210,16 @@ class ShardedChebyshev:
                               device="cpu" if via_host else x_local.device)
             recv_bufs[p] = buf
             ops.append(dist.P2POp(dist.irecv, buf, self._peer(p), group=self.group))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        for p, buf in recv_bufs.items():
-            _unpack(x_ext, self._recv_idx[p], buf.to(x_local.device) if via_host else buf)
-        return x_ext
+        reqs = dist.batch_isend_irecv(ops)
+
+        def finish():
+            for req in reqs:
+                req.wait()
+            for p, buf in recv_bufs.items():
+                _unpack(x_ext, self._recv_idx[p], buf.to(x_local.device) if via_host else buf)
+            keep.clear()
+
+        return x_ext, finish
 
     def _peer(self, p):
         import torch.distributed as dist
@@ -215,12 +227,22 @@ class ShardedChebyshev:
         return p if self.group is None else dist.get_global_rank(self.group, p)
 
     def __call__(self, x_local):
-        x_ext = self.exchange(x_local)
         if self._compute is not None:
-            return self._compute(self.layout, x_ext, self.kernel)
-        y, self._workspace = _native.cheb_forward(self.plan, x_ext, self.kernel, self.bias, self.K, act=self.act,
-                                                  precision=self.precision, algo=self.algo,
-                                                  workspace=self._workspace)
+            return self._compute(self.layout, self.exchange(x_local), self.kernel)
         Fin = x_local.shape[2]
         self.fused = self.plan.fused_ok(Fin, int(self.kernel.shape[1]), self.K) and self.algo != _native.ALGO_UNFUSED
+        kw = dict(act=self.act, precision=self.precision, algo=self.algo)
+        if not self.fused or self.world == 1:
+            x_ext = self.exchange(x_local)
+            y, self._workspace = _native.cheb_forward(self.plan, x_ext, self.kernel, self.bias, self.K,
+                                                      workspace=self._workspace, **kw)
+            return y
+        # the tiles that read no halo row run while the halo rows are on the wire (RCCL works on its own stream),
+        # the boundary tiles after they have landed: the exchange hides behind the interior
+        x_ext, finish = self.exchange_start(x_local)
+        y, self._workspace = _native.cheb_forward(self.plan, x_ext, self.kernel, self.bias, self.K,
+                                                  workspace=self._workspace, part=_native.PART_INTERIOR, **kw)
+        finish()
+        y, self._workspace = _native.cheb_forward(self.plan, x_ext, self.kernel, self.bias, self.K,
+                                                  workspace=self._workspace, part=_native.PART_BOUNDARY, out=y, **kw)
         return y

@@ -114,6 +114,19 @@ int dsph_poly_forward(const dsph_plan* plan, const float* x, const float* w, con
                       int32_t act, int32_t precision, int32_t algo, void* workspace,
                       size_t workspace_bytes, void* hip_stream);
 
+/* The same forward restricted to a subset of the output tiles (fused kernel only; DSPH_E_UNSUPPORTED otherwise):
+ * DSPH_PART_INTERIOR = the 256-row tiles whose whole (K-1)-hop region lies inside the plan's output rows, i.e. on
+ * a sharded plan the tiles that read no halo row of another rank; DSPH_PART_BOUNDARY = the others.  Launching
+ * INTERIOR while the halo exchange is in flight and BOUNDARY after it hides the exchange behind the interior
+ * (deepsphere/sharding.py).  INTERIOR + BOUNDARY write exactly the rows DSPH_PART_ALL writes, with the same bits. */
+#define DSPH_PART_ALL 0
+#define DSPH_PART_INTERIOR 1
+#define DSPH_PART_BOUNDARY 2
+int dsph_poly_forward_part(const dsph_plan* plan, const float* x, const float* w, const float* bias,
+                           float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t basis,
+                           int32_t act, int32_t precision, int32_t algo, int32_t part, void* workspace,
+                           size_t workspace_bytes, void* hip_stream);
+
 /* One recurrence step on (N, n_cols, F) planes:  out = alpha * (L~ @ in) - beta * prev
  * for rows [0, rows) of every map (rows <= n_rows; rows <= 0 means n_rows); prev may be NULL
  * when beta == 0.  Replaces one utils.split_sparse_dense_matmul call plus the `2*... - x0`

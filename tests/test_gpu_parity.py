@@ -369,6 +369,20 @@ def test_sharded_plans_on_one_gpu(world, algo):
         assert tuple(y.shape) == (N, b - a, Fout)
         assert rel_err(y.cpu().numpy(), ref[:, a:b]) < TOL_FP32
         assert torch.equal(y, full[:, a:b]), "a shard must reproduce the unsharded rows bit for bit"
+        if algo == "fused":
+            # interior tiles (no halo row in their region) with the halo rows still garbage, boundary tiles after
+            # the halo has "arrived": what the overlapped exchange of ShardedChebyshev does
+            xl = _dev(x[:, lay.local_ids])
+            halo = xl[:, lay.n_own:].clone()
+            xl[:, lay.n_own:] = float("nan")
+            out = torch.full((N, b - a, Fout), float("nan"), device="cuda")
+            _native.cheb_forward(plan, xl, _dev(W), None, K, algo=a_code, part=_native.PART_INTERIOR, out=out)
+            torch.cuda.synchronize()
+            xl[:, lay.n_own:] = halo
+            _native.cheb_forward(plan, xl, _dev(W), None, K, algo=a_code, part=_native.PART_BOUNDARY, out=out)
+            assert torch.equal(out, y), "interior + boundary launches must equal the single launch bit for bit"
+            with pytest.raises(RuntimeError):
+                _native.cheb_forward(plan, xl, _dev(W), None, K, algo=_native.ALGO_UNFUSED, part=_native.PART_INTERIOR)
 
 
 def test_sharded_layer_world_one():
