@@ -195,6 +195,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # A sharded forward that cannot run (an exception on any rank during its first step, agreed on by all ranks)
+    # must not lose the measurement: fall back to independent replicas of the whole map and say so in the line.
+    replicas_note = None
+    if world > 1:
+        err = None
+        try:
+            if os.environ.get("DSPH_BENCH_FAIL_SHARD"):  # exercises the fallback below
+                raise RuntimeError("forced by DSPH_BENCH_FAIL_SHARD")
+            run()
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            err = repr(exc)
+        flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float32, device=device if args.backend == "nccl" else "cpu")
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = flag.item() > 0
+        except Exception as exc:  # noqa: BLE001
+            failed, err = True, err or repr(exc)
+        if failed:
+            replicas_note = f"replicas only: the sharded forward failed ({err or 'on another rank'})"
+            layer = gnn_layers.Chebyshev.from_prepared_ell(
+                cols, vals, K, lmax=lmax, Fout=Fout, device=device, precision=args.precision, algo=args.algo,
+                initializer=lambda t: t.copy_(torch.from_numpy(w_np)))
+            xr = torch.randn((N, M, Fin), device=device, generator=torch.Generator(device=device).manual_seed(11 + rank))
+
+            def run():  # noqa: F811
+                with torch.no_grad():
+                    return layer(xr)
+            fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
+            kernel_name = "cheb_fused_kernel" if fused else kernel_name
     for _ in range(args.warmup):
         run()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -213,11 +243,11 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = N * M * Fout / (elapsed / args.steps) / 1e6
+    value = N * M * Fout / (elapsed / args.steps) / 1e6 * (world if replicas_note else 1)
 
     if rank == 0:
         # per rank: its share of the map (the halo rows it also reads are not algorithmic bytes)
-        b_alg = algorithmic_bytes(N, M // world if world > 1 else M, Fin, Fout, K, W_ell)
+        b_alg = algorithmic_bytes(N, M // world if (world > 1 and not replicas_note) else M, Fin, Fout, K, W_ell)
         dev_ms = float(np.mean(per_fwd_ms))
         achieved = b_alg / (dev_ms * 1e-3) / 1e9
         traffic = None
@@ -238,7 +268,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if replicas_note else "strong",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else
             "f32 (recurrence f32; contraction 3-pass split-bf16 MFMA with f32 accumulate, max err 6e-6 of max|y|)",
@@ -249,7 +279,7 @@ def main():
                 "ell_width": W_ell,
                 "graph": "8-neighbour HEALPix grid stencil, normalised Laplacian, lmax by 64-step Lanczos",
                 "algo": "fused" if fused else "unfused",
-                "sharding": "none" if world == 1 else f"{world} contiguous NEST ranges, (K-1)-ring halo of x per step",
+                "sharding": "none" if world == 1 else (replicas_note or f"{world} contiguous NEST ranges, (K-1)-ring halo of x per step, exchange hidden behind the interior tiles"),
                 "setup_s": round(setup_s, 1),
             },
             "roofline": {
