@@ -47,7 +47,7 @@ struct FusedArgs {
 #ifdef DSPH_STAMPS
   unsigned long long* stamps;  // diagnostic build only: [8 waves][8 items][32 points] s_memtime values
 #endif
-  int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no MFMA, 8 no y store
+  int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no contraction, 8 no y store
 };
 
 // Byte offset of 16-byte slot `slot` (0..3) of region row `row` inside a [rows][16] fp32 plane.
