@@ -471,8 +471,12 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   args.alpha_rest = alpha_rest;
   args.beta_rest = beta_rest;
   args.wfrag_bytes = (int)wb;
+#ifdef DSPH_ABLATE  // diagnostic build only (make ABLATE=1): the shipped library never skips work
   const char* dbg = getenv("DSPH_FUSED_DEBUG");
   args.dbg = dbg ? atoi(dbg) : 0;
+#else
+  args.dbg = 0;
+#endif
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wb;
   const int grid = wgrad_mode ? fused_grid(plan, ft) : fused_grid(plan, ft, args.ntiles);

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a diagnostic library: make -C deepsphere-cosmo-tf2_amd/csrc clean && make -C deepsphere-cosmo-tf2_amd/csrc -j8 ABLATE=1
 # timing-only ablations of the fused kernel (outputs are wrong when a bit is set)
 for d in 0 1 2 3 8 9 10 11; do  # bits: 1 no recurrence, 2 no contraction, 8 no y store
   echo -n "dbg=$d  "

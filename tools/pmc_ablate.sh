@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a diagnostic library: make -C deepsphere-cosmo-tf2_amd/csrc clean && make -C deepsphere-cosmo-tf2_amd/csrc -j8 ABLATE=1
 # instruction counts of the fused kernel per ablation build (outputs are wrong when a bit is set)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
