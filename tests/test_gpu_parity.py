@@ -656,3 +656,23 @@ def test_fuzz_fused_against_unfused():
                          text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "ALL OK" in res.stdout
+
+
+def test_backward_weights_many_tiles_per_workgroup():
+    """BASELINE config 2 size (nside 256, 3072 tiles, 12 per workgroup, batch 8): the weight gradient accumulated over
+    many tiles and maps inside one workgroup (fused) against the planes + wgrad route, and dx against the same."""
+    import bench
+
+    dev = torch.device("cuda", 0)
+    cols, vals, _ = bench.build_laplacian(256, dev)
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    M, K, Fin, Fout, N = cols.shape[0], 5, 16, 32, 8
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn((N, M, Fin), device=dev, generator=g)
+    dy = torch.randn((N, M, Fout), device=dev, generator=g)
+    ref, _ = _native.cheb_backward_weights(plan, x, dy, K, algo=_native.ALGO_UNFUSED)
+    for prec, tol in ((_native.PREC_FP32, 2e-5), (_native.PREC_BF16X3, TOL_BF16X3)):
+        dw, _ = _native.cheb_backward_weights(plan, x, dy, K, algo=_native.ALGO_FUSED, precision=prec)
+        err = float((dw - ref).abs().max() / ref.abs().max())
+        print(f"dW nside 256 prec {prec}: rel diff fused vs unfused {err:.2e}")
+        assert err < tol
