@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "cheb_fused_kernel.h"
+#include "cheb_struct_kernel.h"
 
 namespace dsph {
 
@@ -54,14 +55,23 @@ struct FusedTiles {
   // of another rank) and the rest ("boundary"); positions [0, n_interior) and [n_interior, ntiles) of d_part
   int32_t* d_part = nullptr;
   int n_interior = 0;
+  int n_part = 0;      // entries of d_part: all tiles of a full table, the class-G tiles otherwise
+  // class-R tiles (cheb_struct_kernel.h), interior ones first; empty in a full table
+  int32_t* d_rlist = nullptr;
+  int n_r = 0, n_r_interior = 0;
 };
 
 struct FusedPlan {
   std::vector<int32_t> h_cols;  // host copy of the ELL (needed to build tiles for a new K)
   std::vector<float> h_vals;
   std::mutex mu;
-  std::map<int, FusedTiles> by_depth;
+  std::map<int, FusedTiles> by_depth;  // key: 2 * depth + (1: BFS tables of every tile, 0: of the class-G tiles only)
   int num_cu = 256;
+  // direction-ordered copy of L~ and the per-row regularity flags (cheb_struct.hip), built on first use
+  float* d_gvals8 = nullptr;
+  float* d_gdiag = nullptr;
+  unsigned char* d_rowflag = nullptr;
+  bool rows_tried = false;
 };
 
 static int template_width(int w) {
@@ -78,6 +88,7 @@ static void free_tiles(FusedTiles& ft) {
   if (ft.d_lcols) (void)hipFree(ft.d_lcols);
   if (ft.d_lvals) (void)hipFree(ft.d_lvals);
   if (ft.d_part) (void)hipFree(ft.d_part);
+  if (ft.d_rlist) (void)hipFree(ft.d_rlist);
   ft = FusedTiles();
 }
 
@@ -96,6 +107,9 @@ FusedPlan* fused_plan_build(const dsph_plan* plan, const int32_t* h_cols, const 
 void fused_plan_destroy(FusedPlan* fp) {
   if (!fp) return;
   for (auto& kv : fp->by_depth) free_tiles(kv.second);
+  if (fp->d_gvals8) (void)hipFree(fp->d_gvals8);
+  if (fp->d_gdiag) (void)hipFree(fp->d_gdiag);
+  if (fp->d_rowflag) (void)hipFree(fp->d_rowflag);
   delete fp;
 }
 
@@ -108,12 +122,16 @@ void fused_plan_invalidate(FusedPlan* fp) {
 }
 
 // Breadth-first rings of every tile; uploads the tables.  Returns a reference to the cached entry.
-static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
+// full: BFS tables of every tile (planes / weight-gradient modes of the BFS kernel); otherwise the tiles are first
+// classified and only the class-G ones (not a plain 2-D stencil square) get BFS tables, the rest go to d_rlist.
+static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = false) {
   FusedPlan* fp = plan->fused;
   std::lock_guard<std::mutex> lock(fp->mu);
-  auto it = fp->by_depth.find(D);
+  DeviceGuard guard(plan->device);  // tables live on the plan's device, whatever the caller's current one is
+  const int key = 2 * D + (full ? 1 : 0);
+  auto it = fp->by_depth.find(key);
   if (it != fp->by_depth.end()) return it->second;
-  FusedTiles& ft = fp->by_depth[D];
+  FusedTiles& ft = fp->by_depth[key];
   ft.D = D;
   ft.width = template_width(plan->width);
   const int W = plan->width, WT = ft.width;
@@ -131,7 +149,22 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
   std::vector<uint16_t> lcols;
   std::vector<float> lvals;
   region.reserve((size_t)ntiles * 600);
-  std::vector<int32_t> ring, next, interior, boundary;
+  std::vector<int32_t> ring, next, interior, boundary, r_interior, r_boundary;
+  std::vector<unsigned char> cls((size_t)ntiles, 0);
+  if (!full && D <= ST_DMAX && getenv("DSPH_NO_STRUCT") == nullptr) {
+    if (!fp->rows_tried) {
+      fp->rows_tried = true;
+      if (struct_build_rows(plan, &fp->d_gvals8, &fp->d_gdiag, &fp->d_rowflag) != DSPH_OK) {
+        if (fp->d_gvals8) (void)hipFree(fp->d_gvals8);
+        if (fp->d_gdiag) (void)hipFree(fp->d_gdiag);
+        if (fp->d_rowflag) (void)hipFree(fp->d_rowflag);
+        fp->d_gvals8 = fp->d_gdiag = nullptr;
+        fp->d_rowflag = nullptr;
+      }
+    }
+    if (fp->d_rowflag && struct_classify_tiles(plan, fp->d_rowflag, ntiles, D, out_rows, cls.data()) != DSPH_OK)
+      std::fill(cls.begin(), cls.end(), 0);
+  }
   int rmax = 0, emax = 0;
   int64_t ell_rows = 0;
   for (int t = 0; t < ntiles; ++t) {
@@ -139,6 +172,11 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
     const size_t base = region.size();
     if (base > 0x7fffffffULL - 70000) return ft;  // offsets are int32
     tile_off[t] = (int32_t)base;
+    if (cls[t] & 1) {  // class R: no BFS tables
+      ((cls[t] & 2) ? r_interior : r_boundary).push_back(t);
+      ell_off[t] = ell_rows;
+      continue;
+    }
     ring.clear();
     for (int64_t r = r0; r < r1; ++r) {
       stamp[r] = t;
@@ -241,14 +279,20 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D) {
   if (lcols.empty()) { lcols.push_back(0); lvals.push_back(0.f); }
   ft.n_interior = (int)interior.size();
   interior.insert(interior.end(), boundary.begin(), boundary.end());
+  ft.n_part = (int)interior.size();
   if (interior.empty()) interior.push_back(0);
+  ft.n_r_interior = (int)r_interior.size();
+  r_interior.insert(r_interior.end(), r_boundary.begin(), r_boundary.end());
+  ft.n_r = (int)r_interior.size();
+  if (r_interior.empty()) r_interior.push_back(0);
   bool good = up((void**)&ft.d_tile_off, tile_off.data(), tile_off.size() * 4) &&
               up((void**)&ft.d_ring_end, ring_end.data(), ring_end.size() * 4) &&
               up((void**)&ft.d_ell_off, ell_off.data(), ell_off.size() * 8) &&
               up((void**)&ft.d_region, region.data(), region.size() * 4) &&
               up((void**)&ft.d_lcols, lcols.data(), lcols.size() * 2) &&
               up((void**)&ft.d_lvals, lvals.data(), lvals.size() * 4) &&
-              up((void**)&ft.d_part, interior.data(), interior.size() * 4);
+              up((void**)&ft.d_part, interior.data(), interior.size() * 4) &&
+              up((void**)&ft.d_rlist, r_interior.data(), r_interior.size() * 4);
   if (!good) {
     FusedTiles keep = ft;
     free_tiles(ft);
@@ -272,20 +316,37 @@ static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
   return (size_t)K * C * NB * 2048;
 }
 
-bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
+static bool supported_impl(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K, bool full) {
   if (!plan->fused) return false;
   if (K < 2 || K - 1 > FUSED_DMAX) return false;
   if (Fin % 4 != 0 || Fin < 4 || Fout < 1) return false;  // Fout > 64: one launch per 64-column block
-  const FusedTiles& ft = get_tiles(plan, K - 1);
+  const FusedTiles& ft = get_tiles(plan, K - 1, full);
   if (!ft.ok) return false;
+  if (ft.n_r > 0 && !struct_shape_ok(Fin, std::min(Fout, 64), K)) return false;
+  if (ft.n_part == 0) return true;  // every tile is class R
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   if (pr == 0) return false;
   const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wfrag_bytes(Fin, std::min(Fout, 64), K) + FUSED_BIAS_BYTES;
   return lds <= (size_t)LDS_BYTES;
 }
 
+bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
+  return supported_impl(plan, Fin, Fout, K, false);
+}
+
+// tiles of the K-term forward by kernel: class R (structured-tile kernel) and class G (BFS-tile kernel)
+bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs) {
+  if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return false;
+  const FusedTiles& ft = get_tiles(plan, K - 1, false);
+  if (!ft.ok) return false;
+  *n_struct = ft.n_r;
+  *n_bfs = ft.n_part;
+  return true;
+}
+
+// two fragment layouts: the BFS-tile kernel's and, behind it, the structured-tile kernel's
 size_t fused_workspace_bytes(const dsph_plan*, int64_t, int32_t Fin, int32_t Fout, int32_t K, int32_t) {
-  return wfrag_bytes(Fin, std::min(Fout, 64), K);
+  return wfrag_bytes(Fin, std::min(Fout, 64), K) + struct_wfrag_bytes(Fin, std::min(Fout, 64), K);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -338,7 +399,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
 }
 
 // Planes mode of the same kernel: T_1 .. T_{K-1} of x, each (N, n_cols, Fin), valid on the plan's output rows.
-bool fused_planes_supported(const dsph_plan* plan, int32_t Fin, int32_t K) { return fused_supported(plan, Fin, 1, K); }
+bool fused_planes_supported(const dsph_plan* plan, int32_t Fin, int32_t K) { return supported_impl(plan, Fin, 1, K, true); }
 
 int launch_cheb_fused_planes(const dsph_plan* plan, const float* x, float* planes_out, int64_t N, int32_t Fin,
                              int32_t K, float alpha_rest, float beta_rest, hipStream_t stream) {
@@ -354,7 +415,7 @@ static int fused_grid(const dsph_plan* plan, const FusedTiles& ft, int ntiles = 
 
 // slices per launch: as many accumulator tiles (one per slice and order, 8 KiB each) as fit the LDS next to the planes
 static int wgrad_slices_per_launch(const dsph_plan* plan, int32_t K) {
-  const FusedTiles& ft = get_tiles(plan, K - 1);
+  const FusedTiles& ft = get_tiles(plan, K - 1, true);
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   if (pr == 0) return 0;
   const long freeb = (long)LDS_BYTES - 2L * pr * FUSED_CH * 4;
@@ -362,12 +423,12 @@ static int wgrad_slices_per_launch(const dsph_plan* plan, int32_t K) {
 }
 
 bool fused_wgrad_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
-  return fused_supported(plan, Fin, Fout, K) && wgrad_slices_per_launch(plan, K) >= 1;
+  return supported_impl(plan, Fin, Fout, K, true) && wgrad_slices_per_launch(plan, K) >= 1;
 }
 
 size_t fused_wgrad_workspace_bytes(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
   if (!fused_wgrad_supported(plan, Fin, Fout, K)) return 0;
-  const FusedTiles& ft = get_tiles(plan, K - 1);
+  const FusedTiles& ft = get_tiles(plan, K - 1, true);
   const int C = (Fin + FUSED_CH - 1) / FUSED_CH;
   return (size_t)2 * fused_grid(plan, ft) * C * K * 16 * 64 * sizeof(float);
 }
@@ -412,16 +473,17 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                void* workspace, size_t workspace_bytes, hipStream_t stream, const float* dy,
                                float* dw, int32_t ld, int32_t part) {
   if (ld <= 0) ld = Fout;  // row stride of w, bias-less y / dy / dw: the layer's Fout when this is one column block
-  if (!fused_supported(plan, Fin, Fout, K)) {
+  const bool wgrad_mode = dy != nullptr;  // y then carries the slab workspace
+  const bool planes_mode = planes_out != nullptr || wgrad_mode;
+  if (!supported_impl(plan, Fin, Fout, K, planes_mode)) {
     set_error("cheb_fused: plan/shape not supported");
     return DSPH_E_UNSUPPORTED;
   }
-  const bool wgrad_mode = dy != nullptr;  // y then carries the slab workspace
-  const bool planes_mode = planes_out != nullptr || wgrad_mode;
-  const FusedTiles& ft = get_tiles(plan, K - 1);
+  const FusedTiles& ft = get_tiles(plan, K - 1, planes_mode);
   const size_t wb = planes_mode ? 0 : wfrag_bytes(Fin, Fout, K);
-  if (!planes_mode && (!workspace || workspace_bytes < wb)) {
-    set_error("cheb_fused: workspace %zu < %zu", workspace_bytes, wb);
+  const size_t wb_all = planes_mode ? 0 : wb + struct_wfrag_bytes(Fin, Fout, K);
+  if (!planes_mode && (!workspace || workspace_bytes < wb_all)) {
+    set_error("cheb_fused: workspace %zu < %zu", workspace_bytes, wb_all);
     return DSPH_E_WORKSPACE;
   }
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15) ||
@@ -430,6 +492,29 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     return DSPH_E_BADARG;
   }
   const int C = (Fin + FUSED_CH - 1) / FUSED_CH, NB = (Fout + 31) / 32;
+  // ---- class-R tiles: the structured-tile kernel (forward only) ------------------------------------------------
+  if (!planes_mode && ft.n_r > 0) {
+    const int nr = part == 0 ? ft.n_r : (part == 1 ? ft.n_r_interior : ft.n_r - ft.n_r_interior);
+    if (nr > 0) {
+      StructLaunch sl;
+      sl.x = x; sl.w = w; sl.bias = bias; sl.y = y;
+      sl.wfrag = static_cast<unsigned char*>(workspace) + wb;
+      sl.tiles = part == 2 ? ft.d_rlist + ft.n_r_interior : ft.d_rlist;
+      sl.gvals8 = plan->fused->d_gvals8;
+      sl.gdiag = plan->fused->d_gdiag;
+      sl.x_rows = plan->n_cols;
+      sl.y_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
+      sl.N = N;
+      sl.ntiles = nr;
+      sl.Fin = Fin; sl.Fout = Fout; sl.K = K; sl.act = act; sl.precision = precision; sl.ld = ld;
+      sl.num_cu = plan->fused->num_cu;
+      sl.cheb = beta_rest != 0.f;
+      const int rc = launch_cheb_struct(sl, stream);
+      if (rc != DSPH_OK) return rc;
+    }
+    const int ng = part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior);
+    if (ng == 0) return DSPH_OK;
+  }
   if (!planes_mode) {
     hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,
                        static_cast<unsigned char*>(workspace), (int)Fin, (int)Fout, (int)K, C, NB,
@@ -463,8 +548,9 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   args.ld = ld;
   args.K = K;
   // part: 0 all tiles, 1 interior tiles (no row of another rank in their region), 2 boundary tiles
-  args.tile_list = part == 0 ? nullptr : (part == 1 ? ft.d_part : ft.d_part + ft.n_interior);
-  args.ntiles = part == 0 ? ft.ntiles : (part == 1 ? ft.n_interior : ft.ntiles - ft.n_interior);
+  // the BFS-tile kernel handles the tiles of d_part (every tile of a full table, the class-G ones otherwise)
+  args.tile_list = part == 0 ? (ft.n_part == ft.ntiles ? nullptr : ft.d_part) : (part == 1 ? ft.d_part : ft.d_part + ft.n_interior);
+  args.ntiles = part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior);
   if (args.ntiles == 0) return DSPH_OK;
   args.nchunks = C;
   args.act = act;

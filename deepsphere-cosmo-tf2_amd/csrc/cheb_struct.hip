@@ -1,0 +1,170 @@
+// Host side of the structured-tile kernel (cheb_struct_kernel.h): verification of the 2-D stencil structure of
+// L~ per row and per tile, the direction-ordered copy of its values, weight preparation and the launch.
+//
+// Nothing here assumes HEALPix: a row is "regular" when, reading row and column indices as Morton codes
+// (x = even bits, y = odd bits), every non-zero of the row lies within +-1 of the row in both coordinates and no
+// direction occurs twice; a 256-row tile is "class R" for depth D when its own rows and the cells of its rings
+// 1..D-1 exist and are regular and the cells of ring D exist as columns.  HEALPix NEST maps (and any other map
+// stored in Z-order) satisfy this away from base-pixel borders; everything else goes to the BFS-tile kernel.
+#include "cheb_struct_kernel.h"
+
+namespace dsph {
+
+// canonical direction index (0 = the row itself, 1..8 = kDirX / kDirY order) by (dy + 1) * 3 + (dx + 1)
+__device__ constexpr int kDirIndex[9] = {8, 7, 6, 1, 0, 5, 2, 3, 4};
+
+// One thread per row of L~: gdiag[r], gvals8[r][8] and flag[r] (1 = regular).  Rows r >= n_rows (columns that
+// are not rows of this plan: halo rows of a shard) get zeros and flag 0.
+__global__ __launch_bounds__(256) void struct_rows_kernel(const int32_t* __restrict__ cols, const float* __restrict__ vals,
+                                                          int W, int64_t n_rows, int64_t n_cols,
+                                                          float* __restrict__ gvals8, float* __restrict__ gdiag,
+                                                          unsigned char* __restrict__ flag) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_cols) return;
+  float out[9];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) out[d] = 0.f;
+  bool ok = r < n_rows;
+  if (ok) {
+    const int X = (int)st_compress((unsigned)r), Y = (int)st_compress((unsigned)r >> 1);
+    unsigned used = 0;
+    for (int j = 0; j < W; ++j) {
+      const float v = vals[r * W + j];
+      if (v == 0.f) continue;
+      const unsigned c = (unsigned)cols[r * W + j];
+      const int dx = (int)st_compress(c) - X, dy = (int)st_compress(c >> 1) - Y;
+      if (dx < -1 || dx > 1 || dy < -1 || dy > 1) { ok = false; continue; }
+      const int d = kDirIndex[(dy + 1) * 3 + (dx + 1)];
+      if (used & (1u << d)) ok = false;
+      used |= 1u << d;
+#pragma unroll
+      for (int e = 0; e < 9; ++e)
+        if (e == d) out[e] = v;
+    }
+  }
+  gdiag[r] = out[0];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) gvals8[r * 8 + d] = out[d + 1];
+  flag[r] = ok ? 1 : 0;
+}
+
+// One thread per 256-row tile: cls[t] bit 0 = class R for depth D, bit 1 = interior (every region cell is an
+// output row of the plan, i.e. no halo row of another rank is read).
+__global__ __launch_bounds__(256) void struct_tiles_kernel(const unsigned char* __restrict__ flag, int ntiles, int D,
+                                                           int64_t n_rows, int64_t n_cols, int64_t out_rows,
+                                                           unsigned char* __restrict__ cls) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  const int64_t row0 = (int64_t)t * 256;
+  bool ok = D >= 1 && D <= ST_DMAX && row0 + 256 <= out_rows && row0 + 256 <= 0xffffffffLL;
+  bool interior = true;
+  if (ok) {
+    const int X0 = (int)st_compress((unsigned)row0), Y0 = (int)st_compress((unsigned)row0 >> 1);
+    if (X0 - D < 0 || Y0 - D < 0 || X0 + ST_TILE + D > 65535 || Y0 + ST_TILE + D > 65535) ok = false;
+    for (int gy = -D; ok && gy < ST_TILE + D; ++gy)
+      for (int gx = -D; gx < ST_TILE + D; ++gx) {
+        const int ring = max(max(-gx, gx - (ST_TILE - 1)), max(max(-gy, gy - (ST_TILE - 1)), 0));
+        const int64_t rid = (int64_t)st_morton((unsigned)(X0 + gx), (unsigned)(Y0 + gy));
+        if (rid >= n_cols) { ok = false; break; }
+        if (ring < D && (rid >= n_rows || !flag[rid])) { ok = false; break; }
+        if (rid >= out_rows) interior = false;
+      }
+  }
+  cls[t] = (ok ? 1 : 0) | (interior ? 2 : 0);
+}
+
+// Weight fragments of the structured kernel, one 2 KiB block per (slice c, order k, column block nb), a slice
+// contiguous (it is streamed into LDS as one piece):
+//   bf16x3: lane l, element j <- w[(c*16 + 8*(l>>5) + j)*K + k][32*nb + (l&31)], hi at +0, lo at +1024
+//   fp32  : lane l, half e, i <- w[(c*16 + 8*(l>>5) + 4e + i)*K + k][32*nb + (l&31)] at e*1024 + l*16 + 4i
+__global__ __launch_bounds__(256) void struct_wprep_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
+                                                           int Fin, int Fout, int K, int C, int NB, int prec, int ld) {
+  const int blk = blockIdx.x;  // (c*K + k)*NB + nb
+  const int nb = blk % NB, k = (blk / NB) % K, c = blk / (NB * K);
+  unsigned char* base = out + (size_t)blk * 2048;
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int l = e >> 3, j = e & 7;
+    const int ch = c * 16 + 8 * (l >> 5) + j, col = 32 * nb + (l & 31);
+    const float v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
+    if (prec == DSPH_PREC_BF16X3) {
+      const __bf16 hi = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)hi);
+      reinterpret_cast<__bf16*>(base)[l * 8 + j] = hi;
+      reinterpret_cast<__bf16*>(base + 1024)[l * 8 + j] = lo;
+    } else {
+      reinterpret_cast<float*>(base + (j >> 2) * 1024)[l * 4 + (j & 3)] = v;
+    }
+  }
+}
+
+int struct_build_rows(const dsph_plan* plan, float** gvals8, float** gdiag, unsigned char** flag) {
+  const int64_t n = plan->n_cols;
+  DSPH_HIP(hipMalloc((void**)gvals8, (size_t)n * 8 * sizeof(float)));
+  DSPH_HIP(hipMalloc((void**)gdiag, (size_t)n * sizeof(float)));
+  DSPH_HIP(hipMalloc((void**)flag, (size_t)n));
+  hipLaunchKernelGGL(struct_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, plan->d_cols, plan->d_vals,
+                     (int)plan->width, plan->n_rows, plan->n_cols, *gvals8, *gdiag, *flag);
+  DSPH_HIP(hipGetLastError());
+  DSPH_HIP(hipDeviceSynchronize());
+  return DSPH_OK;
+}
+
+// cls (host, ntiles bytes) <- classification of every 256-row tile for depth D
+int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, int ntiles, int D, int64_t out_rows,
+                          unsigned char* h_cls) {
+  unsigned char* d_cls = nullptr;
+  DSPH_HIP(hipMalloc((void**)&d_cls, (size_t)ntiles));
+  hipLaunchKernelGGL(struct_tiles_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, 0, d_flag, ntiles, D, plan->n_rows,
+                     plan->n_cols, out_rows, d_cls);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(h_cls, d_cls, (size_t)ntiles, hipMemcpyDeviceToHost);
+  (void)hipFree(d_cls);
+  if (e != hipSuccess) return hip_fail(e, "struct_classify_tiles");
+  return DSPH_OK;
+}
+
+bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K) {
+  const int NB = (Fout + 31) / 32;
+  return K >= 2 && K - 1 <= ST_DMAX && Fin >= 4 && Fin % 4 == 0 && Fout >= 1 && Fout <= 64 &&
+         K * NB * 2048 <= ST_WSLICE_BYTES;
+}
+
+size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
+  const int C = (Fin + 15) / 16, NB = (Fout + 31) / 32;
+  return (size_t)C * K * NB * 2048;
+}
+
+int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
+  const int C = (s.Fin + 15) / 16, NB = (s.Fout + 31) / 32;
+  hipLaunchKernelGGL(struct_wprep_kernel, dim3(C * s.K * NB), dim3(256), 0, stream, s.w, s.wfrag, (int)s.Fin, (int)s.Fout,
+                     (int)s.K, C, NB, (int)s.precision, (int)s.ld);
+  DSPH_HIP(hipGetLastError());
+  StructArgs a;
+  a.x = s.x;
+  a.bias = s.bias;
+  a.y = s.y;
+  a.wfrag = s.wfrag;
+  a.tiles = s.tiles;
+  a.gvals8 = s.gvals8;
+  a.gdiag = s.gdiag;
+  a.x_rows = s.x_rows;
+  a.y_rows = s.y_rows;
+  a.ntiles = s.ntiles;
+  a.N = (int)s.N;
+  a.Fin = s.Fin;
+  a.Fout = s.Fout;
+  a.K = s.K;
+  a.C = C;
+  a.act = s.act;
+  a.ld = s.ld;
+  a.cheb = s.cheb ? 1 : 0;
+  const int grid = std::max(8, std::min(s.num_cu, (s.ntiles + 7) / 8 * 8));
+  void (*kern)(StructArgs) = nullptr;
+  if (s.precision == DSPH_PREC_BF16X3) kern = NB == 1 ? cheb_struct_kernel<1, DSPH_PREC_BF16X3> : cheb_struct_kernel<2, DSPH_PREC_BF16X3>;
+  else kern = NB == 1 ? cheb_struct_kernel<1, DSPH_PREC_FP32> : cheb_struct_kernel<2, DSPH_PREC_FP32>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), 0, stream, a);
+  DSPH_HIP(hipGetLastError());
+  return DSPH_OK;
+}
+
+}  // namespace dsph

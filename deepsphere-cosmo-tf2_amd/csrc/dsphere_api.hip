@@ -23,19 +23,6 @@ int hip_fail(hipError_t e, const char* what) {
   return DSPH_E_HIP;
 }
 
-// RAII device switch: plans may live on a device other than the caller's current one.
-struct DeviceGuard {
-  int prev = -1;
-  bool ok = true;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
-    if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
-  }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
-
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int64_t step_rows(const dsph_plan* p, int K, int k) {
@@ -141,6 +128,13 @@ int64_t dsph_plan_out_rows(const dsph_plan* p, int32_t K) { (void)K; return p ? 
 
 int dsph_plan_fused_ok(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K) {
   return (p && fused_supported(p, Fin, Fout, K)) ? 1 : 0;
+}
+
+int dsph_plan_tile_counts(const dsph_plan* p, int32_t K, int64_t* n_struct, int64_t* n_bfs) {
+  if (!p || !n_struct || !n_bfs) { set_error("plan_tile_counts: NULL argument"); return DSPH_E_BADARG; }
+  *n_struct = *n_bfs = 0;
+  if (!fused_tile_counts(p, K, n_struct, n_bfs)) { set_error("plan_tile_counts: the fused kernels cannot run this plan with K = %d", K); return DSPH_E_UNSUPPORTED; }
+  return DSPH_OK;
 }
 
 static int resolve_algo(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo) {

@@ -20,6 +20,19 @@ int hip_fail(hipError_t e, const char* what);
     if (e__ != hipSuccess) return ::dsph::hip_fail(e__, #call);  \
   } while (0)
 
+// RAII device switch: plans may live on a device other than the caller's current one.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 struct FusedPlan;  // tile decomposition for the single-launch kernel (cheb_fused.hip)
 
 }  // namespace dsph
@@ -61,6 +74,7 @@ FusedPlan* fused_plan_build(const dsph_plan* plan, const int32_t* h_cols, const 
 void fused_plan_destroy(FusedPlan* fp);
 void fused_plan_invalidate(FusedPlan* fp);
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
+bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,
@@ -75,6 +89,23 @@ int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* 
                             void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                              int32_t precision);
+
+// structured-tile kernel (cheb_struct.hip)
+struct StructLaunch {
+  const float* x; const float* w; const float* bias; float* y;
+  unsigned char* wfrag;      // workspace: struct_wfrag_bytes()
+  const int32_t* tiles;      // device list of class-R tiles
+  const float* gvals8; const float* gdiag;
+  int64_t x_rows, y_rows, N;
+  int32_t ntiles, Fin, Fout, K, act, precision, ld, num_cu;
+  bool cheb;
+};
+int struct_build_rows(const dsph_plan* plan, float** gvals8, float** gdiag, unsigned char** flag);
+int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, int ntiles, int D, int64_t out_rows,
+                          unsigned char* h_cls);
+bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
+size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K);
+int launch_cheb_struct(const StructLaunch& s, hipStream_t stream);
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {

@@ -36,6 +36,7 @@ SIGNATURES = {
     "dsph_plan_ell_width": (_c_i32, [_c_vp]),
     "dsph_plan_out_rows": (_c_i64, [_c_vp, _c_i32]),
     "dsph_plan_fused_ok": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
+    "dsph_plan_tile_counts": (ctypes.c_int, [_c_vp, _c_i32, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
     "dsph_workspace_bytes": (ctypes.c_size_t, [_c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32]),
     "dsph_cheb_forward": (
         ctypes.c_int,
@@ -168,6 +169,12 @@ class LaplacianPlan:
 
     def fused_ok(self, Fin, Fout, K):
         return bool(lib().dsph_plan_fused_ok(self.handle, int(Fin), int(Fout), int(K)))
+
+    def tile_counts(self, K):
+        """(tiles run by the structured-tile kernel, tiles run by the BFS-tile kernel) of a K-term fused forward."""
+        a, b = _c_i64(0), _c_i64(0)
+        check(lib().dsph_plan_tile_counts(self.handle, int(K), ctypes.byref(a), ctypes.byref(b)), "dsph_plan_tile_counts")
+        return int(a.value), int(b.value)
 
     def workspace_bytes(self, N, Fin, Fout, K, precision=PREC_FP32, algo=ALGO_AUTO):
         return int(lib().dsph_workspace_bytes(self.handle, int(N), int(Fin), int(Fout), int(K), int(precision),

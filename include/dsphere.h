@@ -87,6 +87,12 @@ int64_t dsph_plan_out_rows(const dsph_plan* plan, int32_t K); /* rows y is produ
 /* 1 if the fused single-launch kernel can run this (plan, shape); 0 otherwise */
 int dsph_plan_fused_ok(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 
+/* How the fused forward with K terms splits the plan's 256-row tiles between its two kernels: *n_struct tiles whose
+ * (K-1)-ring region was verified to be a plain square of a 2-D 9-point stencil in Z-order (structured-tile kernel,
+ * csrc/cheb_struct_kernel.h) and *n_bfs tiles handled through breadth-first ring tables (csrc/cheb_fused_kernel.h).
+ * DSPH_E_UNSUPPORTED when neither kernel can run the plan (the unfused path then serves dsph_cheb_forward). */
+int dsph_plan_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
+
 /* Bytes of scratch dsph_cheb_forward needs for this call shape (0 is possible). */
 size_t dsph_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout,
                             int32_t K, int32_t precision, int32_t algo);
