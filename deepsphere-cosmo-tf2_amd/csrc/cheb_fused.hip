@@ -316,7 +316,13 @@ static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
   return (size_t)K * C * NB * 2048;
 }
 
+// The structured-tile kernel addresses x by 32-bit byte offsets inside a map: larger maps take BFS tables throughout.
+static bool want_full(const dsph_plan* plan, int32_t Fin, bool full) {
+  return full || (uint64_t)plan->n_cols * (uint64_t)Fin * 4ull >= (1ull << 32);
+}
+
 static bool supported_impl(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K, bool full) {
+  full = want_full(plan, Fin, full);
   if (!plan->fused) return false;
   if (K < 2 || K - 1 > FUSED_DMAX) return false;
   if (Fin % 4 != 0 || Fin < 4 || Fout < 1) return false;  // Fout > 64: one launch per 64-column block
@@ -479,7 +485,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     set_error("cheb_fused: plan/shape not supported");
     return DSPH_E_UNSUPPORTED;
   }
-  const FusedTiles& ft = get_tiles(plan, K - 1, planes_mode);
+  const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, planes_mode));
   const size_t wb = planes_mode ? 0 : wfrag_bytes(Fin, Fout, K);
   const size_t wb_all = planes_mode ? 0 : wb + struct_wfrag_bytes(Fin, Fout, K);
   if (!planes_mode && (!workspace || workspace_bytes < wb_all)) {

@@ -6,6 +6,12 @@
 // direction occurs twice; a 256-row tile is "class R" for depth D when its own rows and the cells of its rings
 // 1..D-1 exist and are regular and the cells of ring D exist as columns.  HEALPix NEST maps (and any other map
 // stored in Z-order) satisfy this away from base-pixel borders; everything else goes to the BFS-tile kernel.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
 #include "cheb_struct_kernel.h"
 
 namespace dsph {
@@ -123,6 +129,7 @@ int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, in
   return DSPH_OK;
 }
 
+// (the kernel addresses x by 32-bit byte offsets inside a map: struct_map_ok())
 bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K) {
   const int NB = (Fout + 31) / 32;
   return K >= 2 && K - 1 <= ST_DMAX && Fin >= 4 && Fin % 4 == 0 && Fout >= 1 && Fout <= 64 &&
@@ -157,13 +164,34 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   a.C = C;
   a.act = s.act;
   a.ld = s.ld;
-  a.cheb = s.cheb ? 1 : 0;
   const int grid = std::max(8, std::min(s.num_cu, (s.ntiles + 7) / 8 * 8));
+#ifdef DSPH_STAMPS
+  static unsigned long long* d_stamps = nullptr;
+  constexpr size_t NST = 8 * 8 * 32;
+  if (!d_stamps) DSPH_HIP(hipMalloc(&d_stamps, NST * 8));
+  DSPH_HIP(hipMemsetAsync(d_stamps, 0, NST * 8, stream));
+  a.stamps = d_stamps;
+#endif
   void (*kern)(StructArgs) = nullptr;
-  if (s.precision == DSPH_PREC_BF16X3) kern = NB == 1 ? cheb_struct_kernel<1, DSPH_PREC_BF16X3> : cheb_struct_kernel<2, DSPH_PREC_BF16X3>;
-  else kern = NB == 1 ? cheb_struct_kernel<1, DSPH_PREC_FP32> : cheb_struct_kernel<2, DSPH_PREC_FP32>;
+#define DSPH_ST_PICK(P, CH) (NB == 1 ? cheb_struct_kernel<1, P, CH> : cheb_struct_kernel<2, P, CH>)
+  if (s.precision == DSPH_PREC_BF16X3) kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_BF16X3, true) : DSPH_ST_PICK(DSPH_PREC_BF16X3, false);
+  else kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_FP32, true) : DSPH_ST_PICK(DSPH_PREC_FP32, false);
+#undef DSPH_ST_PICK
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), 0, stream, a);
   DSPH_HIP(hipGetLastError());
+#ifdef DSPH_STAMPS
+  if (getenv("DSPH_STAMPS_DUMP")) {
+    std::vector<unsigned long long> h(NST);
+    if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(h.data(), d_stamps, NST * 8, hipMemcpyDeviceToHost) == hipSuccess)
+      for (int w = 0; w < 8; ++w)
+        for (int it = 0; it < 8; ++it) {
+          fprintf(stderr, "STSTAMP wave %d item %d:", w, it + 4);
+          const unsigned long long* r = &h[((size_t)w * 8 + it) * 32];
+          for (int i = 1; i < 18; ++i) fprintf(stderr, " %lld", r[i] && r[i - 1] ? (long long)(r[i] - r[i - 1]) : -1LL);
+          fprintf(stderr, " | t0 %llu\n", r[0]);
+        }
+  }
+#endif
   return DSPH_OK;
 }
 

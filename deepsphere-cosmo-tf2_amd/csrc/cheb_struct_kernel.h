@@ -63,8 +63,27 @@ struct StructArgs {
   const float* gdiag;          // [rows]    diagonal of L~
   int64_t x_rows, y_rows;
   int ntiles, N, Fin, Fout, K, C, act, ld;
-  int cheb;  // 1: T_k = 2 L~ T_{k-1} - T_{k-2} (k >= 2); 0: T_k = L~ T_{k-1}
+#ifdef DSPH_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: [8 waves][8 items][32 points] s_memtime values
+#endif
 };
+
+// Diagnostic build (make STAMPS=1; never the shipped library): s_memtime at the phase boundaries of eight items of
+// one workgroup, into a buffer nothing else reads.  Read the shares, not the run time.
+#ifdef DSPH_STAMPS
+#define ST_STAMP(id)                                                                       \
+  do {                                                                                     \
+    if (stamp_on) {                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      unsigned long long t_;                                                               \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      if (lane == 0) a.stamps[((size_t)wave * 8 + (item - 4)) * 32 + (id)] = t_;           \
+    }                                                                                      \
+  } while (0)
+#else
+#define ST_STAMP(id)
+#endif
 
 // Summation order of a row: the diagonal, then SW, W, NW, N, NE, E, SE, S (dx, dy below) -- the slot order of the
 // repo's own grid-stencil producer (deepsphere/healpix.py), so that on those graphs the sums are the unfused
@@ -109,6 +128,15 @@ __device__ __forceinline__ void st_glds16(const void* gsrc, unsigned lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// the same with a wave-uniform 64-bit base and a 32-bit byte offset per lane
+__device__ __forceinline__ void st_glds16_off(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
 
 // One recurrence step for this lane's 2x2 block: window from plane `pin` (byte offset), new values to `pout`.
 //   FIRST: T_1 = L~ T_0, the block's own T_0 is read too (16 reads); otherwise the centre of the window is `cur`.
@@ -117,19 +145,21 @@ template <bool FIRST, bool CHEB>
 __device__ __forceinline__ void st_gather(const unsigned char* __restrict__ smem, unsigned pin, unsigned pout,
                                           const unsigned (&gb)[4], const float (&v)[4][9], float4 (&cur)[4],
                                           float4 (&prev)[4]) {
+  // Two halves, so that at most 8 + 4 window cells are in registers at a time: the pixels of the block's upper row
+  // need window rows 0..2, those of the lower row need rows 1..3 (row 3 is fetched while the upper row is summed).
   float4 W[4][4];
+  auto rd = [&](int wx, int wy) {
+    W[wy][wx] = *reinterpret_cast<const float4*>(smem + (gb[st_cell_f(wx, wy)] + pin) + st_woff(wx, wy));
+  };
 #pragma unroll
-  for (int wy = 0; wy < 4; ++wy)
+  for (int wy = 0; wy < 3; ++wy)
 #pragma unroll
     for (int wx = 0; wx < 4; ++wx) {
       const bool centre = (wx == 1 || wx == 2) && (wy == 1 || wy == 2);
-      if (centre && !FIRST)
-        W[wy][wx] = cur[(wy - 1) * 2 + (wx - 1)];
-      else
-        W[wy][wx] = *reinterpret_cast<const float4*>(smem + (gb[st_cell_f(wx, wy)] + pin) + st_woff(wx, wy));
+      if (centre && !FIRST) W[wy][wx] = cur[(wy - 1) * 2 + (wx - 1)];
+      else rd(wx, wy);
     }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  auto pixel = [&](int p) {
     const int i = p & 1, j = p >> 1;
     const float4 c = W[j + 1][i + 1];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -157,7 +187,16 @@ __device__ __forceinline__ void st_gather(const unsigned char* __restrict__ smem
     cur[p] = s;
     *reinterpret_cast<float4*>(const_cast<unsigned char*>(smem) + (gb[st_cell_f(i + 1, j + 1)] + pout) +
                                st_woff(i + 1, j + 1)) = s;
-  }
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int wx = 0; wx < 4; ++wx) rd(wx, 3);
+  // the lower pixels' T_{k-1} (rows 1, 2 of the window) are still needed below: pixel() overwrites cur[] only
+  pixel(0);
+  pixel(1);
+  __builtin_amdgcn_sched_barrier(0);
+  pixel(2);
+  pixel(3);
 }
 
 // Plane T_k (this wave's 32 tile pixels, 16 channels) into the accumulators: acc[b] += Wfrag(k, b)^T-form product.
@@ -204,6 +243,108 @@ __device__ __forceinline__ void st_contract(const unsigned char* __restrict__ sm
   }
 }
 
+// Contract T_{k-1} and compute T_k in one straight-line block of three phases (fenced for the scheduler, so that the
+// live ranges stay what the source says): A every LDS read that does not depend on anything; B the upper pixel row's
+// multiply-adds with the first column block's MFMAs underneath; C the lower pixel row with the second block's.
+// `wr`: this lane's block is part of step k (the others compute on whatever their cells hold and write to a pad cell).
+template <bool FIRST, bool CHEB, int NB, int PREC>
+__device__ __forceinline__ void st_interval(const unsigned char* __restrict__ smem, unsigned pin, unsigned pout,
+                                            unsigned wblk, const unsigned (&gb)[4], const float (&v)[4][9],
+                                            float4 (&cur)[4], float4 (&prev)[4], unsigned mb0, unsigned mb1, int lane,
+                                            st_f32x16 (&acc)[NB], bool wr, unsigned dummy) {
+  // lanes whose block is not part of this step store into a pad cell of the output plane instead of branching:
+  // the interval stays one basic block, which is what lets the scheduler put the MFMAs under the multiply-adds
+  unsigned ob[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    ob[p] = (wr ? gb[st_cell_f((p & 1) + 1, (p >> 1) + 1)] + st_woff((p & 1) + 1, (p >> 1) + 1) : dummy) + pout;
+  float4 W[4][4];
+  auto rd = [&](int wx, int wy) {
+    W[wy][wx] = *reinterpret_cast<const float4*>(smem + (gb[st_cell_f(wx, wy)] + pin) + st_woff(wx, wy));
+  };
+  auto pixel = [&](int p) {
+    const int i = p & 1, j = p >> 1;
+    const float4 c = W[j + 1][i + 1];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    s.x = fmaf(v[p][0], c.x, s.x);
+    s.y = fmaf(v[p][0], c.y, s.y);
+    s.z = fmaf(v[p][0], c.z, s.z);
+    s.w = fmaf(v[p][0], c.w, s.w);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const float4 u = W[j + 1 + kDirY[d]][i + 1 + kDirX[d]];
+      const float w = v[p][d + 1];
+      s.x = fmaf(w, u.x, s.x);
+      s.y = fmaf(w, u.y, s.y);
+      s.z = fmaf(w, u.z, s.z);
+      s.w = fmaf(w, u.w, s.w);
+    }
+    if (!FIRST && CHEB) {
+      const float4 q = prev[p];
+      s.x = 2.f * s.x - q.x;
+      s.y = 2.f * s.y - q.y;
+      s.z = 2.f * s.z - q.z;
+      s.w = 2.f * s.w - q.w;
+    }
+    prev[p] = c;
+    cur[p] = s;
+    *reinterpret_cast<float4*>(const_cast<unsigned char*>(smem) + ob[p]) = s;
+  };
+  // ---- A: reads ---------------------------------------------------------------------------------------------------
+  const float4 a0 = *reinterpret_cast<const float4*>(smem + pin + mb0);
+  const float4 a1 = *reinterpret_cast<const float4*>(smem + pin + mb1);
+  const unsigned char* __restrict__ wp = smem + wblk + lane * 16;
+  float4 w0h = *reinterpret_cast<const float4*>(wp), w0l = *reinterpret_cast<const float4*>(wp + 1024);
+#pragma unroll
+  for (int wy = 0; wy < 3; ++wy)
+#pragma unroll
+    for (int wx = 0; wx < 4; ++wx) {
+      const bool centre = (wx == 1 || wx == 2) && (wy == 1 || wy == 2);
+      if (centre && !FIRST) W[wy][wx] = cur[(wy - 1) * 2 + (wx - 1)];
+      else rd(wx, wy);
+    }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- B: first column block under the upper pixel row ------------------------------------------------------------
+  const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  st_bf16x8 thi, tlo;
+  if (PREC == DSPH_PREC_BF16X3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const __bf16 hi = (__bf16)av[j];
+      thi[j] = hi;
+      tlo[j] = (__bf16)(av[j] - (float)hi);
+    }
+  }
+  auto mfma_block = [&](int b, const float4& wh, const float4& wl) {
+    if (PREC == DSPH_PREC_BF16X3) {
+      const st_bf16x8 whi = __builtin_bit_cast(st_bf16x8, wh), wlo = __builtin_bit_cast(st_bf16x8, wl);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, tlo, acc[b], 0, 0, 0);  // small terms first
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, thi, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, thi, acc[b], 0, 0, 0);
+    } else {
+      const float wf[8] = {wh.x, wh.y, wh.z, wh.w, wl.x, wl.y, wl.z, wl.w};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[t], av[t], acc[b], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int wx = 0; wx < 4; ++wx) {  // window row 3, and the lower centre row when the centre is not in registers
+    rd(wx, 3);
+  }
+  mfma_block(0, w0h, w0l);
+  if (NB == 2) {  // the second block's fragments take over the first one's registers
+    w0h = *reinterpret_cast<const float4*>(wp + 2048);
+    w0l = *reinterpret_cast<const float4*>(wp + 2048 + 1024);
+  }
+  pixel(0);
+  pixel(1);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- C: second column block under the lower pixel row -----------------------------------------------------------
+  if (NB == 2) mfma_block(1, w0h, w0l);
+  pixel(2);
+  pixel(3);
+}
+
 // y of one map for this lane's pixel: register quad tq of block b holds output channels 32 b + 8 tq + 4 h .. + 3.
 template <int NB, int ACT, bool VEC>
 __device__ __forceinline__ void st_store(const st_f32x16 (&acc)[NB], float* __restrict__ yp, const float* __restrict__ sBias,
@@ -231,12 +372,13 @@ __device__ __forceinline__ void st_store(const st_f32x16 (&acc)[NB], float* __re
     }
 }
 
-template <int NB, int PREC>
+template <int NB, int PREC, bool CHEB>
 __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[ST_LDS_TOTAL];
   float* const sBias = reinterpret_cast<float*>(smem + ST_LDS_BIAS);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar registers, "s" asm operands
   const int D = a.K - 1;
   if (tid < 64) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
 
@@ -266,16 +408,23 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
 
   // ---- DMA role: wave w issues pieces w, w+8, ...; lane l fills slot l & 3 of cell 16 i + (l >> 2) of the plane --
   constexpr int NP = (ST_DMA_PIECES + 7) / 8;  // 5
-  unsigned dcell[NP];  // gx | gy << 8 | logical slot << 16 | valid << 24
-#pragma unroll
-  for (int s = 0; s < NP; ++s) {
+  // cell (gx, gy) and logical slot of piece s of this lane; valid: inside the plane and inside the D-ring region
+  auto dma_cell = [&](int s, unsigned& gx, unsigned& gy, unsigned& slot) -> bool {
     const int piece = wave + 8 * s;
     const unsigned p = 16u * piece + (lane >> 2);
-    const unsigned par = p / ST_HP, rem = p % ST_HP, gy = rem / ST_P2, gxh = rem % ST_P2;
-    const unsigned gx = 2 * gxh + par;
+    const unsigned par = p / ST_HP, rem = p % ST_HP, gxh = rem % ST_P2;
+    gy = rem / ST_P2;
+    gx = 2 * gxh + par;
+    slot = (lane & 3u) ^ st_cell_f(gx, gy);
     const int lo = ST_DMAX - D, hi = ST_DMAX + ST_TILE - 1 + D;
-    const bool ok = piece < ST_DMA_PIECES && gxh < ST_S / 2 && (int)gx >= lo && (int)gx <= hi && (int)gy >= lo && (int)gy <= hi;
-    dcell[s] = gx | (gy << 8) | (((lane & 3u) ^ st_cell_f(gx, gy)) << 16) | ((ok ? 1u : 0u) << 24);
+    return piece < ST_DMA_PIECES && gxh < ST_S / 2 && (int)gx >= lo && (int)gx <= hi && (int)gy >= lo && (int)gy <= hi;
+  };
+  unsigned dinfo = 0;  // per piece s: bits 3s..3s+1 logical slot, bit 3s+2 valid
+#pragma unroll
+  for (int s = 0; s < NP; ++s) {
+    unsigned gx, gy, slot;
+    const bool ok = dma_cell(s, gx, gy, slot);
+    dinfo |= (slot | (ok ? 4u : 0u)) << (3 * s);
   }
 
   // tiles are dealt to XCDs in contiguous ranges (blocks b and b+8 share an XCD and its L2)
@@ -287,38 +436,51 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
   const int wpieces = wslice / 1024;
   const bool vec_ok = (a.Fout % 4 == 0) && (a.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
 
-  // x rows of the region cells this lane fetches, for the tile being PREFETCHED
-  int64_t drow[NP];
-  auto set_drows = [&](int tpos) {
+  // per-lane activity: bit k = this lane's block is part of step k
+  unsigned lact = 0;
+#pragma unroll
+  for (int k = 1; k <= ST_DMAX; ++k) lact |= (k <= D && active_at(k)) ? (1u << k) : 0u;
+  // where the other lanes' stores go: the pad cell (half-row index 12) of their window's second row, own slot
+  const unsigned dummy = (unsigned)((2 * by + 1) * ST_P2 + ST_S / 2) * 64u + 16u * q;
+
+  // byte offsets (from the map's first element) of the x pieces this lane fetches, for the tile being PREFETCHED
+  // (the host admits only maps of less than 4 GiB to this kernel)
+  unsigned doff[NP];
+  auto set_doffs = [&](int tpos) {
     const unsigned row0 = (unsigned)a.tiles[tpos] * 256u;
     const unsigned X0 = st_compress(row0), Y0 = st_compress(row0 >> 1);
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
-      const unsigned gx = dcell[s] & 255u, gy = (dcell[s] >> 8) & 255u;
-      const bool ok = (dcell[s] >> 24) != 0;
+      unsigned gx, gy, slot;
+      const bool ok = dma_cell(s, gx, gy, slot);
       const unsigned rid = ok ? st_morton(X0 + gx - ST_DMAX, Y0 + gy - ST_DMAX) : row0;
-      drow[s] = (int64_t)rid * a.Fin;
+      doff[s] = (rid * (unsigned)a.Fin + 4u * slot) * 4u;
     }
   };
-  // issue the DMA of item `it` of the tile whose rows are in drow[]: x slice -> plane at `pdst`, weights -> `wdst`
-  auto issue_dma = [&](int it, unsigned pdst, unsigned wdst) {
+  const bool ragged = (a.Fin & 15) != 0;  // the last slice has channels past Fin: they are read from valid channels
+  // piece s (compile-time) of the x slice of item `it` -> plane at pdst
+  auto dma_x = [&](auto s_c, int it, unsigned pdst) {
+    constexpr int s = decltype(s_c)::value;
     const int n = it / a.C, c = it - n * a.C;
-    const float* __restrict__ xb = a.x + (int64_t)n * a.x_rows * a.Fin;
-#pragma unroll
-    for (int s = 0; s < NP; ++s) {
-      const int ch0 = c * 16 + 4 * (int)((dcell[s] >> 16) & 3u);
-      const int ch = ch0 < a.Fin ? ch0 : a.Fin - 4;  // channels past Fin meet zero weights
-      if ((dcell[s] >> 24) != 0) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(pdst + 1024u * (unsigned)(wave + 8 * s));
-        st_glds16(xb + drow[s] + ch, dst);
-      }
+    const float* __restrict__ base = a.x + ((int64_t)n * a.x_rows * a.Fin + c * 16);
+    unsigned off = doff[s];
+    if (ragged) {
+      const int ch0 = c * 16 + 4 * (int)((dinfo >> (3 * s)) & 3u);
+      if (ch0 >= a.Fin) off -= (unsigned)(ch0 - (a.Fin - 4)) * 4u;  // meets zero weights
     }
-    const unsigned char* __restrict__ wsrc = a.wfrag + (size_t)c * wslice + lane * 16;
-    for (int j = wave; j < wpieces; j += 8) {
-      const unsigned dst = __builtin_amdgcn_readfirstlane(wdst + 1024u * (unsigned)j);
-      st_glds16(wsrc + 1024 * j, dst);
+    if ((dinfo >> (3 * s)) & 4u)
+      st_glds16_off(base, off, __builtin_amdgcn_readfirstlane(pdst + 1024u * (unsigned)(wave + 8 * s)));
+  };
+  // piece u of this wave's share of the weight fragments of item `it`'s slice -> buffer at wdst
+  auto dma_w = [&](int u, int it, unsigned wdst) {
+    const int j = wave + 8 * u;
+    if (j < wpieces) {
+      const int c = it % a.C;
+      st_glds16_off(a.wfrag + (size_t)c * wslice + 1024 * j, (unsigned)lane * 16u,
+                    __builtin_amdgcn_readfirstlane(wdst + 1024u * (unsigned)j));
     }
   };
+  using std::integral_constant;
 
   st_f32x16 acc[NB];
   float v[4][9];
@@ -328,17 +490,23 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
 
   int t = t_begin + slot0;
   if (t >= t_end) return;
-  unsigned px = 0;                    // byte offset of the X plane of the current item (plane 0 or 2); Y is plane 1
-  unsigned wb = ST_LDS_W;             // weight buffer of the current item
-  set_drows(t);
-  issue_dma(0, px, wb);
-  const bool late = wave >= 4;  // second wave of each SIMD: gathers first, contracts second
+  unsigned px = 0;         // byte offset of the X plane of the current item (plane 0 or 2); Y is plane 1
+  unsigned wb = ST_LDS_W;  // weight buffer of the current item
+  constexpr unsigned py = ST_PLANE_BYTES;
+  set_doffs(t);
+  dma_x(integral_constant<int, 0>{}, 0, px);
+  dma_x(integral_constant<int, 1>{}, 0, px);
+  dma_x(integral_constant<int, 2>{}, 0, px);
+  dma_x(integral_constant<int, 3>{}, 0, px);
+  dma_x(integral_constant<int, 4>{}, 0, px);
+  for (int u = 0; u < 3; ++u) dma_w(u, 0, wb);
+  bool stored = false;  // the previous item ended with this wave's y stores (the youngest vector-memory operations)
 
   for (; t < t_end; t += nslots) {
     const unsigned row0 = (unsigned)a.tiles[t] * 256u;
     {  // L~ values of this lane's four pixels (blocks that no step touches keep zeros and load nothing)
       const unsigned X0 = st_compress(row0), Y0 = st_compress(row0 >> 1);
-      const bool ld_ok = active_at(1);
+      const bool ld_ok = (lact & 2u) != 0;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const unsigned gx = 2 * bx + 1 + (p & 1), gy = 2 * by + 1 + (p >> 1);
@@ -352,45 +520,86 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
     }
     for (int item = 0; item < items; ++item) {
       const int n = item / a.C, c = item - n * a.C;
-      // ---- B_a: this item's x slice and weights have landed; every LDS read of the previous item is done -----
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      const unsigned pxn = px ^ (2u * ST_PLANE_BYTES);
-      const unsigned wb_next = wb == (unsigned)ST_LDS_W ? (unsigned)(ST_LDS_W + ST_WSLICE_BYTES) : (unsigned)ST_LDS_W;
-      {  // prefetch the next item (of this tile, or the first of this workgroup's next tile)
-        const bool last = item + 1 == items;
-        if (!last) {
-          issue_dma(item + 1, pxn, wb_next);
-        } else if (t + nslots < t_end) {
-          set_drows(t + nslots);
-          issue_dma(0, pxn, wb_next);
-        }
+#ifdef DSPH_STAMPS
+      const bool stamp_on = blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
+#endif
+      ST_STAMP(0);
+      // ---- B_a: this item's x slice and weights have landed (the y stores just issued may still be in flight);
+      //      every LDS read of the previous item is done ------------------------------------------------------------
+      if (stored && vec_ok) {
+        if (NB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      ST_STAMP(1);
+      __syncthreads();
+      ST_STAMP(2);
+      const unsigned pxn = px ^ (2u * ST_PLANE_BYTES);
+      const unsigned wbn = wb == (unsigned)ST_LDS_W ? (unsigned)(ST_LDS_W + ST_WSLICE_BYTES) : (unsigned)ST_LDS_W;
+      // the next item (of this tile, or the first of this workgroup's next tile) is fetched piece by piece between
+      // the phases below: a burst of eight pieces per wave would hold every wave at the address unit for 2-4 k cycles
+      const bool more = item + 1 < items || t + nslots < t_end;
+      const int nit = item + 1 < items ? item + 1 : 0;
+      if (item + 1 == items && more) set_doffs(t + nslots);
+      if (more) dma_x(integral_constant<int, 0>{}, nit, pxn);
+      ST_STAMP(3);
       if (c == 0) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
       }
-      const unsigned py = ST_PLANE_BYTES;  // Y plane
-      // ---- interval k = 1 .. K-1: contract T_{k-1}, compute T_k -------------------------------------------------
-      for (int k = 1; k < a.K; ++k) {
-        const unsigned pin = (k & 1) ? px : py, pout = (k & 1) ? py : px;
-        const unsigned wk = wb + (unsigned)((k - 1) * NB * 2048);
-        if (!late) st_contract<NB, PREC>(smem, pin, wk, mb0, mb1, lane, acc);
-        if (active_at(k)) {
-          if (k == 1) st_gather<true, false>(smem, pin, pout, gb, v, cur, prev);
-          else if (a.cheb) st_gather<false, true>(smem, pin, pout, gb, v, cur, prev);
-          else st_gather<false, false>(smem, pin, pout, gb, v, cur, prev);
-        }
-        if (late) st_contract<NB, PREC>(smem, pin, wk, mb0, mb1, lane, acc);
+      // ---- interval k = 1 .. K-1: contract T_{k-1}, compute T_k ---------------------------------------------------
+#define ST_INTERVAL(k, FIRST_, PIN, POUT)                                                                   \
+  {                                                                                                         \
+    const unsigned wk = wb + (unsigned)(((k) - 1) * NB * 2048);                                             \
+    st_interval<FIRST_, CHEB, NB, PREC>(smem, PIN, POUT, wk, gb, v, cur, prev, mb0, mb1, lane, acc,         \
+                                        (lact & (1u << (k))) != 0, dummy);                                  \
+  }
+      ST_INTERVAL(1, true, px, py)
+      ST_STAMP(4);
+      if (more) { dma_x(integral_constant<int, 1>{}, nit, pxn); dma_w(0, nit, wbn); }
+      ST_STAMP(5);
+      __syncthreads();
+      ST_STAMP(6);
+      if (a.K > 2) {
+        ST_INTERVAL(2, false, py, px)
+        ST_STAMP(7);
+        if (more) { dma_x(integral_constant<int, 2>{}, nit, pxn); dma_w(1, nit, wbn); }
+        ST_STAMP(8);
         __syncthreads();
+        ST_STAMP(9);
+      }
+      if (a.K > 3) {
+        ST_INTERVAL(3, false, px, py)
+        ST_STAMP(10);
+        if (more) { dma_x(integral_constant<int, 3>{}, nit, pxn); dma_w(2, nit, wbn); }
+        ST_STAMP(11);
+        __syncthreads();
+        ST_STAMP(12);
+      }
+      if (a.K > 4) {
+        ST_INTERVAL(4, false, py, px)
+        ST_STAMP(13);
+        if (more) dma_x(integral_constant<int, 4>{}, nit, pxn);
+        ST_STAMP(14);
+        __syncthreads();
+        ST_STAMP(15);
+      }
+#undef ST_INTERVAL
+      if (more) {  // pieces that the shorter recurrences have not sent yet
+        if (a.K <= 2) { dma_x(integral_constant<int, 2>{}, nit, pxn); dma_w(1, nit, wbn); }
+        if (a.K <= 3) { dma_x(integral_constant<int, 3>{}, nit, pxn); dma_w(2, nit, wbn); }
+        if (a.K <= 4) dma_x(integral_constant<int, 4>{}, nit, pxn);
       }
       {  // the last plane
         const unsigned pl = ((a.K - 1) & 1) ? py : px;
         st_contract<NB, PREC>(smem, pl, wb + (unsigned)((a.K - 1) * NB * 2048), mb0, mb1, lane, acc);
       }
-      if (c == a.C - 1) {  // y of this map, straight from the accumulators
+      ST_STAMP(16);
+      stored = c == a.C - 1;
+      if (stored) {  // y of this map, straight from the accumulators
         float* __restrict__ yp = a.y + ((int64_t)n * a.y_rows + row0 + y_pix) * a.ld;
         // one uniform switch per map, not one per element (the inlined activation switch is 5 k instructions otherwise)
         if (!vec_ok) st_store<NB, -1, false>(acc, yp, sBias, (int)mh, a.Fout, a.act);
@@ -398,8 +607,9 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
         else if (a.act == DSPH_ACT_RELU) st_store<NB, DSPH_ACT_RELU, true>(acc, yp, sBias, (int)mh, a.Fout, a.act);
         else st_store<NB, -1, true>(acc, yp, sBias, (int)mh, a.Fout, a.act);
       }
+      ST_STAMP(17);
       px = pxn;
-      wb = wb_next;
+      wb = wbn;
     }
   }
 }
