@@ -188,6 +188,7 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
           fprintf(stderr, "STSTAMP wave %d item %d:", w, it + 4);
           const unsigned long long* r = &h[((size_t)w * 8 + it) * 32];
           for (int i = 1; i < 18; ++i) fprintf(stderr, " %lld", r[i] && r[i - 1] ? (long long)(r[i] - r[i - 1]) : -1LL);
+          fprintf(stderr, " | k2: A %lld B %lld C %lld", (long long)(r[18] - r[6]), (long long)(r[19] - r[18]), (long long)(r[7] - r[19]));
           fprintf(stderr, " | t0 %llu\n", r[0]);
         }
   }

@@ -247,11 +247,11 @@ __device__ __forceinline__ void st_contract(const unsigned char* __restrict__ sm
 // live ranges stay what the source says): A every LDS read that does not depend on anything; B the upper pixel row's
 // multiply-adds with the first column block's MFMAs underneath; C the lower pixel row with the second block's.
 // `wr`: this lane's block is part of step k (the others compute on whatever their cells hold and write to a pad cell).
-template <bool FIRST, bool CHEB, int NB, int PREC>
+template <bool FIRST, bool CHEB, int NB, int PREC, class StampFn>
 __device__ __forceinline__ void st_interval(const unsigned char* __restrict__ smem, unsigned pin, unsigned pout,
                                             unsigned wblk, const unsigned (&gb)[4], const float (&v)[4][9],
                                             float4 (&cur)[4], float4 (&prev)[4], unsigned mb0, unsigned mb1, int lane,
-                                            st_f32x16 (&acc)[NB], bool wr, unsigned dummy) {
+                                            st_f32x16 (&acc)[NB], bool wr, unsigned dummy, StampFn stamp) {
   // lanes whose block is not part of this step store into a pad cell of the output plane instead of branching:
   // the interval stays one basic block, which is what lets the scheduler put the MFMAs under the multiply-adds
   unsigned ob[4];
@@ -304,6 +304,7 @@ __device__ __forceinline__ void st_interval(const unsigned char* __restrict__ sm
       else rd(wx, wy);
     }
   __builtin_amdgcn_sched_barrier(0);
+  stamp(0);
   // ---- B: first column block under the upper pixel row ------------------------------------------------------------
   const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
   st_bf16x8 thi, tlo;
@@ -328,9 +329,8 @@ __device__ __forceinline__ void st_interval(const unsigned char* __restrict__ sm
     }
   };
 #pragma unroll
-  for (int wx = 0; wx < 4; ++wx) {  // window row 3, and the lower centre row when the centre is not in registers
-    rd(wx, 3);
-  }
+  for (int wx = 0; wx < 4; ++wx) rd(wx, 3);
+  // the MFMAs are issued in front of the pixels' multiply-adds and run underneath them
   mfma_block(0, w0h, w0l);
   if (NB == 2) {  // the second block's fragments take over the first one's registers
     w0h = *reinterpret_cast<const float4*>(wp + 2048);
@@ -338,38 +338,68 @@ __device__ __forceinline__ void st_interval(const unsigned char* __restrict__ sm
   }
   pixel(0);
   pixel(1);
+  if (PREC == DSPH_PREC_FP32) {  // eight 64-cycle MFMAs per phase: one, then a run of the pixels' multiply-adds, and so on
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
+  stamp(1);
   // ---- C: second column block under the lower pixel row -----------------------------------------------------------
   if (NB == 2) mfma_block(1, w0h, w0l);
   pixel(2);
   pixel(3);
+  if (PREC == DSPH_PREC_FP32 && NB == 2) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+    }
+  }
 }
 
-// y of one map for this lane's pixel: register quad tq of block b holds output channels 32 b + 8 tq + 4 h .. + 3.
+// y of one map.  The accumulators hold, per lane (pixel r, half h), register quad tq of block b = output channels
+// 32 b + 8 tq + 4 h .. + 3: stored as they stand a wave instruction touches 32 rows x 2 x 16 B (measured: 250-500
+// cycles of issue per instruction, every wave at once).  They go through a 32 x 32 block of LDS instead (the plane that
+// no longer holds anything: free until the next item's first step), so that eight lanes write 128 contiguous bytes.
+constexpr int ST_SCR_PITCH = 144;                      // bytes per pixel row of the block (32 floats + 4 pad)
+constexpr int ST_SCR_WAVE = 32 * ST_SCR_PITCH;         // 4,608 B per wave; 8 waves = 36,864 <= ST_PLANE_BYTES
 template <int NB, int ACT, bool VEC>
-__device__ __forceinline__ void st_store(const st_f32x16 (&acc)[NB], float* __restrict__ yp, const float* __restrict__ sBias,
-                                         int mh, int Fout, int act_rt) {
+__device__ __forceinline__ void st_store(const st_f32x16 (&acc)[NB], unsigned char* __restrict__ scr,
+                                         float* __restrict__ ytile, int ld, const float* __restrict__ sBias, int wave,
+                                         int lane, int Fout, int act_rt) {
   const int act = ACT >= 0 ? ACT : act_rt;
+  const int r = lane & 31, h = lane >> 5;
+  const int j = lane & 7, pq = lane >> 3;
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+  for (int b = 0; b < NB; ++b) {
 #pragma unroll
-    for (int tq = 0; tq < 4; ++tq) {
-      const int ch = 32 * b + 8 * tq + 4 * mh;
-      const float4 bv = *reinterpret_cast<const float4*>(sBias + ch);
-      float4 o;
-      o.x = apply_act(acc[b][4 * tq + 0] + bv.x, act);
-      o.y = apply_act(acc[b][4 * tq + 1] + bv.y, act);
-      o.z = apply_act(acc[b][4 * tq + 2] + bv.z, act);
-      o.w = apply_act(acc[b][4 * tq + 3] + bv.w, act);
+    for (int tq = 0; tq < 4; ++tq)
+      *reinterpret_cast<float4*>(scr + r * ST_SCR_PITCH + (8 * tq + 4 * h) * 4) =
+          make_float4(acc[b][4 * tq + 0], acc[b][4 * tq + 1], acc[b][4 * tq + 2], acc[b][4 * tq + 3]);
+    const int ch = 32 * b + 4 * j;
+    const float4 bv = *reinterpret_cast<const float4*>(sBias + ch);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = pq + 8 * i;  // pixel (p & 15, 2 wave + (p >> 4)) of the tile
+      float4 o = *reinterpret_cast<const float4*>(scr + p * ST_SCR_PITCH + 16 * j);
+      o.x = apply_act(o.x + bv.x, act);
+      o.y = apply_act(o.y + bv.y, act);
+      o.z = apply_act(o.z + bv.z, act);
+      o.w = apply_act(o.w + bv.w, act);
+      float* __restrict__ yp = ytile + (int64_t)st_morton((unsigned)(p & 15), (unsigned)(2 * wave + (p >> 4))) * ld + ch;
       if (VEC) {
-        if (ch < Fout) *reinterpret_cast<float4*>(yp + ch) = o;
+        if (ch < Fout) *reinterpret_cast<float4*>(yp) = o;
       } else {
-        if (ch + 0 < Fout) yp[ch + 0] = o.x;
-        if (ch + 1 < Fout) yp[ch + 1] = o.y;
-        if (ch + 2 < Fout) yp[ch + 2] = o.z;
-        if (ch + 3 < Fout) yp[ch + 3] = o.w;
+        if (ch + 0 < Fout) yp[0] = o.x;
+        if (ch + 1 < Fout) yp[1] = o.y;
+        if (ch + 2 < Fout) yp[2] = o.z;
+        if (ch + 3 < Fout) yp[3] = o.w;
       }
     }
+  }
 }
 
 template <int NB, int PREC, bool CHEB>
@@ -404,7 +434,6 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
   const unsigned mgx = ST_DMAX + mpx, mgy = ST_DMAX + mpy;
   const unsigned mb0 = st_cell_off(mgx, mgy) + 16u * ((2 * mh) ^ st_cell_f(mgx, mgy));
   const unsigned mb1 = st_cell_off(mgx, mgy) + 16u * ((2 * mh + 1) ^ st_cell_f(mgx, mgy));
-  const unsigned y_pix = st_morton(mpx, mpy);  // row of this lane's pixel inside the tile
 
   // ---- DMA role: wave w issues pieces w, w+8, ...; lane l fills slot l & 3 of cell 16 i + (l >> 2) of the plane --
   constexpr int NP = (ST_DMA_PIECES + 7) / 8;  // 5
@@ -549,13 +578,16 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
         for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        asm volatile("" ::: "memory");  // a real branch: as selects the zeroing costs 32 instructions in every item
       }
       // ---- interval k = 1 .. K-1: contract T_{k-1}, compute T_k ---------------------------------------------------
 #define ST_INTERVAL(k, FIRST_, PIN, POUT)                                                                   \
   {                                                                                                         \
     const unsigned wk = wb + (unsigned)(((k) - 1) * NB * 2048);                                             \
     st_interval<FIRST_, CHEB, NB, PREC>(smem, PIN, POUT, wk, gb, v, cur, prev, mb0, mb1, lane, acc,         \
-                                        (lact & (1u << (k))) != 0, dummy);                                  \
+                                        (lact & (1u << (k))) != 0, dummy, [&](int id) {                     \
+                                          if ((k) == 2) { ST_STAMP(18 + id); }                              \
+                                        });                                                                 \
   }
       ST_INTERVAL(1, true, px, py)
       ST_STAMP(4);
@@ -600,12 +632,14 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
       ST_STAMP(16);
       stored = c == a.C - 1;
       if (stored) {  // y of this map, straight from the accumulators
-        float* __restrict__ yp = a.y + ((int64_t)n * a.y_rows + row0 + y_pix) * a.ld;
+        float* __restrict__ yt = a.y + ((int64_t)n * a.y_rows + row0) * a.ld;
+        // the plane that does not hold T_{K-1}: its last readers passed the barrier above
+        unsigned char* scr = smem + (((a.K - 1) & 1) ? px : py) + wave * ST_SCR_WAVE;
         // one uniform switch per map, not one per element (the inlined activation switch is 5 k instructions otherwise)
-        if (!vec_ok) st_store<NB, -1, false>(acc, yp, sBias, (int)mh, a.Fout, a.act);
-        else if (a.act == DSPH_ACT_NONE) st_store<NB, DSPH_ACT_NONE, true>(acc, yp, sBias, (int)mh, a.Fout, a.act);
-        else if (a.act == DSPH_ACT_RELU) st_store<NB, DSPH_ACT_RELU, true>(acc, yp, sBias, (int)mh, a.Fout, a.act);
-        else st_store<NB, -1, true>(acc, yp, sBias, (int)mh, a.Fout, a.act);
+        if (!vec_ok) st_store<NB, -1, false>(acc, scr, yt, a.ld, sBias, wave, lane, a.Fout, a.act);
+        else if (a.act == DSPH_ACT_NONE) st_store<NB, DSPH_ACT_NONE, true>(acc, scr, yt, a.ld, sBias, wave, lane, a.Fout, a.act);
+        else if (a.act == DSPH_ACT_RELU) st_store<NB, DSPH_ACT_RELU, true>(acc, scr, yt, a.ld, sBias, wave, lane, a.Fout, a.act);
+        else st_store<NB, -1, true>(acc, scr, yt, a.ld, sBias, wave, lane, a.Fout, a.act);
       }
       ST_STAMP(17);
       px = pxn;

@@ -15,7 +15,7 @@ __device__ __forceinline__ void glds16_off(const void* sbase, unsigned voff, uns
 // window of `win` rows per workgroup; nwaves: how many waves of the workgroup issue; NP pieces back to back, R rounds
 template <int NP>
 __global__ __launch_bounds__(512, 2) void k(const float* x, int seg, int stride, int win, int nwaves, int R,
-                                            unsigned long long* out, int spread) {
+                                            unsigned long long* out, int spread, int cold) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[8 * NP * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(512, 2) void k(const float* x, int seg, int stride,
     const unsigned row = (unsigned)((rowslot * 2654435761u) >> 8) % (unsigned)win;
     voff[p] = row * (unsigned)stride + (unsigned)(lane % lanes_per_row) * 16u;
   }
-  const float* base = x + (size_t)blockIdx.x * ((size_t)win * stride / 4);
+  const float* base = x + (size_t)blockIdx.x * ((size_t)4096 * 4 * stride / 4);
   unsigned long long t_issue = 0, t_total = 0;
   for (int r = 0; r < R; ++r) {
     __syncthreads();
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(512, 2) void k(const float* x, int seg, int stride,
     if (wave < nwaves) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        glds16_off(base, voff[p] + (unsigned)(r & 3) * 64u * 0u, __builtin_amdgcn_readfirstlane((unsigned)((wave * NP + p) * 1024)));
+        glds16_off(base, voff[p] + (cold ? (unsigned)r * 64u * (unsigned)stride * 0u + (unsigned)(r % 13) * 147456u : 0u), __builtin_amdgcn_readfirstlane((unsigned)((wave * NP + p) * 1024)));
         if (spread) __builtin_amdgcn_s_sleep(4);
       }
     }
@@ -49,22 +49,23 @@ __global__ __launch_bounds__(512, 2) void k(const float* x, int seg, int stride,
 }
 
 int main() {
-  const size_t bytes = (size_t)256 * 4096 * 256;  // 256 blocks x 4096 rows x 256 B = 256 MB
+  const size_t bytes = (size_t)256 * 4096 * 256 * 4;  // 256 blocks x 4096 rows x 256 B = 256 MB
   float* x; unsigned long long* out;
   hipMalloc(&x, bytes); hipMemset(x, 0, bytes);
   hipMalloc(&out, 1024); hipMemset(out, 0, 1024);
   const int segs[] = {64, 128, 256, 1024};
-  const int wins[] = {576, 4096};  // rows per workgroup window: 147 KB (L2-ish) and 1 MB
+  const int wins[] = {576};  // rows per workgroup window: 147 KB (L2-ish) and 1 MB
   for (int win : wins)
     for (int seg : segs)
       for (int nw : {1, 8})
-        for (int spread : {0, 4}) {
-          k<8><<<256, 512>>>(x, seg, 256, win, nw, 40, out, spread);
+        for (int spread : {0})
+        for (int cold : {0, 1}) {
+          k<8><<<256, 512>>>(x, seg, 256, win, nw, 40, out, spread, cold);
           hipDeviceSynchronize();
           unsigned long long h[16];
           hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
-          printf("win %4d rows seg %4d B waves %d sleep %d: issue %5llu cyc / 8 pieces (wave0), total %5llu; last wave issue %5llu total %5llu\n",
-                 win, seg, nw, spread, h[0], h[1], h[(nw - 1) * 2], h[(nw - 1) * 2 + 1]);
+          printf("cold %d win %4d rows seg %4d B waves %d sleep %d: issue %5llu cyc / 8 pieces (wave0), total %5llu; last wave issue %5llu total %5llu\n",
+                 cold, win, seg, nw, spread, h[0], h[1], h[(nw - 1) * 2], h[(nw - 1) * 2 + 1]);
         }
   return 0;
 }
