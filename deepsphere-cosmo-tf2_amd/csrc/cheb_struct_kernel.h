@@ -286,8 +286,8 @@ __device__ __forceinline__ void st_interval(const unsigned char* __restrict__ sm
       s.z = 2.f * s.z - q.z;
       s.w = 2.f * s.w - q.w;
     }
-    prev[p] = c;
-    cur[p] = s;
+    if (FIRST) cur[p] = c;  // the block's own T_0, read from the plane in this step only
+    prev[p] = s;            // T_k takes the place of T_{k-2}: the caller swaps the two arrays' roles, no moves
     *reinterpret_cast<float4*>(const_cast<unsigned char*>(smem) + ob[p]) = s;
   };
   // ---- A: reads ---------------------------------------------------------------------------------------------------
@@ -488,9 +488,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
   };
   const bool ragged = (a.Fin & 15) != 0;  // the last slice has channels past Fin: they are read from valid channels
   // piece s (compile-time) of the x slice of item `it` -> plane at pdst
-  auto dma_x = [&](auto s_c, int it, unsigned pdst) {
+  auto dma_x = [&](auto s_c, int n, int c, unsigned pdst) {
     constexpr int s = decltype(s_c)::value;
-    const int n = it / a.C, c = it - n * a.C;
     const float* __restrict__ base = a.x + ((int64_t)n * a.x_rows * a.Fin + c * 16);
     unsigned off = doff[s];
     if (ragged) {
@@ -501,10 +500,9 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
       st_glds16_off(base, off, __builtin_amdgcn_readfirstlane(pdst + 1024u * (unsigned)(wave + 8 * s)));
   };
   // piece u of this wave's share of the weight fragments of item `it`'s slice -> buffer at wdst
-  auto dma_w = [&](int u, int it, unsigned wdst) {
+  auto dma_w = [&](int u, int c, unsigned wdst) {
     const int j = wave + 8 * u;
     if (j < wpieces) {
-      const int c = it % a.C;
       st_glds16_off(a.wfrag + (size_t)c * wslice + 1024 * j, (unsigned)lane * 16u,
                     __builtin_amdgcn_readfirstlane(wdst + 1024u * (unsigned)j));
     }
@@ -513,9 +511,9 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
 
   st_f32x16 acc[NB];
   float v[4][9];
-  float4 cur[4], prev[4];
+  float4 ta[4], tb[4];  // T_{k-1} and T_{k-2} of this lane's four pixels, in alternating roles
 #pragma unroll
-  for (int p = 0; p < 4; ++p) cur[p] = prev[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < 4; ++p) ta[p] = tb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   int t = t_begin + slot0;
   if (t >= t_end) return;
@@ -523,12 +521,15 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
   unsigned wb = ST_LDS_W;  // weight buffer of the current item
   constexpr unsigned py = ST_PLANE_BYTES;
   set_doffs(t);
-  dma_x(integral_constant<int, 0>{}, 0, px);
-  dma_x(integral_constant<int, 1>{}, 0, px);
-  dma_x(integral_constant<int, 2>{}, 0, px);
-  dma_x(integral_constant<int, 3>{}, 0, px);
-  dma_x(integral_constant<int, 4>{}, 0, px);
+  dma_x(integral_constant<int, 0>{}, 0, 0, px);
+  dma_x(integral_constant<int, 1>{}, 0, 0, px);
+  dma_x(integral_constant<int, 2>{}, 0, 0, px);
+  dma_x(integral_constant<int, 3>{}, 0, 0, px);
+  dma_x(integral_constant<int, 4>{}, 0, 0, px);
   for (int u = 0; u < 3; ++u) dma_w(u, 0, wb);
+#ifdef DSPH_ST_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(DSPH_ST_PRIO);  // the second wave of every SIMD: see Makefile
+#endif
   bool stored = false;  // the previous item ended with this wave's y stores (the youngest vector-memory operations)
 
   for (; t < t_end; t += nslots) {
@@ -547,8 +548,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
         v[p][5] = n1.x; v[p][6] = n1.y; v[p][7] = n1.z; v[p][8] = n1.w;
       }
     }
+    int n = 0, c = 0;  // map and slice of the current item
     for (int item = 0; item < items; ++item) {
-      const int n = item / a.C, c = item - n * a.C;
 #ifdef DSPH_STAMPS
       const bool stamp_on = blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
 #endif
@@ -569,9 +570,11 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
       // the next item (of this tile, or the first of this workgroup's next tile) is fetched piece by piece between
       // the phases below: a burst of eight pieces per wave would hold every wave at the address unit for 2-4 k cycles
       const bool more = item + 1 < items || t + nslots < t_end;
-      const int nit = item + 1 < items ? item + 1 : 0;
+      // map and slice of the next item (of this tile, or the first of this workgroup's next tile)
+      const int cn = (c + 1 == a.C || item + 1 == items) ? 0 : c + 1;
+      const int nn = item + 1 == items ? 0 : (c + 1 == a.C ? n + 1 : n);
       if (item + 1 == items && more) set_doffs(t + nslots);
-      if (more) dma_x(integral_constant<int, 0>{}, nit, pxn);
+      if (more) dma_x(integral_constant<int, 0>{}, nn, cn, pxn);
       ST_STAMP(3);
       if (c == 0) {
 #pragma unroll
@@ -581,49 +584,49 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
         asm volatile("" ::: "memory");  // a real branch: as selects the zeroing costs 32 instructions in every item
       }
       // ---- interval k = 1 .. K-1: contract T_{k-1}, compute T_k ---------------------------------------------------
-#define ST_INTERVAL(k, FIRST_, PIN, POUT)                                                                   \
+#define ST_INTERVAL(k, FIRST_, PIN, POUT, CUR, PREV)                                                        \
   {                                                                                                         \
     const unsigned wk = wb + (unsigned)(((k) - 1) * NB * 2048);                                             \
-    st_interval<FIRST_, CHEB, NB, PREC>(smem, PIN, POUT, wk, gb, v, cur, prev, mb0, mb1, lane, acc,         \
+    st_interval<FIRST_, CHEB, NB, PREC>(smem, PIN, POUT, wk, gb, v, CUR, PREV, mb0, mb1, lane, acc,         \
                                         (lact & (1u << (k))) != 0, dummy, [&](int id) {                     \
                                           if ((k) == 2) { ST_STAMP(18 + id); }                              \
                                         });                                                                 \
   }
-      ST_INTERVAL(1, true, px, py)
+      ST_INTERVAL(1, true, px, py, ta, tb)   // ta <- T_0, tb <- T_1
       ST_STAMP(4);
-      if (more) { dma_x(integral_constant<int, 1>{}, nit, pxn); dma_w(0, nit, wbn); }
+      if (more) { dma_x(integral_constant<int, 1>{}, nn, cn, pxn); dma_w(0, cn, wbn); }
       ST_STAMP(5);
       __syncthreads();
       ST_STAMP(6);
       if (a.K > 2) {
-        ST_INTERVAL(2, false, py, px)
+        ST_INTERVAL(2, false, py, px, tb, ta)  // ta <- T_2
         ST_STAMP(7);
-        if (more) { dma_x(integral_constant<int, 2>{}, nit, pxn); dma_w(1, nit, wbn); }
+        if (more) { dma_x(integral_constant<int, 2>{}, nn, cn, pxn); dma_w(1, cn, wbn); }
         ST_STAMP(8);
         __syncthreads();
         ST_STAMP(9);
       }
       if (a.K > 3) {
-        ST_INTERVAL(3, false, px, py)
+        ST_INTERVAL(3, false, px, py, ta, tb)  // tb <- T_3
         ST_STAMP(10);
-        if (more) { dma_x(integral_constant<int, 3>{}, nit, pxn); dma_w(2, nit, wbn); }
+        if (more) { dma_x(integral_constant<int, 3>{}, nn, cn, pxn); dma_w(2, cn, wbn); }
         ST_STAMP(11);
         __syncthreads();
         ST_STAMP(12);
       }
       if (a.K > 4) {
-        ST_INTERVAL(4, false, py, px)
+        ST_INTERVAL(4, false, py, px, tb, ta)  // ta <- T_4
         ST_STAMP(13);
-        if (more) dma_x(integral_constant<int, 4>{}, nit, pxn);
+        if (more) dma_x(integral_constant<int, 4>{}, nn, cn, pxn);
         ST_STAMP(14);
         __syncthreads();
         ST_STAMP(15);
       }
 #undef ST_INTERVAL
       if (more) {  // pieces that the shorter recurrences have not sent yet
-        if (a.K <= 2) { dma_x(integral_constant<int, 2>{}, nit, pxn); dma_w(1, nit, wbn); }
-        if (a.K <= 3) { dma_x(integral_constant<int, 3>{}, nit, pxn); dma_w(2, nit, wbn); }
-        if (a.K <= 4) dma_x(integral_constant<int, 4>{}, nit, pxn);
+        if (a.K <= 2) { dma_x(integral_constant<int, 2>{}, nn, cn, pxn); dma_w(1, cn, wbn); }
+        if (a.K <= 3) { dma_x(integral_constant<int, 3>{}, nn, cn, pxn); dma_w(2, cn, wbn); }
+        if (a.K <= 4) dma_x(integral_constant<int, 4>{}, nn, cn, pxn);
       }
       {  // the last plane
         const unsigned pl = ((a.K - 1) & 1) ? py : px;
@@ -644,6 +647,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a
       ST_STAMP(17);
       px = pxn;
       wb = wbn;
+      n = nn;
+      c = cn;
     }
   }
 }
