@@ -79,41 +79,91 @@ def build_laplacian_masked(nside, device, fraction=1.0 / 3.0):
     return cols, vals.astype(np.float32), lmax
 
 
-def cpu_baseline(K, Fin, Fout, device, budget_s):
-    """The oracle's fp32 port of the reference op sequence on nside=256, one map (1/64 of the
-    headline pixel-batch), all host cores."""
-    from scipy import sparse
+def cpu_baseline(K, Fin, Fout, device, budget_s, nside_headline=1024):
+    """The reference op sequence (gnn_layers.py:131-150) in fp32 on the host cores, every op multi-threaded
+    (oracle/cheb_port.c: OpenMP relayouts and sparse products, BLAS GEMM).  Sample: ONE map of the headline nside
+    when the host has the memory for the reference's materialisations (K + 2 copies of x plus the stacked matrix,
+    ~40 GB at nside 1024), else nside 512; the op is linear in the batch, so Mpix*channels/s does not depend on it."""
+    import psutil
 
     from oracle import cheb_cpu_baseline as cb
 
-    nside_s, N_s = 256, 1
+    cores = os.cpu_count() or 1
+    avail_gb = psutil.virtual_memory().available / 2 ** 30
+    nside_s = nside_headline if avail_gb > 96 else (512 if avail_gb > 28 else 256)
+    N_s = 1
     cols, vals, _ = build_laplacian(nside_s, device)
     M = cols.shape[0]
-    Wd = cols.shape[1]
-    Lt = sparse.csr_matrix((vals.reshape(-1), cols.reshape(-1), np.arange(0, Wd * M + 1, Wd)), shape=(M, M))
     rng = np.random.default_rng(11)
     x = rng.standard_normal((N_s, M, Fin), dtype=np.float32)
     w = (np.random.default_rng(13).standard_normal((Fin * K, Fout)) / np.sqrt(Fin * (K + 0.5) / 2)).astype(np.float32)
-    cores = os.cpu_count() or 1
-    res = cb.time_forward(Lt, x, w, K, budget_s=budget_s / 2, threads=cores)
-    res1 = cb.time_forward_scipy_1thread(Lt, x, w, K, budget_s=budget_s / 2)
-    v_torch = N_s * M * Fout / res["seconds"] / 1e6
-    v_scipy = N_s * M * Fout / res1["seconds"] / 1e6
-    sample = f"nside={nside_s} full-sphere, batch={N_s}, K={K}, Fin={Fin}, Fout={Fout} (1/64 of the headline pixel-batch)"
-    # two ports of gnn_layers.py:131-150 on the same sample; the faster one is the baseline
-    torch_port = {"value": round(v_torch, 3), "cores": int(res["threads"]),
-                  "what": f"torch-CPU fp32 (torch.sparse.mm CSR + matmul), median of {res['reps']} forwards, {res['seconds'] * 1e3:.0f} ms each"}
-    scipy_port = {"value": round(v_scipy, 3), "cores": 1,
-                  "what": f"scipy CSR @ dense + numpy GEMM, BLAS limited to one thread, median of {res1['reps']} forwards, {res1['seconds'] * 1e3:.0f} ms each"}
-    best, other = (scipy_port, torch_port) if v_scipy >= v_torch else (torch_port, scipy_port)
-    return {
-        "value": best["value"],
+    res = cb.time_forward_threaded(cols, vals, x, w, K, threads=cores, budget_s=budget_s * 0.7)
+    v_thr = N_s * M * Fout / res["seconds"] / 1e6
+    out = {
+        "value": round(v_thr, 3),
         "unit": "Mpix*channels/s",
-        "cores": best["cores"],
+        "cores": int(res["threads"]),
         "kind": "port",
-        "sample": f"{sample}; {best['what']}",
-        "other_port": other,
+        "sample": f"nside={nside_s} full-sphere, batch={N_s} (1/{(nside_headline // nside_s) ** 2 * 4} of the headline pixel-batch), "
+                  f"K={K}, Fin={Fin}, Fout={Fout}; OpenMP port of the reference op sequence + BLAS GEMM on {res['threads']} threads, "
+                  f"median of {res['reps']} forwards, {res['seconds'] * 1e3:.0f} ms each; host RAM available {avail_gb:.0f} GiB",
     }
+    # the single-thread scipy figure of round 1, on a small sample, for continuity
+    try:
+        from scipy import sparse
+
+        c2, v2, _ = build_laplacian(256, device)
+        M2, Wd = c2.shape
+        Lt = sparse.csr_matrix((v2.reshape(-1), c2.reshape(-1), np.arange(0, Wd * M2 + 1, Wd)), shape=(M2, M2))
+        x2 = rng.standard_normal((1, M2, Fin), dtype=np.float32)
+        r1 = cb.time_forward_scipy_1thread(Lt, x2, w, K, budget_s=budget_s * 0.15)
+        out["other_port"] = {"value": round(M2 * Fout / r1["seconds"] / 1e6, 3), "cores": 1,
+                             "what": f"scipy CSR @ dense + numpy GEMM on one thread, nside=256, batch=1, {r1['seconds'] * 1e3:.0f} ms"}
+    except Exception as exc:  # noqa: BLE001
+        out["other_port"] = {"error": repr(exc)}
+    return out
+
+
+def measured_error(cols, vals, x, y, w_np, K, nside, seed=3, n_random=24):
+    """max |y - y_ref| / max |y| of the TIMED output against the float64 oracle (used as the checker, after the timed
+    region): the oracle is run on the (K-1)-hop patches around rows in every map -- base-pixel corners and borders,
+    tile corners, first / last rows, random rows."""
+    from scipy import sparse
+
+    from oracle import cheb_oracle as orc
+
+    M = cols.shape[0]
+    ns2 = nside * nside
+    rng = np.random.default_rng(seed)
+    centres = [0, 1, M - 1, ns2 - 1, ns2, min(M - 1, 5 * ns2 + 77)] + [int(v) for v in rng.integers(0, M, size=n_random)]
+    centres += [min(M - 1, f * ns2 + d) for f in range(0, 12, 3) for d in (0, ns2 - 1, ns2 // 2, 255, 256)]
+    centres = np.unique(np.array(centres, dtype=np.int64))
+    region = centres.copy()
+    for _ in range(K - 1):
+        region = np.unique(np.concatenate([region, cols[region][vals[region] != 0]]))
+    lut = -np.ones(M, dtype=np.int64)
+    lut[region] = np.arange(region.size)
+    rc, rv = cols[region], vals[region]
+    keep = (rv != 0) & (lut[rc] >= 0)
+    rows = np.repeat(np.arange(region.size), cols.shape[1]).reshape(rc.shape)
+    sub = sparse.csr_matrix((rv[keep].astype(np.float64), (rows[keep], lut[rc][keep])), shape=(region.size, region.size))
+    xs = x[:, torch.as_tensor(region, device=x.device)].cpu().numpy().astype(np.float64)
+    ref = orc.chebyshev_forward(sub, xs, w_np.astype(np.float64), K)[:, lut[centres]]
+    got = y[:, torch.as_tensor(centres, device=y.device)].cpu().numpy().astype(np.float64)
+    s_max = float(y.abs().max())
+    return float(np.abs(got - ref).max() / s_max), int(centres.size * x.shape[0])
+
+
+def fused_kernel_name(plan, K):
+    """Which kernels one fused forward launches: the structured-tile kernel on the class-R tiles, the BFS-tile kernel
+    on the rest (dsph_plan_tile_counts)."""
+    n_struct, n_bfs = plan.tile_counts(K)
+    parts = []
+    if n_struct:
+        parts.append(f"cheb_struct_kernel ({n_struct} tiles)")
+    if n_bfs:
+        parts.append(f"cheb_fused_kernel ({n_bfs} tiles)")
+    return " + ".join(parts)
 
 
 def main():
@@ -128,7 +178,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = halo rows "
                          "staged through the host, ranks dealt round-robin over the visible GPUs (debugging on a 1-GPU box)")
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline; 0 disables it")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline; 0 disables it")
+    ap.add_argument("--allow-replicas", action="store_true",
+                    help="with --gpus > 1: if the sharded forward fails, time independent replicas instead of exiting non-zero")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,7 +224,7 @@ def main():
             with torch.no_grad():  # inference forward: bias/activation fused in the kernel epilogue
                 return layer(x)
         fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-        kernel_name = "cheb_fused_kernel" if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
+        kernel_name = fused_kernel_name(layer._get_plan(), K) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
     else:
         from deepsphere import sharding
 
@@ -185,7 +237,7 @@ def main():
         x.normal_(generator=gen)
         run = lambda: shard(x)  # noqa: E731
         fused = shard.plan.fused_ok(Fin, Fout, K) and args.algo != "unfused"
-        kernel_name = ("cheb_fused_kernel" if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \
+        kernel_name = (fused_kernel_name(shard.plan, K) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \
             " + rows_pack_kernel + " + \
             ("RCCL send/recv" if args.backend == "nccl" else "gloo send/recv (host-staged)") + " of the (K-1)-ring halo"
     setup_s = time.time() - t0
@@ -213,6 +265,12 @@ def main():
             failed = flag.item() > 0
         except Exception as exc:  # noqa: BLE001
             failed, err = True, err or repr(exc)
+        if failed and not args.allow_replicas:
+            if rank == 0:
+                print(f"bench.py: the sharded forward failed ({err or 'on another rank'}); pass --allow-replicas to time "
+                      "independent replicas instead", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            raise SystemExit(3)
         if failed:
             replicas_note = f"replicas only: the sharded forward failed ({err or 'on another rank'})"
             layer = gnn_layers.Chebyshev.from_prepared_ell(
@@ -224,15 +282,16 @@ def main():
                 with torch.no_grad():
                     return layer(xr)
             fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-            kernel_name = "cheb_fused_kernel" if fused else kernel_name
+            kernel_name = fused_kernel_name(layer._get_plan(), K) if fused else kernel_name
     for _ in range(args.warmup):
         run()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t_start = time.perf_counter()
+    y_timed = None
     for a, b in ev:
         a.record()
-        run()
+        y_timed = run()
         b.record()
     barrier()
     elapsed = time.perf_counter() - t_start
@@ -251,6 +310,14 @@ def main():
         dev_ms = float(np.mean(per_fwd_ms))
         achieved = b_alg / (dev_ms * 1e-3) / 1e9
         traffic = None
+        err_note = ""
+        if world == 1 and not os.environ.get("DSPH_BENCH_NO_CHECK"):
+            # the oracle as the checker of what was just timed (after the timed region): max error over the patches
+            try:
+                e_rel, n_pts = measured_error(cols, vals, x, y_timed, w_np, K, nside)
+                err_note = f"measured max err {e_rel:.2e} of max|y| on {n_pts} (map, row) outputs of the timed run vs the float64 oracle"
+            except Exception as exc:  # noqa: BLE001
+                err_note = f"error measurement failed: {exc!r}"
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -260,7 +327,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mpix*channels/s Chebyshev-conv fwd, nside=1024 K=5 F=64; HBM roofline %",
+            "metric": f"Mpix*channels/s Chebyshev-conv fwd, nside={nside} K={K} F={Fin if Fin == Fout else f'{Fin}->{Fout}'}; HBM roofline %",
             "value": round(value, 2),
             "unit": "Mpix*channels/s",
             "n_gpus": world,
@@ -270,8 +337,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak" if replicas_note else "strong",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else
-            "f32 (recurrence f32; contraction 3-pass split-bf16 MFMA with f32 accumulate, max err 6e-6 of max|y|)",
+            "dtype": ("f32 (recurrence and contraction exact f32: v_mfma_f32_32x32x2_f32" if args.precision == "fp32" else
+                      "f32 (recurrence f32; contraction 3-pass split-bf16 MFMA with f32 accumulate") + (f"; {err_note})" if err_note else ")"),
             "data": "synthetic",
             "config": {
                 "workload": f"nside={nside} {'partial sky (cap of 1/3 of the sphere, nside-8 superpixels)' if args.config in MASKED else 'full-sphere'}, K={K}, Fin={Fin}, Fout={Fout}, batch={N} ({args.config})",
@@ -292,6 +359,7 @@ def main():
                 "frac_of_measured_copy_6290": round(achieved / 6290.0, 4),
                 "median_forward_ms_hip_events": round(float(np.median(per_fwd_ms)), 4),
                 "traffic": traffic,
+                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of tools/measure_round.sh; not re-measured in this run)" if traffic else None,
                 "algorithmic_bytes": b_alg,
                 "avg_forward_ms_hip_events": round(dev_ms, 4),
             },
@@ -307,8 +375,13 @@ def main():
                 run()
             torch.cuda.synchronize()
             ms32 = (time.perf_counter() - t1) / 5 * 1e3
+            f_d = 2.0 * N * M * K * Fin * Fout  # flops of the dense contraction
+            tf32 = f_d / (ms32 * 1e-3) / 1e12
             out["fp32_exact"] = {"ms_per_step": round(ms32, 4), "value": round(N * M * Fout / ms32 / 1e3, 2),
-                                 "note": "contraction on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain)"}
+                                 "note": "the layer's default precision: contraction on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain)",
+                                 "roofline": {"bound": "mfma_f32", "achieved": round(tf32, 2), "peak": 157.3, "unit": "TFLOP/s",
+                                              "frac": round(tf32 / 157.3, 4), "flops": f_d,
+                                              "hbm_frac": round(b_alg / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
         if world == 1:
             # one run with bias + ReLU fused into the kernel epilogue
             layer.precision = args.precision

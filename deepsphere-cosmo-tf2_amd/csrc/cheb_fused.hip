@@ -72,6 +72,7 @@ struct FusedPlan {
   float* d_gdiag = nullptr;
   unsigned char* d_rowflag = nullptr;
   bool rows_tried = false;
+  bool host_released = false;  // DSPH_PREPARE_RELEASE_HOST: no tables for further depths
 };
 
 static int template_width(int w) {
@@ -131,6 +132,10 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   const int key = 2 * D + (full ? 1 : 0);
   auto it = fp->by_depth.find(key);
   if (it != fp->by_depth.end()) return it->second;
+  if (fp->host_released) {  // the ELL arrays are gone: report "not tileable" without caching anything
+    static const FusedTiles none;
+    return none;
+  }
   FusedTiles& ft = fp->by_depth[key];
   ft.D = D;
   ft.width = template_width(plan->width);
@@ -338,6 +343,20 @@ static bool supported_impl(const dsph_plan* plan, int32_t Fin, int32_t Fout, int
 
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
   return supported_impl(plan, Fin, Fout, K, false);
+}
+
+int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags) {
+  if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return DSPH_OK;  // nothing to build: the unfused path serves it
+  (void)get_tiles(plan, K - 1, want_full(plan, Fin, false));
+  if (flags & DSPH_PREPARE_BACKWARD) (void)get_tiles(plan, K - 1, true);
+  if (flags & DSPH_PREPARE_RELEASE_HOST) {
+    FusedPlan* fp = plan->fused;
+    std::lock_guard<std::mutex> lock(fp->mu);
+    std::vector<int32_t>().swap(fp->h_cols);
+    std::vector<float>().swap(fp->h_vals);
+    fp->host_released = true;
+  }
+  return DSPH_OK;
 }
 
 // tiles of the K-term forward by kernel: class R (structured-tile kernel) and class G (BFS-tile kernel)

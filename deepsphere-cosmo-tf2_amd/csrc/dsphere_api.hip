@@ -121,13 +121,27 @@ int dsph_plan_set_levels(dsph_plan* p, int32_t n_levels, const int64_t* rows_at_
   return DSPH_OK;
 }
 
+int dsph_plan_prepare(dsph_plan* p, int32_t K, int32_t Fin, int32_t flags) {
+  if (!p || K <= 0 || Fin <= 0 || (flags & ~(DSPH_PREPARE_BACKWARD | DSPH_PREPARE_RELEASE_HOST))) {
+    set_error("plan_prepare: bad arguments (plan %p, K %d, Fin %d, flags %d)", (void*)p, K, Fin, flags);
+    return DSPH_E_BADARG;
+  }
+  DeviceGuard guard(p->device);
+  if (!guard.ok) { set_error("plan_prepare: cannot select device %d", p->device); return DSPH_E_HIP; }
+  return fused_prepare(p, K, Fin, flags);
+}
+
+// A plan with halo columns and no shrinking schedule cannot run more than one recurrence step by itself: step 2
+// would gather halo entries of T_1 that no step wrote (the fused kernels reject it; the unfused path must too).
+static bool needs_levels(const dsph_plan* p, int32_t K) { return p->n_cols > p->n_rows && K > 2 && p->levels.empty(); }
+
 int64_t dsph_plan_rows(const dsph_plan* p) { return p ? p->n_rows : 0; }
 int64_t dsph_plan_cols(const dsph_plan* p) { return p ? p->n_cols : 0; }
 int32_t dsph_plan_ell_width(const dsph_plan* p) { return p ? p->width : 0; }
 int64_t dsph_plan_out_rows(const dsph_plan* p, int32_t K) { (void)K; return p ? out_rows(p) : 0; }
 
 int dsph_plan_fused_ok(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K) {
-  return (p && fused_supported(p, Fin, Fout, K)) ? 1 : 0;
+  return (p && fused_supported(p, Fin, Fout, K)) ? 1 : 0;  // (tables are built under the plan's device: get_tiles)
 }
 
 int dsph_plan_tile_counts(const dsph_plan* p, int32_t K, int64_t* n_struct, int64_t* n_bfs) {
@@ -219,6 +233,11 @@ int dsph_poly_forward_part(const dsph_plan* p, const float* x, const float* w, c
     set_error("cheb_forward: plan has %d levels, K = %d needs %d", (int)p->levels.size(), K, K - 1);
     return DSPH_E_BADARG;
   }
+  if (needs_levels(p, K)) {
+    set_error("cheb_forward: the plan has %lld halo columns and no levels (dsph_plan_set_levels): K = %d would read halo rows of T_1 that nobody writes",
+              (long long)(p->n_cols - p->n_rows), K);
+    return DSPH_E_BADARG;
+  }
   if (N == 0) return DSPH_OK;
   const int a = resolve_algo(p, Fin, Fout, K, algo);
   if (a < 0) { set_error("cheb_forward: fused kernel cannot run this plan/shape (Fin=%d Fout=%d K=%d)", Fin, Fout, K); return DSPH_E_UNSUPPORTED; }
@@ -271,6 +290,10 @@ int dsph_cheb_planes(const dsph_plan* p, const float* x, float* planes, int64_t 
   }
   if (!p->levels.empty() && (int)p->levels.size() < K - 1) {
     set_error("cheb_planes: plan has %d levels, K = %d needs %d", (int)p->levels.size(), K, K - 1);
+    return DSPH_E_BADARG;
+  }
+  if (needs_levels(p, K)) {
+    set_error("cheb_planes: the plan has halo columns and no levels: K = %d is not computable", K);
     return DSPH_E_BADARG;
   }
   if (N == 0 || K == 1) return DSPH_OK;
@@ -331,9 +354,14 @@ int dsph_cheb_backward_weights(const dsph_plan* p, const float* x, const float* 
     set_error("backward_weights: plan has %d levels, K = %d needs %d", (int)p->levels.size(), K, K - 1);
     return DSPH_E_BADARG;
   }
+  if (needs_levels(p, K)) {
+    set_error("backward_weights: the plan has halo columns and no levels: K = %d is not computable", K);
+    return DSPH_E_BADARG;
+  }
   const float alpha_rest = basis == DSPH_BASIS_CHEBYSHEV ? 2.f : 1.f;
   const float beta_rest = basis == DSPH_BASIS_CHEBYSHEV ? 1.f : 0.f;
   hipStream_t stream = (hipStream_t)hip_stream;
+  DeviceGuard guard0(p->device);  // the tables behind fused_wgrad_supported live on the plan's device
   const bool can_fuse = fused_wgrad_supported(p, Fin, Fout, K);
   if (algo == DSPH_ALGO_FUSED && !can_fuse) {
     set_error("backward_weights: fused kernel cannot run this plan/shape (Fin=%d Fout=%d K=%d)", Fin, Fout, K);

@@ -18,6 +18,7 @@ ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 PREC_FP32, PREC_BF16X3 = 0, 1
 ALGO_AUTO, ALGO_UNFUSED, ALGO_FUSED = 0, 1, 2
 PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
+PREPARE_BACKWARD, PREPARE_RELEASE_HOST = 1, 2
 BASIS_CHEBYSHEV, BASIS_MONOMIAL = 0, 1
 
 _c_i64 = ctypes.c_int64
@@ -36,6 +37,7 @@ SIGNATURES = {
     "dsph_plan_ell_width": (_c_i32, [_c_vp]),
     "dsph_plan_out_rows": (_c_i64, [_c_vp, _c_i32]),
     "dsph_plan_fused_ok": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
+    "dsph_plan_prepare": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
     "dsph_plan_tile_counts": (ctypes.c_int, [_c_vp, _c_i32, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
     "dsph_workspace_bytes": (ctypes.c_size_t, [_c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32]),
     "dsph_cheb_forward": (
@@ -169,6 +171,12 @@ class LaplacianPlan:
 
     def fused_ok(self, Fin, Fout, K):
         return bool(lib().dsph_plan_fused_ok(self.handle, int(Fin), int(Fout), int(K)))
+
+    def prepare(self, K, Fin, backward=False, release_host=False):
+        """Build the fused kernels' tables for a K-term layer now (``dsph_plan_prepare``): afterwards a forward
+        neither allocates nor synchronises, so it can be timed and captured into a graph."""
+        flags = (PREPARE_BACKWARD if backward else 0) | (PREPARE_RELEASE_HOST if release_host else 0)
+        check(lib().dsph_plan_prepare(self.handle, int(K), int(Fin), flags), "dsph_plan_prepare")
 
     def tile_counts(self, K):
         """(tiles run by the structured-tile kernel, tiles run by the BFS-tile kernel) of a K-term fused forward."""

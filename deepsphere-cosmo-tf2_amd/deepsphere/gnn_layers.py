@@ -253,10 +253,13 @@ class Chebyshev(torch.nn.Module):
         return self._plan_t
 
     # -- forward --------------------------------------------------------------------------------
-    def forward(self, input_tensor, training=None):
+    def forward(self, input_tensor, training=False):
         """
         :param input_tensor: (batch, M, Fin) tensor or array; cast to float32 like Keras does
-        :param training: batch-norm mode; defaults to the module's ``self.training``
+        :param training: batch-norm mode.  Default False like the reference's ``call(input_tensor, training=False)``
+            (gnn_layers.py:106): a direct ``layer(x)`` normalises with the moving statistics and leaves them
+            untouched, whatever ``module.training`` says; pass ``training=True`` (``HealpyGCNN`` forwards its own
+            argument) to use and update batch statistics.  ``None`` means "follow ``self.training``" (torch style).
         :return: (batch, M, Fout) float32 tensor on the layer's device
         """
         if not isinstance(input_tensor, torch.Tensor):
@@ -272,6 +275,10 @@ class Chebyshev(torch.nn.Module):
         if Fin != self._Fin:
             raise ValueError(f"layer was built for Fin = {self._Fin}, got {Fin}")
         plan = self._get_plan()
+        if getattr(self, "_prepared", None) != (self.K, Fin):
+            # tile tables now, not inside the first kernel launch (allocation + synchronisation: dsph_plan_prepare)
+            plan.prepare(self.K, Fin)
+            self._prepared = (self.K, Fin)
         wants_grad = torch.is_grad_enabled() and (
             self.kernel.requires_grad or input_tensor.requires_grad or (self.use_bias and self.bias.requires_grad))
         if wants_grad:
@@ -436,7 +443,7 @@ class GCNN_ResidualLayer(torch.nn.Module):
             return mod(x)
         raise NotImplementedError("layer_norm over non-trailing axes")
 
-    def forward(self, input_tensor, training=None):
+    def forward(self, input_tensor, training=False):
         if not isinstance(input_tensor, torch.Tensor):
             input_tensor = torch.as_tensor(np.asarray(input_tensor))
         x = self.layer1(input_tensor, training=training)

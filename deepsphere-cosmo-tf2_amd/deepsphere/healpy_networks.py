@@ -105,7 +105,7 @@ class HealpyGCNN(torch.nn.Sequential):
         per = (nside_out // nside_in) ** 2
         return (indices[:, None] * per + np.arange(per, dtype=np.int64)[None, :]).reshape(-1)
 
-    def forward(self, input_tensor, training=None):
+    def forward(self, input_tensor, training=False):
         x = input_tensor
         for layer in self:
             if isinstance(layer, (gnn.Chebyshev, gnn.GCNN_ResidualLayer)):

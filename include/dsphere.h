@@ -8,7 +8,14 @@
  * types.  All device pointers are HIP device memory on the plan's device; the caller
  * (PyTorch) owns x, w, bias, y and the workspace.  Functions return 0 on success or a
  * negative DSPH_E_* code; the message is available from dsph_last_error() (thread-local).
- * Nothing here allocates, frees or synchronises inside dsph_cheb_* (graph-capture safe).
+ *
+ * Allocation and synchronisation: dsph_plan_create, dsph_plan_prepare, dsph_plan_set_levels and
+ * dsph_plan_destroy allocate / free device memory and synchronise.  The compute entry points
+ * (dsph_cheb_*, dsph_poly_*, dsph_rows_*) only enqueue kernels on the caller's stream -- EXCEPT that
+ * the first fused call for a (plan, K) that has not been through dsph_plan_prepare builds the tile
+ * tables on the spot (device allocation + synchronous copies).  Call dsph_plan_prepare once per K
+ * before timing, and before capturing a forward into a hipGraph; after it, a forward neither
+ * allocates nor synchronises (tests/test_gpu_parity.py::test_prepared_forward_*).
  */
 #ifndef DSPHERE_H
 #define DSPHERE_H
@@ -80,6 +87,20 @@ void dsph_plan_destroy(dsph_plan* plan);
  * Host array, copied. */
 int dsph_plan_set_levels(dsph_plan* plan, int32_t n_levels, const int64_t* rows_at_level);
 
+/* Build everything the fused kernels need from this plan for a K-term layer with Fin input channels, now
+ * instead of inside the first forward: the direction-ordered copy of L~ and the per-row / per-tile verification
+ * of the 2-D stencil structure (structured-tile kernel), and the breadth-first ring tables of the remaining
+ * tiles (BFS-tile kernel).  Allocates device memory, launches set-up kernels and synchronises.
+ *   flags  DSPH_PREPARE_BACKWARD      also the tables of dsph_cheb_planes / dsph_cheb_backward_weights
+ *          DSPH_PREPARE_RELEASE_HOST  afterwards drop the plan's host copy of the ELL arrays (kept by
+ *                                     dsph_plan_create to build tables for further K); preparing another K
+ *                                     later then fails with DSPH_E_UNSUPPORTED and forwards with that K take
+ *                                     the unfused path under DSPH_ALGO_AUTO
+ * Returns DSPH_OK also when the fused kernels cannot run the plan (dsph_plan_fused_ok says which). */
+#define DSPH_PREPARE_BACKWARD 1
+#define DSPH_PREPARE_RELEASE_HOST 2
+int dsph_plan_prepare(dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
+
 int64_t dsph_plan_rows(const dsph_plan* plan);
 int64_t dsph_plan_cols(const dsph_plan* plan);
 int32_t dsph_plan_ell_width(const dsph_plan* plan);
@@ -140,6 +161,11 @@ int dsph_poly_forward_part(const dsph_plan* plan, const float* x, const float* w
  * where the host exchanges boundary rows between steps, and for tests. */
 int dsph_cheb_step(const dsph_plan* plan, const float* in, const float* prev, float* out,
                    int64_t N, int32_t F, float alpha, float beta, int64_t rows, void* hip_stream);
+/* Note on plans with halo columns (n_cols > n_rows): a step writes rows [0, rows) only, so a SECOND step would
+ * gather halo entries nobody produced.  The multi-step entry points (dsph_cheb_forward / dsph_poly_forward*,
+ * dsph_cheb_planes, dsph_cheb_backward_weights) therefore return DSPH_E_BADARG for K > 2 on such a plan unless a
+ * shrinking schedule was installed with dsph_plan_set_levels; drive dsph_cheb_step yourself, exchanging the halo
+ * between steps, for the one-ring-per-step mode. */
 
 /* The dense contraction alone on K planes of shape (N, plane_rows, Fin), plane k at
  * planes[k] (device pointers in a HOST array of K entries):

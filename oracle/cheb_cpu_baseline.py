@@ -92,3 +92,91 @@ def time_forward_scipy_1thread(Lt, x_np, kernel_np, K, budget_s=10.0):
         if time.perf_counter() - t_all > budget_s or len(times) >= 3:
             break
     return {"seconds": float(np.median(times)), "reps": len(times), "y": y}
+
+
+# ---- multi-threaded port (oracle/cheb_port.c): the figure bench.py reports as cpu_baseline ----------------------
+
+_PORT = None
+
+
+def load_port():
+    """Compile (gcc -O3 -march=native -fopenmp, on the box it runs on) and load oracle/cheb_port.c."""
+    global _PORT
+    if _PORT is not None:
+        return _PORT
+    import ctypes
+    import os
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    out_dir = os.path.join(here, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libcheb_port.so")
+    src = os.path.join(here, "cheb_port.c")
+    cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", src, "-o", so]
+    lib = None
+    if os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src):
+        try:
+            lib = ctypes.CDLL(so)
+        except OSError:
+            lib = None
+    if lib is None:
+        subprocess.run(cmd, check=True)
+        lib = ctypes.CDLL(so)
+    i64, vp, f32, i32 = ctypes.c_int64, ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+    lib.port_relayout_in.argtypes = [vp, vp, i64, i64, i64, i32]
+    lib.port_spmm.argtypes = [vp, vp, i64, i64, vp, vp, vp, i64, f32, f32, i32]
+    lib.port_relayout_out.argtypes = [vp, vp, i64, i64, i64, i64, i32]
+    for fn in (lib.port_relayout_in, lib.port_spmm, lib.port_relayout_out):
+        fn.restype = None
+    _PORT = lib
+    return lib
+
+
+def forward_threaded(ell_cols, ell_vals, x_np, kernel_np, K, threads):
+    """The reference op sequence (gnn_layers.py:131-150) with every op spread over `threads` host threads:
+    relayout, K-1 sparse products with the axpy, stack + transposes, dense GEMM (numpy -> BLAS threads)."""
+    import ctypes
+
+    lib = load_port()
+    N, M, Fin = x_np.shape
+    W = ell_cols.shape[1]
+    cols = np.ascontiguousarray(ell_cols, dtype=np.int32)
+    vals = np.ascontiguousarray(ell_vals, dtype=np.float32)
+    x = np.ascontiguousarray(x_np, dtype=np.float32)
+    C = Fin * N
+    p = lambda a: a.ctypes.data  # noqa: E731
+    planes = [np.empty((M, C), dtype=np.float32)]
+    lib.port_relayout_in(p(x), p(planes[0]), N, M, Fin, threads)
+    if K > 1:
+        planes.append(np.empty((M, C), dtype=np.float32))
+        lib.port_spmm(p(cols), p(vals), M, W, p(planes[0]), None, p(planes[1]), C, 1.0, 0.0, threads)
+    for k in range(2, K):
+        planes.append(np.empty((M, C), dtype=np.float32))
+        lib.port_spmm(p(cols), p(vals), M, W, p(planes[k - 1]), p(planes[k - 2]), p(planes[k]), C, 2.0, 1.0, threads)
+    X = np.empty((N * M, Fin * K), dtype=np.float32)
+    arr = (ctypes.c_void_p * K)(*[p(a) for a in planes])
+    lib.port_relayout_out(arr, p(X), K, N, M, Fin, threads)
+    return (X @ np.ascontiguousarray(kernel_np, dtype=np.float32)).reshape(N, M, -1)
+
+
+def time_forward_threaded(ell_cols, ell_vals, x_np, kernel_np, K, threads, budget_s=20.0):
+    import time
+
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=int(threads))
+    except Exception:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    times = []
+    t_all = time.perf_counter()
+    with ctx:
+        y = forward_threaded(ell_cols, ell_vals, x_np[:1], kernel_np, K, threads)  # warm-up, one map
+        while True:
+            t0 = time.perf_counter()
+            y = forward_threaded(ell_cols, ell_vals, x_np, kernel_np, K, threads)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > budget_s or len(times) >= 5:
+                break
+    return {"seconds": float(np.median(times)), "reps": len(times), "threads": int(threads), "y": y}
