@@ -1,5 +1,5 @@
 """T4: pixel-range sharding.  Layout consistency on one process, and the halo exchange end to end
-under gloo with world_size 2 (CPU): the exchange moves real bytes between the two processes, the
+under gloo with world_size 2, 4 and 8 (CPU): the exchange moves real bytes between the two processes, the
 per-shard compute is the float64 oracle injected through the test seam, and the stitched result
 must equal the unsharded oracle."""
 
@@ -107,20 +107,23 @@ def _worker(rank, world, port, K, partial, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,partial", [(5, False), (3, True)])
-def test_two_process_halo_exchange_gloo(K, partial):
+# world 2: the basic exchange; world 4, K 8: BASELINE configs[3]'s split (3 base pixels per rank, 7-ring halo);
+# world 8, partial sky: configs[4]'s (the sorted index list cut into 8 chunks); world 8 full sphere: quarter base pixels
+@pytest.mark.parametrize("world,K,partial", [(2, 5, False), (2, 3, True), (4, 8, False), (8, 5, True), (8, 5, False)])
+def test_halo_exchange_gloo(world, K, partial):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, K, partial, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, K, partial, out)) for r in range(world)]
     for p in procs:
         p.start()
-    res = out.get(timeout=120)
+    res = out.get(timeout=240)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
+    assert len(res) == world
     for err, halo_ok in res:
         assert halo_ok == 1.0
         assert err < 1e-12
