@@ -414,11 +414,26 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
                       size_t workspace_bytes, hipStream_t stream, int32_t part) {
   // more than 64 output columns: one launch per 64-column block (the recurrence is repeated; still one pass
   // over x per block instead of the unfused path's K planes through HBM)
+  // The structured-tile kernel fuses bias and ReLU; with any other activation both fused kernels write the pre-activation
+  // and one elementwise pass finishes y (only when class-R tiles exist: the BFS-tile kernel knows every activation).
+  bool defer_act = false;
+  if (act != DSPH_ACT_NONE && act != DSPH_ACT_RELU && K - 1 <= FUSED_DMAX && K >= 2) {
+    const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
+    defer_act = ft.ok && ft.n_r > 0;
+  }
+  if (defer_act && part != 0) {
+    set_error("cheb_fused: interior / boundary launches support the activations NONE and RELU only");
+    return DSPH_E_UNSUPPORTED;
+  }
   for (int32_t cb = 0; cb < Fout; cb += 64) {
     const int rc = launch_fused_common(plan, x, w + cb, bias ? bias + cb : nullptr, y + cb, nullptr, N, Fin,
-                                       std::min<int32_t>(64, Fout - cb), K, act, precision, alpha_rest, beta_rest,
-                                       workspace, workspace_bytes, stream, nullptr, nullptr, Fout, part);
+                                       std::min<int32_t>(64, Fout - cb), K, defer_act ? DSPH_ACT_NONE : act, precision,
+                                       alpha_rest, beta_rest, workspace, workspace_bytes, stream, nullptr, nullptr, Fout, part);
     if (rc != DSPH_OK) return rc;
+  }
+  if (defer_act) {
+    const int64_t orows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
+    return launch_struct_act(y, N * orows, Fout, Fout, act, stream);
   }
   return DSPH_OK;
 }
@@ -520,7 +535,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   // ---- class-R tiles: the structured-tile kernel (forward only) ------------------------------------------------
   if (!planes_mode && ft.n_r > 0) {
     const int nr = part == 0 ? ft.n_r : (part == 1 ? ft.n_r_interior : ft.n_r - ft.n_r_interior);
-    if (nr > 0) {
+    if (nr > 0 && !(getenv("DSPH_DBG_ONLY") && getenv("DSPH_DBG_ONLY")[0] == 'b')) {
       StructLaunch sl;
       sl.x = x; sl.w = w; sl.bias = bias; sl.y = y;
       sl.wfrag = static_cast<unsigned char*>(workspace) + wb;
@@ -538,7 +553,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       if (rc != DSPH_OK) return rc;
     }
     const int ng = part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior);
-    if (ng == 0) return DSPH_OK;
+    if (ng == 0 || (getenv("DSPH_DBG_ONLY") && getenv("DSPH_DBG_ONLY")[0] == 's')) return DSPH_OK;
   }
   if (!planes_mode) {
     hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,

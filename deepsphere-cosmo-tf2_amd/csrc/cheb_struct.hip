@@ -130,6 +130,24 @@ int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, in
 }
 
 // (the kernel addresses x by 32-bit byte offsets inside a map: struct_map_ok())
+// The activations the structured-tile kernel does not apply itself (it fuses bias and ReLU only): one elementwise
+// pass over a (rows x cols) block of y with row stride ld.
+__global__ __launch_bounds__(256) void struct_act_kernel(float* __restrict__ y, int64_t rows, int cols, int ld, int act) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * cols) return;
+  const int64_t r = e / cols;
+  const int c = (int)(e - r * cols);
+  y[r * ld + c] = apply_act(y[r * ld + c], act);
+}
+
+int launch_struct_act(float* y, int64_t rows, int32_t cols, int32_t ld, int32_t act, hipStream_t stream) {
+  const int64_t total = rows * cols;
+  if (total <= 0) return DSPH_OK;
+  hipLaunchKernelGGL(struct_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, rows, (int)cols, (int)ld, (int)act);
+  DSPH_HIP(hipGetLastError());
+  return DSPH_OK;
+}
+
 bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K) {
   const int NB = (Fout + 31) / 32;
   return K >= 2 && K - 1 <= ST_DMAX && Fin >= 4 && Fin % 4 == 0 && Fout >= 1 && Fout <= 64 &&

@@ -16,11 +16,14 @@
 //     once per tile instead of a 6 B x 9 x region-rows tile-local table;
 //   * x arrives by LDS-DMA (global_load_lds_dwordx4) into a third plane one item ahead: no staging registers,
 //     no staging stores; the weight fragments of the next slice are streamed the same way (20 KiB x 2);
-//   * plane T_{k-1} is contracted (MFMA) in the same barrier interval in which step k reads it; the two waves of
-//     a SIMD take the two halves of the interval in opposite order, so one gathers while the other feeds the
-//     matrix pipe;
+//   * twelve waves in two roles (three per SIMD, 168 registers each).  Waves 0-7 run the recurrence and nothing
+//     else.  Waves 8-11 -- one per SIMD -- contract plane T_{k-1} (MFMA, 64 pixels x 64 columns each) in the same
+//     barrier interval in which step k reads it, issue every LDS-DMA piece (a vector-memory instruction holds the
+//     issuing wave for hundreds of cycles), and store y.  The last plane of an item is contracted, and a finished map
+//     stored, under the FIRST step of the next item, so nothing but the recurrence is on the critical path;
 //   * the contraction is transposed (A = weight fragment, B = plane fragment): the accumulator holds 4 consecutive
-//     output channels of ONE pixel per register quad, so y is stored by dwordx4 straight from the registers.
+//     output channels of ONE pixel per register quad; y goes through a 4 KiB transposition block -- the wave's own
+//     64 tile cells of the plane it has just contracted -- so that eight lanes store 128 contiguous bytes.
 //
 // Cell (gx, gy) of a plane, gx, gy in [0, 24): cell index (gx & 1) * HP + gy * P2 + (gx >> 1) ("column-parity
 // split": the 2x2 blocks all have odd origins, so in a plain row-major plane the four blocks read together by a
@@ -43,11 +46,14 @@ constexpr int ST_P2 = 13;                       // cells per half-row (12 + 1 pa
 constexpr int ST_HP = ST_S * ST_P2;             // cells per column-parity half
 constexpr int ST_CELLS = 2 * ST_HP;             // 624 (48 of them padding)
 constexpr int ST_PLANE_BYTES = ST_CELLS * 64;   // 39,936
-constexpr int ST_THREADS = 512;
+constexpr int ST_GATHER_WAVES = 8;              // waves 0..7: the recurrence
+constexpr int ST_CONTRACT_WAVES = 4;            // waves 8..11: contraction, LDS-DMA, y
+constexpr int ST_THREADS = 64 * (ST_GATHER_WAVES + ST_CONTRACT_WAVES);  // 768: three waves per SIMD
 constexpr int ST_WSLICE_BYTES = 20480;          // weight fragments of one slice: K * NB * 2048 <= 20480
 constexpr int ST_LDS_W = 3 * ST_PLANE_BYTES;    // 119,808
 constexpr int ST_LDS_BIAS = ST_LDS_W + 2 * ST_WSLICE_BYTES;  // 160,768
-constexpr int ST_LDS_TOTAL = ST_LDS_BIAS + 256;              // 161,024 of 163,840
+constexpr int ST_LDS_ROWS = ST_LDS_BIAS + 256;               // byte offset, inside a map, of the x row of every plane cell
+constexpr int ST_LDS_TOTAL = ST_LDS_ROWS + ST_CELLS * 4;     // 163,520 of 163,840
 constexpr int ST_DMA_PIECES = ST_CELLS / 16;    // 39 wave-instructions of 1 KiB fill a plane
 
 typedef float st_f32x16 __attribute__((ext_vector_type(16)));
@@ -78,7 +84,7 @@ struct StructArgs {
       unsigned long long t_;                                                               \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
       __builtin_amdgcn_sched_barrier(0);                                                   \
-      if (lane == 0) a.stamps[((size_t)wave * 8 + (item - 4)) * 32 + (id)] = t_;           \
+      if (lane == 0) a.stamps[((size_t)(wave < 8 ? wave : 7) * 8 + (item - 4)) * 32 + (id)] = t_;  \
     }                                                                                      \
   } while (0)
 #else
@@ -129,7 +135,13 @@ __device__ __forceinline__ void st_glds16(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 // the same with a wave-uniform 64-bit base and a 32-bit byte offset per lane
-__device__ __forceinline__ void st_glds16_off(const void* sbase, unsigned voff, unsigned lds_dst) {
+__device__ __forceinline__ void st_glds16_off(const void* sbase_in, unsigned voff, unsigned lds_dst) {
+  // the base is uniform by construction; say so, or the "s" operand is refused whenever hipcc keeps it in a VGPR
+  const unsigned long long bits = reinterpret_cast<unsigned long long>(sbase_in);
+  // (readfirstlane returns int: through unsigned, or the low half sign-extends into the high one)
+  const unsigned long long ubits = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bits) |
+                                   ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bits >> 32)) << 32);
+  const void* sbase = reinterpret_cast<const void*>(ubits);
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -138,122 +150,17 @@ __device__ __forceinline__ void st_glds16_off(const void* sbase, unsigned voff, 
       : "memory");
 }
 
-// One recurrence step for this lane's 2x2 block: window from plane `pin` (byte offset), new values to `pout`.
-//   FIRST: T_1 = L~ T_0, the block's own T_0 is read too (16 reads); otherwise the centre of the window is `cur`.
-//   CHEB : T_k = 2 L~ T_{k-1} - T_{k-2}
+// One recurrence step for this lane's 2x2 block (gather waves): window from plane `pin` (byte offset), T_k to `pout`.
+//   FIRST: T_1 = L~ T_0, the block's own T_0 is read too (16 reads) and kept in `cur`; otherwise the centre of the
+//          window is `cur` (T_{k-1} of the lane's own pixels, in registers since the previous step)
+//   CHEB : T_k = 2 L~ T_{k-1} - T_{k-2}, with T_{k-2} in `prev`
+// T_k replaces T_{k-2} in `prev`: the caller swaps the roles of the two arrays from step to step, nothing is moved.
+// `wr`: this lane's block is part of step k; the others compute on whatever their cells hold and store into a pad
+// cell of the output plane (`dummy`) instead of branching.
 template <bool FIRST, bool CHEB>
 __device__ __forceinline__ void st_gather(const unsigned char* __restrict__ smem, unsigned pin, unsigned pout,
                                           const unsigned (&gb)[4], const float (&v)[4][9], float4 (&cur)[4],
-                                          float4 (&prev)[4]) {
-  // Two halves, so that at most 8 + 4 window cells are in registers at a time: the pixels of the block's upper row
-  // need window rows 0..2, those of the lower row need rows 1..3 (row 3 is fetched while the upper row is summed).
-  float4 W[4][4];
-  auto rd = [&](int wx, int wy) {
-    W[wy][wx] = *reinterpret_cast<const float4*>(smem + (gb[st_cell_f(wx, wy)] + pin) + st_woff(wx, wy));
-  };
-#pragma unroll
-  for (int wy = 0; wy < 3; ++wy)
-#pragma unroll
-    for (int wx = 0; wx < 4; ++wx) {
-      const bool centre = (wx == 1 || wx == 2) && (wy == 1 || wy == 2);
-      if (centre && !FIRST) W[wy][wx] = cur[(wy - 1) * 2 + (wx - 1)];
-      else rd(wx, wy);
-    }
-  auto pixel = [&](int p) {
-    const int i = p & 1, j = p >> 1;
-    const float4 c = W[j + 1][i + 1];
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    s.x = fmaf(v[p][0], c.x, s.x);
-    s.y = fmaf(v[p][0], c.y, s.y);
-    s.z = fmaf(v[p][0], c.z, s.z);
-    s.w = fmaf(v[p][0], c.w, s.w);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      const float4 u = W[j + 1 + kDirY[d]][i + 1 + kDirX[d]];
-      const float w = v[p][d + 1];
-      s.x = fmaf(w, u.x, s.x);
-      s.y = fmaf(w, u.y, s.y);
-      s.z = fmaf(w, u.z, s.z);
-      s.w = fmaf(w, u.w, s.w);
-    }
-    if (!FIRST && CHEB) {
-      const float4 q = prev[p];
-      s.x = 2.f * s.x - q.x;
-      s.y = 2.f * s.y - q.y;
-      s.z = 2.f * s.z - q.z;
-      s.w = 2.f * s.w - q.w;
-    }
-    prev[p] = c;
-    cur[p] = s;
-    *reinterpret_cast<float4*>(const_cast<unsigned char*>(smem) + (gb[st_cell_f(i + 1, j + 1)] + pout) +
-                               st_woff(i + 1, j + 1)) = s;
-  };
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int wx = 0; wx < 4; ++wx) rd(wx, 3);
-  // the lower pixels' T_{k-1} (rows 1, 2 of the window) are still needed below: pixel() overwrites cur[] only
-  pixel(0);
-  pixel(1);
-  __builtin_amdgcn_sched_barrier(0);
-  pixel(2);
-  pixel(3);
-}
-
-// Plane T_k (this wave's 32 tile pixels, 16 channels) into the accumulators: acc[b] += Wfrag(k, b)^T-form product.
-// mb0 / mb1: byte offsets (inside a plane) of this lane's two 16-byte slots (channels 8h..8h+3 and 8h+4..8h+7).
-template <int NB, int PREC>
-__device__ __forceinline__ void st_contract(const unsigned char* __restrict__ smem, unsigned plane, unsigned wblk,
-                                            unsigned mb0, unsigned mb1, int lane, st_f32x16 (&acc)[NB]) {
-  const float4 a0 = *reinterpret_cast<const float4*>(smem + plane + mb0);
-  const float4 a1 = *reinterpret_cast<const float4*>(smem + plane + mb1);
-  const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-  if (PREC == DSPH_PREC_BF16X3) {
-    st_bf16x8 whi[NB], wlo[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      whi[b] = *reinterpret_cast<const st_bf16x8*>(smem + wblk + b * 2048 + lane * 16);
-      wlo[b] = *reinterpret_cast<const st_bf16x8*>(smem + wblk + b * 2048 + 1024 + lane * 16);
-    }
-    st_bf16x8 thi, tlo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const __bf16 hi = (__bf16)av[j];
-      thi[j] = hi;
-      tlo[j] = (__bf16)(av[j] - (float)hi);
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[b], tlo, acc[b], 0, 0, 0);  // small terms first
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[b], thi, acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[b], thi, acc[b], 0, 0, 0);
-    }
-  } else {
-    float wf[NB][8];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const float4 w0 = *reinterpret_cast<const float4*>(smem + wblk + b * 2048 + lane * 16);
-      const float4 w1 = *reinterpret_cast<const float4*>(smem + wblk + b * 2048 + 1024 + lane * 16);
-      wf[b][0] = w0.x; wf[b][1] = w0.y; wf[b][2] = w0.z; wf[b][3] = w0.w;
-      wf[b][4] = w1.x; wf[b][5] = w1.y; wf[b][6] = w1.z; wf[b][7] = w1.w;
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[b][t], av[t], acc[b], 0, 0, 0);
-  }
-}
-
-// Contract T_{k-1} and compute T_k in one straight-line block of three phases (fenced for the scheduler, so that the
-// live ranges stay what the source says): A every LDS read that does not depend on anything; B the upper pixel row's
-// multiply-adds with the first column block's MFMAs underneath; C the lower pixel row with the second block's.
-// `wr`: this lane's block is part of step k (the others compute on whatever their cells hold and write to a pad cell).
-template <bool FIRST, bool CHEB, int NB, int PREC, class StampFn>
-__device__ __forceinline__ void st_interval(const unsigned char* __restrict__ smem, unsigned pin, unsigned pout,
-                                            unsigned wblk, const unsigned (&gb)[4], const float (&v)[4][9],
-                                            float4 (&cur)[4], float4 (&prev)[4], unsigned mb0, unsigned mb1, int lane,
-                                            st_f32x16 (&acc)[NB], bool wr, unsigned dummy, StampFn stamp) {
-  // lanes whose block is not part of this step store into a pad cell of the output plane instead of branching:
-  // the interval stays one basic block, which is what lets the scheduler put the MFMAs under the multiply-adds
+                                          float4 (&prev)[4], bool wr, unsigned dummy) {
   unsigned ob[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
@@ -262,6 +169,7 @@ __device__ __forceinline__ void st_interval(const unsigned char* __restrict__ sm
   auto rd = [&](int wx, int wy) {
     W[wy][wx] = *reinterpret_cast<const float4*>(smem + (gb[st_cell_f(wx, wy)] + pin) + st_woff(wx, wy));
   };
+  // The sum of a pixel runs in the unfused kernel's order: the diagonal, then the eight directions.
   auto pixel = [&](int p) {
     const int i = p & 1, j = p >> 1;
     const float4 c = W[j + 1][i + 1];
@@ -286,15 +194,12 @@ __device__ __forceinline__ void st_interval(const unsigned char* __restrict__ sm
       s.z = 2.f * s.z - q.z;
       s.w = 2.f * s.w - q.w;
     }
-    if (FIRST) cur[p] = c;  // the block's own T_0, read from the plane in this step only
-    prev[p] = s;            // T_k takes the place of T_{k-2}: the caller swaps the two arrays' roles, no moves
+    if (FIRST) cur[p] = c;
+    prev[p] = s;
     *reinterpret_cast<float4*>(const_cast<unsigned char*>(smem) + ob[p]) = s;
   };
-  // ---- A: reads ---------------------------------------------------------------------------------------------------
-  const float4 a0 = *reinterpret_cast<const float4*>(smem + pin + mb0);
-  const float4 a1 = *reinterpret_cast<const float4*>(smem + pin + mb1);
-  const unsigned char* __restrict__ wp = smem + wblk + lane * 16;
-  float4 w0h = *reinterpret_cast<const float4*>(wp), w0l = *reinterpret_cast<const float4*>(wp + 1024);
+  // two halves, so that at most 8 + 4 window cells are in registers at a time: the upper pixel row needs window rows
+  // 0..2, the lower one rows 1..3 (row 3 is fetched while the upper row is summed)
 #pragma unroll
   for (int wy = 0; wy < 3; ++wy)
 #pragma unroll
@@ -304,353 +209,463 @@ __device__ __forceinline__ void st_interval(const unsigned char* __restrict__ sm
       else rd(wx, wy);
     }
   __builtin_amdgcn_sched_barrier(0);
-  stamp(0);
-  // ---- B: first column block under the upper pixel row ------------------------------------------------------------
-  const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-  st_bf16x8 thi, tlo;
-  if (PREC == DSPH_PREC_BF16X3) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const __bf16 hi = (__bf16)av[j];
-      thi[j] = hi;
-      tlo[j] = (__bf16)(av[j] - (float)hi);
-    }
-  }
-  auto mfma_block = [&](int b, const float4& wh, const float4& wl) {
-    if (PREC == DSPH_PREC_BF16X3) {
-      const st_bf16x8 whi = __builtin_bit_cast(st_bf16x8, wh), wlo = __builtin_bit_cast(st_bf16x8, wl);
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, tlo, acc[b], 0, 0, 0);  // small terms first
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, thi, acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, thi, acc[b], 0, 0, 0);
-    } else {
-      const float wf[8] = {wh.x, wh.y, wh.z, wh.w, wl.x, wl.y, wl.z, wl.w};
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[t], av[t], acc[b], 0, 0, 0);
-    }
-  };
 #pragma unroll
   for (int wx = 0; wx < 4; ++wx) rd(wx, 3);
-  // the MFMAs are issued in front of the pixels' multiply-adds and run underneath them
-  mfma_block(0, w0h, w0l);
-  if (NB == 2) {  // the second block's fragments take over the first one's registers
-    w0h = *reinterpret_cast<const float4*>(wp + 2048);
-    w0l = *reinterpret_cast<const float4*>(wp + 2048 + 1024);
-  }
   pixel(0);
   pixel(1);
-  if (PREC == DSPH_PREC_FP32) {  // eight 64-cycle MFMAs per phase: one, then a run of the pixels' multiply-adds, and so on
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
-    }
-  }
   __builtin_amdgcn_sched_barrier(0);
-  stamp(1);
-  // ---- C: second column block under the lower pixel row -----------------------------------------------------------
-  if (NB == 2) mfma_block(1, w0h, w0l);
   pixel(2);
   pixel(3);
-  if (PREC == DSPH_PREC_FP32 && NB == 2) {
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-    }
-  }
 }
 
-// y of one map.  The accumulators hold, per lane (pixel r, half h), register quad tq of block b = output channels
-// 32 b + 8 tq + 4 h .. + 3: stored as they stand a wave instruction touches 32 rows x 2 x 16 B (measured: 250-500
-// cycles of issue per instruction, every wave at once).  They go through a 32 x 32 block of LDS instead (the plane that
-// no longer holds anything: free until the next item's first step), so that eight lanes write 128 contiguous bytes.
-constexpr int ST_SCR_PITCH = 144;                      // bytes per pixel row of the block (32 floats + 4 pad)
-constexpr int ST_SCR_WAVE = 32 * ST_SCR_PITCH;         // 4,608 B per wave; 8 waves = 36,864 <= ST_PLANE_BYTES
-template <int NB, int ACT, bool VEC>
-__device__ __forceinline__ void st_store(const st_f32x16 (&acc)[NB], unsigned char* __restrict__ scr,
-                                         float* __restrict__ ytile, int ld, const float* __restrict__ sBias, int wave,
-                                         int lane, int Fout, int act_rt) {
-  const int act = ACT >= 0 ? ACT : act_rt;
-  const int r = lane & 31, h = lane >> 5;
-  const int j = lane & 7, pq = lane >> 3;
+// Plane T_k into the accumulators of a contraction wave: its 64 tile pixels (two 32-pixel blocks, pixel rows
+// 4c .. 4c+3 of the tile) x 16 channels against the fragments of (order k, slice) at `wblk`.
+// mb[pb]: byte offset inside a plane of this lane's first 16-byte slot (channels 8h .. 8h+3) for pixel block pb; the
+// second slot (channels 8h+4 .. 8h+7) is the first one's address with bit 4 flipped (the slots are XOR-swizzled).
+template <int NB, int PREC>
+__device__ __forceinline__ void st_contract(const unsigned char* __restrict__ smem, unsigned plane, unsigned wblk,
+                                            const unsigned (&mb)[2], int lane, st_f32x16 (&acc)[2][NB]) {
+  float4 a[2][2];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
+  for (int pb = 0; pb < 2; ++pb) {
+    a[pb][0] = *reinterpret_cast<const float4*>(smem + plane + mb[pb]);
+    a[pb][1] = *reinterpret_cast<const float4*>(smem + plane + (mb[pb] ^ 16u));
+  }
+  const unsigned char* __restrict__ wp = smem + wblk + lane * 16;
+  if (PREC == DSPH_PREC_BF16X3) {
+    st_bf16x8 whi[NB], wlo[NB];
 #pragma unroll
-    for (int tq = 0; tq < 4; ++tq)
-      *reinterpret_cast<float4*>(scr + r * ST_SCR_PITCH + (8 * tq + 4 * h) * 4) =
-          make_float4(acc[b][4 * tq + 0], acc[b][4 * tq + 1], acc[b][4 * tq + 2], acc[b][4 * tq + 3]);
-    const int ch = 32 * b + 4 * j;
-    const float4 bv = *reinterpret_cast<const float4*>(sBias + ch);
+    for (int b = 0; b < NB; ++b) {
+      whi[b] = *reinterpret_cast<const st_bf16x8*>(wp + b * 2048);
+      wlo[b] = *reinterpret_cast<const st_bf16x8*>(wp + b * 2048 + 1024);
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = pq + 8 * i;  // pixel (p & 15, 2 wave + (p >> 4)) of the tile
-      float4 o = *reinterpret_cast<const float4*>(scr + p * ST_SCR_PITCH + 16 * j);
-      o.x = apply_act(o.x + bv.x, act);
-      o.y = apply_act(o.y + bv.y, act);
-      o.z = apply_act(o.z + bv.z, act);
-      o.w = apply_act(o.w + bv.w, act);
-      float* __restrict__ yp = ytile + (int64_t)st_morton((unsigned)(p & 15), (unsigned)(2 * wave + (p >> 4))) * ld + ch;
-      if (VEC) {
-        if (ch < Fout) *reinterpret_cast<float4*>(yp) = o;
-      } else {
-        if (ch + 0 < Fout) yp[0] = o.x;
-        if (ch + 1 < Fout) yp[1] = o.y;
-        if (ch + 2 < Fout) yp[2] = o.z;
-        if (ch + 3 < Fout) yp[3] = o.w;
+    for (int pb = 0; pb < 2; ++pb) {
+      const float av[8] = {a[pb][0].x, a[pb][0].y, a[pb][0].z, a[pb][0].w, a[pb][1].x, a[pb][1].y, a[pb][1].z, a[pb][1].w};
+      st_bf16x8 thi, tlo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 hi = (__bf16)av[j];
+        thi[j] = hi;
+        tlo[j] = (__bf16)(av[j] - (float)hi);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[b], tlo, acc[pb][b], 0, 0, 0);  // small terms first
+        acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[b], thi, acc[pb][b], 0, 0, 0);
+        acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[b], thi, acc[pb][b], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float4 w0 = *reinterpret_cast<const float4*>(wp + b * 2048);
+      const float4 w1 = *reinterpret_cast<const float4*>(wp + b * 2048 + 1024);
+      const float wf[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const float av[8] = {a[pb][0].x, a[pb][0].y, a[pb][0].z, a[pb][0].w, a[pb][1].x, a[pb][1].y, a[pb][1].z, a[pb][1].w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[t], av[t], acc[pb][b], 0, 0, 0);
       }
     }
   }
 }
 
+// y of one map for a contraction wave's 64 pixels.  The accumulators hold, per lane (pixel r of block pb, half h),
+// register quad tq of column block b = output channels 32 b + 8 tq + 4 h .. + 3: stored as they stand a wave
+// instruction would touch 32 rows x 2 x 16 B (250-500 cycles of issue each).  They go through a 32 x 32 block of LDS
+// first -- the wave's own 64 tile cells (4 KiB) of the plane it has just contracted, which nobody else reads any more
+// and which no LDS-DMA piece may touch before the next barrier -- so that eight lanes store 128 contiguous bytes.
+// The block's 16-byte units are XOR-ed with the pixel's low bits: conflict-free stores and loads without padding.
+// Epilogue: bias, then max(., floor) with floor = 0 (ReLU) or -inf (none): the other activations of the ABI are applied
+// by a separate elementwise pass (cheb_struct.hip), so this is ONE code path instead of one per activation.
+template <int NB>
+__device__ __forceinline__ void st_store(const st_f32x16 (&acc)[2][NB], unsigned char* __restrict__ smem, unsigned plane,
+                                         int cw, float* __restrict__ ytile, int ld, const float* __restrict__ sBias,
+                                         int lane, int Fout, float floor_v, bool vec) {
+  const unsigned r = lane & 31, h = lane >> 5, j = lane & 7, pq = lane >> 3;
+  // byte a of the 4 KiB block lives in chunk a >> 9 (512 B = the 8 cells of one column parity of one tile pixel row)
+  auto scr = [&](unsigned a) -> unsigned {
+    const unsigned chunk = a >> 9, row = chunk >> 1, par = chunk & 1;
+    return plane + ((par * ST_HP + (ST_DMAX + 4 * cw + row) * ST_P2 + ST_DMAX / 2) * 64u) + (a & 511u);
+  };
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      __builtin_amdgcn_sched_barrier(0);  // one block at a time: overlapping them only costs registers
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq)
+        *reinterpret_cast<float4*>(smem + scr(r * 128u + 16u * ((2u * tq + h) ^ (r & 7u)))) =
+            make_float4(acc[pb][b][4 * tq + 0], acc[pb][b][4 * tq + 1], acc[pb][b][4 * tq + 2], acc[pb][b][4 * tq + 3]);
+      const int ch = 32 * b + 4 * (int)j;
+      const float4 bv = *reinterpret_cast<const float4*>(sBias + ch);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned p = pq + 8 * i;  // pixel (p & 15, 4 cw + 2 pb + (p >> 4)) of the tile
+        float4 o = *reinterpret_cast<const float4*>(smem + scr(p * 128u + 16u * (j ^ (p & 7u))));
+        o.x = fmaxf(o.x + bv.x, floor_v);
+        o.y = fmaxf(o.y + bv.y, floor_v);
+        o.z = fmaxf(o.z + bv.z, floor_v);
+        o.w = fmaxf(o.w + bv.w, floor_v);
+        float* __restrict__ yp = ytile + (int64_t)st_morton(p & 15u, 4u * cw + 2u * pb + (p >> 4)) * ld + ch;
+        if (vec) {
+          if (ch < Fout) *reinterpret_cast<float4*>(yp) = o;
+        } else {
+          if (ch + 0 < Fout) yp[0] = o.x;
+          if (ch + 1 < Fout) yp[1] = o.y;
+          if (ch + 2 < Fout) yp[2] = o.z;
+          if (ch + 3 < Fout) yp[3] = o.w;
+        }
+      }
+    }
+}
+
+// x piece `piece` (1 KiB: cells 16 piece .. 16 piece + 15 of the plane) as lane `lane` sees it: bits 0..1 the logical
+// 16-byte slot it fetches (the stored one is XOR-swizzled), bit 2 set when the cell exists and lies inside the D-ring region.
+__device__ __forceinline__ unsigned st_piece_info(int piece, int lane, int D) {
+  const unsigned p = 16u * piece + (lane >> 2);
+  const unsigned par = p / ST_HP, rem = p % ST_HP, gxh = rem % ST_P2, gy = rem / ST_P2, gx = 2 * gxh + par;
+  const int lo = ST_DMAX - D, hi = ST_DMAX + ST_TILE - 1 + D;
+  const bool ok = piece < ST_DMA_PIECES && gxh < ST_S / 2 && (int)gx >= lo && (int)gx <= hi && (int)gy >= lo && (int)gy <= hi;
+  return ((lane & 3u) ^ st_cell_f(gx, gy)) | (ok ? 4u : 0u);
+}
+// The 39 x pieces of an item are issued by both roles, in proportion to the slack they have (a piece holds the issuing
+// wave for 250-300 cycles): pieces 0..19 by the eight recurrence waves (wave w: w, w+8, w+16), pieces 20..38 by the
+// four contraction waves (wave c: 20+c, 24+c, ...), which also issue the 20 weight pieces.
+constexpr int ST_GPIECES = 20;
+
 template <int NB, int PREC, bool CHEB>
-__global__ __launch_bounds__(ST_THREADS, 2) void cheb_struct_kernel(StructArgs a) {
+__global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[ST_LDS_TOTAL];
   float* const sBias = reinterpret_cast<float*>(smem + ST_LDS_BIAS);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar registers, "s" asm operands
+  const bool gather = wave < ST_GATHER_WAVES;
+  const int cw = wave - ST_GATHER_WAVES;  // contraction wave 0..3
   const int D = a.K - 1;
   if (tid < 64) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
-
-  // ---- gather role: quad -> 2x2 block (odd origin), lane -> 16-byte slot ------------------------------------
-  const unsigned blk = kStructBlock[tid >> 2];
-  const bool has_blk = blk != 0xffu;
-  const int bx = has_blk ? (int)(blk & 15u) : 0, by = has_blk ? (int)(blk >> 4) : 0;
-  const unsigned q = tid & 3;
-  unsigned gb[4];  // byte offset of the window's top-left cell (2bx, 2by), slot q ^ f, f = 0..3
-#pragma unroll
-  for (unsigned f = 0; f < 4; ++f) gb[f] = st_cell_off(2 * bx, 2 * by) + 16u * (q ^ f);
-  // first / last block index (per axis) that step j touches: region [4-(D-j), 19+(D-j)], block b = cells 2b+1, 2b+2
-  auto step_lo = [&](int j) { return (4 - (D - j) - 1) >> 1; };
-  auto step_hi = [&](int j) { return (19 + (D - j) - 1) >> 1; };
-  auto active_at = [&](int j) {
-    const int lo = step_lo(j), hi = step_hi(j);
-    return has_blk && bx >= lo && bx <= hi && by >= lo && by <= hi;
-  };
-
-  // ---- contraction role: wave w owns tile pixel rows 2w, 2w+1; lane (r, h): pixel r, channels 8h..8h+7 ---------
-  const unsigned mr = lane & 31, mh = lane >> 5;
-  const unsigned mpx = mr & 15, mpy = 2 * wave + (mr >> 4);
-  const unsigned mgx = ST_DMAX + mpx, mgy = ST_DMAX + mpy;
-  const unsigned mb0 = st_cell_off(mgx, mgy) + 16u * ((2 * mh) ^ st_cell_f(mgx, mgy));
-  const unsigned mb1 = st_cell_off(mgx, mgy) + 16u * ((2 * mh + 1) ^ st_cell_f(mgx, mgy));
-
-  // ---- DMA role: wave w issues pieces w, w+8, ...; lane l fills slot l & 3 of cell 16 i + (l >> 2) of the plane --
-  constexpr int NP = (ST_DMA_PIECES + 7) / 8;  // 5
-  // cell (gx, gy) and logical slot of piece s of this lane; valid: inside the plane and inside the D-ring region
-  auto dma_cell = [&](int s, unsigned& gx, unsigned& gy, unsigned& slot) -> bool {
-    const int piece = wave + 8 * s;
-    const unsigned p = 16u * piece + (lane >> 2);
-    const unsigned par = p / ST_HP, rem = p % ST_HP, gxh = rem % ST_P2;
-    gy = rem / ST_P2;
-    gx = 2 * gxh + par;
-    slot = (lane & 3u) ^ st_cell_f(gx, gy);
-    const int lo = ST_DMAX - D, hi = ST_DMAX + ST_TILE - 1 + D;
-    return piece < ST_DMA_PIECES && gxh < ST_S / 2 && (int)gx >= lo && (int)gx <= hi && (int)gy >= lo && (int)gy <= hi;
-  };
-  unsigned dinfo = 0;  // per piece s: bits 3s..3s+1 logical slot, bit 3s+2 valid
-#pragma unroll
-  for (int s = 0; s < NP; ++s) {
-    unsigned gx, gy, slot;
-    const bool ok = dma_cell(s, gx, gy, slot);
-    dinfo |= (slot | (ok ? 4u : 0u)) << (3 * s);
-  }
 
   // tiles are dealt to XCDs in contiguous ranges (blocks b and b+8 share an XCD and its L2)
   const int G = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
   const int nslots = (G + 7 - xcd) / 8;
   const int t_begin = (int)((int64_t)a.ntiles * xcd / 8), t_end = (int)((int64_t)a.ntiles * (xcd + 1) / 8);
   const int items = a.N * a.C;
+  constexpr unsigned py = ST_PLANE_BYTES;  // the Y plane; X alternates between planes 0 and 2
+  if (t_begin + slot0 >= t_end) return;
+
+  if (gather) {
+    // =================================================================================================================
+    // waves 0..7: the recurrence.  Quad -> 2x2 block (odd origin), lane -> 16-byte slot.
+    // =================================================================================================================
+#ifdef DSPH_ST_GPRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(DSPH_ST_GPRIO);  // the younger recurrence wave of each SIMD
+#endif
+    const int gtid = tid;  // 0..511
+    const unsigned blk = kStructBlock[gtid >> 2];
+    const bool has_blk = blk != 0xffu;
+    const int bx = has_blk ? (int)(blk & 15u) : 0, by = has_blk ? (int)(blk >> 4) : 0;
+    const unsigned q = gtid & 3;
+    unsigned gb[4];  // byte offset of the window's top-left cell (2bx, 2by), slot q ^ f, f = 0..3
+#pragma unroll
+    for (unsigned f = 0; f < 4; ++f) gb[f] = st_cell_off(2 * bx, 2 * by) + 16u * (q ^ f);
+    // block b covers cells 2b+1, 2b+2; step j computes the region [4-(D-j), 19+(D-j)]
+    unsigned lact = 0;  // bit k: this lane's block is part of step k
+#pragma unroll
+    for (int k = 1; k <= ST_DMAX; ++k) {
+      const int lo = (ST_DMAX - (D - k) - 1) >> 1, hi = (ST_DMAX + ST_TILE - 1 + (D - k) - 1) >> 1;
+      const bool on = k <= D && has_blk && bx >= lo && bx <= hi && by >= lo && by <= hi;
+      lact |= on ? (1u << k) : 0u;
+    }
+    // where the other lanes' stores go: the pad cell (half-row index 12) of their window's second row, own slot
+    const unsigned dummy = (unsigned)((2 * by + 1) * ST_P2 + ST_S / 2) * 64u + 16u * q;
+
+    // this wave's x pieces of the NEXT item: w, w + 8, w + 16 (< ST_GPIECES), one per interval 2, 3, 4
+    unsigned ginfo = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int piece = wave + 8 * s;
+      ginfo |= (piece < ST_GPIECES ? st_piece_info(piece, lane, D) : 0u) << (3 * s);
+    }
+    const unsigned* const sRowG = reinterpret_cast<const unsigned*>(smem + ST_LDS_ROWS);
+    const bool raggedG = (a.Fin & 15) != 0;
+    auto gdma = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
+      constexpr int s = decltype(s_c)::value;
+      const int piece = wave + 8 * s;
+      const float* __restrict__ base = a.x + ((int64_t)n * a.x_rows * a.Fin + c * 16);
+      unsigned off = sRowG[16 * piece + (lane >> 2)] + 16u * ((ginfo >> (3 * s)) & 3u);
+      if (raggedG) {
+        const int ch0 = c * 16 + 4 * (int)((ginfo >> (3 * s)) & 3u);
+        if (ch0 >= a.Fin) off -= (unsigned)(ch0 - (a.Fin - 4)) * 4u;
+      }
+      if ((ginfo >> (3 * s)) & 4u) st_glds16_off(base, off, __builtin_amdgcn_readfirstlane(pdst + 1024u * (unsigned)piece));
+    };
+    using std::integral_constant;
+    float v[4][9];
+    float4 ta[4], tb[4];  // T_{k-1} and T_{k-2} of this lane's four pixels, in alternating roles
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ta[p] = tb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned px = 0;
+    __syncthreads();  // the contraction waves' row table (prologue)
+    gdma(integral_constant<int, 0>{}, 0, 0, px);
+    gdma(integral_constant<int, 1>{}, 0, 0, px);
+    gdma(integral_constant<int, 2>{}, 0, 0, px);
+    for (int t = t_begin + slot0; t < t_end; t += nslots) {
+      const unsigned row0 = (unsigned)a.tiles[t] * 256u;
+      {  // L~ values of this lane's four pixels (blocks that no step touches load a valid row and never use it)
+        const unsigned X0 = st_compress(row0), Y0 = st_compress(row0 >> 1);
+        const bool ld_ok = (lact & 2u) != 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const unsigned gx = 2 * bx + 1 + (p & 1), gy = 2 * by + 1 + (p >> 1);
+          const unsigned rid = ld_ok ? st_morton(X0 + gx - ST_DMAX, Y0 + gy - ST_DMAX) : row0;
+          const float4 n0 = *reinterpret_cast<const float4*>(a.gvals8 + (size_t)rid * 8);
+          const float4 n1 = *reinterpret_cast<const float4*>(a.gvals8 + (size_t)rid * 8 + 4);
+          v[p][0] = a.gdiag[rid];
+          v[p][1] = n0.x; v[p][2] = n0.y; v[p][3] = n0.z; v[p][4] = n0.w;
+          v[p][5] = n1.x; v[p][6] = n1.y; v[p][7] = n1.z; v[p][8] = n1.w;
+        }
+      }
+      int n = 0, c = 0;  // map and slice of the current item
+      for (int item = 0; item < items; ++item) {
+#ifdef DSPH_STAMPS
+        const bool stamp_on = wave < 7 && blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
+#endif
+        ST_STAMP(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the item's x slice
+        __syncthreads();  // B_a: the whole slice and the weights have landed
+        ST_STAMP(1);
+        const unsigned pxn = px ^ (2u * ST_PLANE_BYTES);
+        const bool more = item + 1 < items || t + nslots < t_end;
+        const int cn = (c + 1 == a.C || item + 1 == items) ? 0 : c + 1;
+        const int nn = item + 1 == items ? 0 : (c + 1 == a.C ? n + 1 : n);
+        st_gather<true, false>(smem, px, py, gb, v, ta, tb, (lact & 2u) != 0, dummy);  // ta <- T_0, tb <- T_1
+        ST_STAMP(2);
+        __syncthreads();
+        ST_STAMP(3);
+        if (a.K > 2) {
+          st_gather<false, CHEB>(smem, py, px, gb, v, tb, ta, (lact & 4u) != 0, dummy);  // ta <- T_2
+          if (more) gdma(integral_constant<int, 0>{}, nn, cn, pxn);
+          ST_STAMP(4);
+          __syncthreads();
+          ST_STAMP(5);
+        }
+        if (a.K > 3) {
+          st_gather<false, CHEB>(smem, px, py, gb, v, ta, tb, (lact & 8u) != 0, dummy);  // tb <- T_3
+          if (more) gdma(integral_constant<int, 1>{}, nn, cn, pxn);
+          ST_STAMP(6);
+          __syncthreads();
+          ST_STAMP(7);
+        }
+        if (a.K > 4) {
+          st_gather<false, CHEB>(smem, py, px, gb, v, tb, ta, (lact & 16u) != 0, dummy);  // ta <- T_4
+          if (more) gdma(integral_constant<int, 2>{}, nn, cn, pxn);
+          ST_STAMP(8);
+          __syncthreads();
+          ST_STAMP(9);
+        }
+        if (more) {  // pieces that the shorter recurrences have not sent yet
+          if (a.K <= 2) gdma(integral_constant<int, 0>{}, nn, cn, pxn);
+          if (a.K <= 3) gdma(integral_constant<int, 1>{}, nn, cn, pxn);
+          if (a.K <= 4) gdma(integral_constant<int, 2>{}, nn, cn, pxn);
+        }
+        px = pxn;
+        n = nn;
+        c = cn;
+      }
+    }
+    return;
+  }
+
+  // ===================================================================================================================
+  // waves 8..11: contraction, LDS-DMA, y.  Wave c owns tile pixel rows 4c .. 4c+3; lane (r, h) of pixel block pb:
+  // pixel (r & 15, 4c + 2pb + (r >> 4)), channels 8h .. 8h+7.
+  // ===================================================================================================================
+  // One wave per SIMD next to two recurrence waves, and the youngest of the three: at equal priority it gets the issue
+  // slots the other two leave (its 8 LDS reads queue behind their 256, its bf16 split waits for their multiply-adds)
+  // and every interval then ends when IT arrives at the barrier (1.9 k cycles per plane instead of 0.8 k).
+  __builtin_amdgcn_s_setprio(3);
+  const unsigned mr = lane & 31, mh = lane >> 5;
+  unsigned mb[2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const unsigned gx = ST_DMAX + (mr & 15), gy = ST_DMAX + 4 * cw + 2 * pb + (mr >> 4);
+    mb[pb] = st_cell_off(gx, gy) + 16u * ((2 * mh) ^ st_cell_f(gx, gy));
+  }
+  // LDS-DMA: wave c issues x pieces c, c+4, ...; lane l fills slot l & 3 of cell 16 piece + (l >> 2) of the plane
+  constexpr int NPX = (ST_DMA_PIECES - ST_GPIECES + ST_CONTRACT_WAVES - 1) / ST_CONTRACT_WAVES;  // 5
+  unsigned dinfo = 0;  // per piece s: bits 3s..3s+1 logical slot, bit 3s+2 valid
+#pragma unroll
+  for (int s = 0; s < NPX; ++s) dinfo |= st_piece_info(ST_GPIECES + cw + ST_CONTRACT_WAVES * s, lane, D) << (3 * s);
   const int wslice = a.K * NB * 2048;  // bytes of one slice's fragments
   const int wpieces = wslice / 1024;
   const bool vec_ok = (a.Fout % 4 == 0) && (a.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
-
-  // per-lane activity: bit k = this lane's block is part of step k
-  unsigned lact = 0;
-#pragma unroll
-  for (int k = 1; k <= ST_DMAX; ++k) lact |= (k <= D && active_at(k)) ? (1u << k) : 0u;
-  // where the other lanes' stores go: the pad cell (half-row index 12) of their window's second row, own slot
-  const unsigned dummy = (unsigned)((2 * by + 1) * ST_P2 + ST_S / 2) * 64u + 16u * q;
-
-  // byte offsets (from the map's first element) of the x pieces this lane fetches, for the tile being PREFETCHED
-  // (the host admits only maps of less than 4 GiB to this kernel)
-  unsigned doff[NP];
-  auto set_doffs = [&](int tpos) {
+  const bool ragged = (a.Fin & 15) != 0;  // the last slice has channels past Fin: they are read from valid channels
+  // Byte offsets (from the map's first element) of the x rows of the region cells of the tile being PREFETCHED, in LDS:
+  // ten offsets per lane in registers (and what hipcc hoists around them) cost the contraction role 40 spilled registers.
+  // Rebuilt by the four contraction waves in the first interval of a tile's last item, used from the second interval on
+  // (a barrier lies between).  The host admits only maps of less than 4 GiB to this kernel.
+  unsigned* const sRow = reinterpret_cast<unsigned*>(smem + ST_LDS_ROWS);
+  auto build_rows = [&](int tpos) __attribute__((always_inline)) {
     const unsigned row0 = (unsigned)a.tiles[tpos] * 256u;
     const unsigned X0 = st_compress(row0), Y0 = st_compress(row0 >> 1);
-#pragma unroll
-    for (int s = 0; s < NP; ++s) {
-      unsigned gx, gy, slot;
-      const bool ok = dma_cell(s, gx, gy, slot);
+    const int lo = ST_DMAX - D, hi = ST_DMAX + ST_TILE - 1 + D;
+    for (unsigned p = (unsigned)(tid - 64 * ST_GATHER_WAVES); p < (unsigned)ST_CELLS; p += 64 * ST_CONTRACT_WAVES) {
+      const unsigned par = p / ST_HP, rem = p % ST_HP, gxh = rem % ST_P2, gy = rem / ST_P2, gx = 2 * gxh + par;
+      const bool ok = gxh < ST_S / 2 && (int)gx >= lo && (int)gx <= hi && (int)gy >= lo && (int)gy <= hi;
       const unsigned rid = ok ? st_morton(X0 + gx - ST_DMAX, Y0 + gy - ST_DMAX) : row0;
-      doff[s] = (rid * (unsigned)a.Fin + 4u * slot) * 4u;
+      sRow[p] = rid * (unsigned)a.Fin * 4u;
     }
   };
-  const bool ragged = (a.Fin & 15) != 0;  // the last slice has channels past Fin: they are read from valid channels
-  // piece s (compile-time) of the x slice of item `it` -> plane at pdst
-  auto dma_x = [&](auto s_c, int n, int c, unsigned pdst) {
+  using std::integral_constant;
+  // piece s (compile-time) of the x slice of item (n, c) -> plane at pdst
+  auto dma_x = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
     constexpr int s = decltype(s_c)::value;
     const float* __restrict__ base = a.x + ((int64_t)n * a.x_rows * a.Fin + c * 16);
-    unsigned off = doff[s];
+    constexpr int piece_base = ST_GPIECES + ST_CONTRACT_WAVES * s;
+    unsigned off = sRow[16 * (piece_base + cw) + (lane >> 2)] + 16u * ((dinfo >> (3 * s)) & 3u);
     if (ragged) {
       const int ch0 = c * 16 + 4 * (int)((dinfo >> (3 * s)) & 3u);
       if (ch0 >= a.Fin) off -= (unsigned)(ch0 - (a.Fin - 4)) * 4u;  // meets zero weights
     }
     if ((dinfo >> (3 * s)) & 4u)
-      st_glds16_off(base, off, __builtin_amdgcn_readfirstlane(pdst + 1024u * (unsigned)(wave + 8 * s)));
+      st_glds16_off(base, off, __builtin_amdgcn_readfirstlane(pdst + 1024u * (unsigned)(piece_base + cw)));
   };
-  // piece u of this wave's share of the weight fragments of item `it`'s slice -> buffer at wdst
-  auto dma_w = [&](int u, int c, unsigned wdst) {
-    const int j = wave + 8 * u;
-    if (j < wpieces) {
+  // piece u of this wave's share of the weight fragments of slice c -> buffer at wdst
+  auto dma_w = [&](int u, int c, unsigned wdst) __attribute__((always_inline)) {
+    const int j = cw + ST_CONTRACT_WAVES * u;
+    if (j < wpieces)
       st_glds16_off(a.wfrag + (size_t)c * wslice + 1024 * j, (unsigned)lane * 16u,
                     __builtin_amdgcn_readfirstlane(wdst + 1024u * (unsigned)j));
+  };
+  // a group of pieces of the next item; groups 0, 1, 2 go out in the intervals 2, 3, 4 (not earlier: until the barrier
+  // that ends interval 1 the previous item's last plane and weights are still being contracted out of those buffers)
+  auto dma_group = [&](int g, int n, int c, unsigned pdst, unsigned wdst) __attribute__((always_inline)) {
+    if (g == 0) {
+      dma_x(integral_constant<int, 0>{}, n, c, pdst); dma_x(integral_constant<int, 1>{}, n, c, pdst);
+      dma_w(0, c, wdst); dma_w(1, c, wdst);
+    } else if (g == 1) {
+      dma_x(integral_constant<int, 2>{}, n, c, pdst); dma_x(integral_constant<int, 3>{}, n, c, pdst);
+      dma_w(2, c, wdst); dma_w(3, c, wdst);
+    } else {
+      dma_x(integral_constant<int, 4>{}, n, c, pdst);
+      dma_w(4, c, wdst);
     }
   };
-  using std::integral_constant;
 
-  st_f32x16 acc[NB];
-  float v[4][9];
-  float4 ta[4], tb[4];  // T_{k-1} and T_{k-2} of this lane's four pixels, in alternating roles
+  st_f32x16 acc[2][NB];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) ta[p] = tb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pb][b][r] = 0.f;
 
   int t = t_begin + slot0;
-  if (t >= t_end) return;
   unsigned px = 0;         // byte offset of the X plane of the current item (plane 0 or 2); Y is plane 1
   unsigned wb = ST_LDS_W;  // weight buffer of the current item
-  constexpr unsigned py = ST_PLANE_BYTES;
-  set_doffs(t);
-  dma_x(integral_constant<int, 0>{}, 0, 0, px);
-  dma_x(integral_constant<int, 1>{}, 0, 0, px);
-  dma_x(integral_constant<int, 2>{}, 0, 0, px);
-  dma_x(integral_constant<int, 3>{}, 0, 0, px);
-  dma_x(integral_constant<int, 4>{}, 0, 0, px);
-  for (int u = 0; u < 3; ++u) dma_w(u, 0, wb);
-#ifdef DSPH_ST_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(DSPH_ST_PRIO);  // the second wave of every SIMD: see Makefile
-#endif
-  bool stored = false;  // the previous item ended with this wave's y stores (the youngest vector-memory operations)
+  build_rows(t);
+  __syncthreads();  // (prologue only; the gather waves meet it below)
+  dma_group(0, 0, 0, px, wb);
+  dma_group(1, 0, 0, px, wb);
+  dma_group(2, 0, 0, px, wb);
+  // the last plane of the previous item, still to be contracted (under the first step of the current one)
+  bool pend = false, pend_store = false;
+  unsigned pend_plane = 0, pend_w = 0, pend_row0 = 0;
+  int pend_n = 0;
+  auto flush_pending = [&]() __attribute__((always_inline)) {
+    if (!pend) return;
+    st_contract<NB, PREC>(smem, pend_plane, pend_w, mb, lane, acc);
+    if (pend_store) {  // that completed a map: y, then fresh accumulators
+      float* __restrict__ yt = a.y + ((int64_t)pend_n * a.y_rows + pend_row0) * a.ld;
+      st_store<NB>(acc, smem, pend_plane, cw, yt, a.ld, sBias, lane, a.Fout,
+                   a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf(), vec_ok);
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[pb][b][r] = 0.f;
+    }
+    pend = false;
+  };
 
   for (; t < t_end; t += nslots) {
     const unsigned row0 = (unsigned)a.tiles[t] * 256u;
-    {  // L~ values of this lane's four pixels (blocks that no step touches keep zeros and load nothing)
-      const unsigned X0 = st_compress(row0), Y0 = st_compress(row0 >> 1);
-      const bool ld_ok = (lact & 2u) != 0;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const unsigned gx = 2 * bx + 1 + (p & 1), gy = 2 * by + 1 + (p >> 1);
-        const unsigned rid = ld_ok ? st_morton(X0 + gx - ST_DMAX, Y0 + gy - ST_DMAX) : row0;
-        const float4 n0 = *reinterpret_cast<const float4*>(a.gvals8 + (size_t)rid * 8);
-        const float4 n1 = *reinterpret_cast<const float4*>(a.gvals8 + (size_t)rid * 8 + 4);
-        v[p][0] = a.gdiag[rid];
-        v[p][1] = n0.x; v[p][2] = n0.y; v[p][3] = n0.z; v[p][4] = n0.w;
-        v[p][5] = n1.x; v[p][6] = n1.y; v[p][7] = n1.z; v[p][8] = n1.w;
-      }
-    }
     int n = 0, c = 0;  // map and slice of the current item
     for (int item = 0; item < items; ++item) {
 #ifdef DSPH_STAMPS
-      const bool stamp_on = blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
+      const bool stamp_on = cw == 0 && blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
 #endif
       ST_STAMP(0);
-      // ---- B_a: this item's x slice and weights have landed (the y stores just issued may still be in flight);
-      //      every LDS read of the previous item is done ------------------------------------------------------------
-      if (stored && vec_ok) {
-        if (NB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      // ---- B_a: this wave's pieces of the item's x slice and weights have landed ----------------------------------------
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       ST_STAMP(1);
       __syncthreads();
       ST_STAMP(2);
       const unsigned pxn = px ^ (2u * ST_PLANE_BYTES);
       const unsigned wbn = wb == (unsigned)ST_LDS_W ? (unsigned)(ST_LDS_W + ST_WSLICE_BYTES) : (unsigned)ST_LDS_W;
-      // the next item (of this tile, or the first of this workgroup's next tile) is fetched piece by piece between
-      // the phases below: a burst of eight pieces per wave would hold every wave at the address unit for 2-4 k cycles
       const bool more = item + 1 < items || t + nslots < t_end;
       // map and slice of the next item (of this tile, or the first of this workgroup's next tile)
       const int cn = (c + 1 == a.C || item + 1 == items) ? 0 : c + 1;
       const int nn = item + 1 == items ? 0 : (c + 1 == a.C ? n + 1 : n);
-      if (item + 1 == items && more) set_doffs(t + nslots);
-      if (more) dma_x(integral_constant<int, 0>{}, nn, cn, pxn);
+      // ---- interval 1: the previous item's last plane (and y of a finished map), then T_0 ----------------------------------
+      if (item + 1 == items && more) build_rows(t + nslots);
+      flush_pending();
       ST_STAMP(3);
-      if (c == 0) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-        asm volatile("" ::: "memory");  // a real branch: as selects the zeroing costs 32 instructions in every item
-      }
-      // ---- interval k = 1 .. K-1: contract T_{k-1}, compute T_k ---------------------------------------------------
-#define ST_INTERVAL(k, FIRST_, PIN, POUT, CUR, PREV)                                                        \
-  {                                                                                                         \
-    const unsigned wk = wb + (unsigned)(((k) - 1) * NB * 2048);                                             \
-    st_interval<FIRST_, CHEB, NB, PREC>(smem, PIN, POUT, wk, gb, v, CUR, PREV, mb0, mb1, lane, acc,         \
-                                        (lact & (1u << (k))) != 0, dummy, [&](int id) {                     \
-                                          if ((k) == 2) { ST_STAMP(18 + id); }                              \
-                                        });                                                                 \
-  }
-      ST_INTERVAL(1, true, px, py, ta, tb)   // ta <- T_0, tb <- T_1
+      st_contract<NB, PREC>(smem, px, wb, mb, lane, acc);
       ST_STAMP(4);
-      if (more) { dma_x(integral_constant<int, 1>{}, nn, cn, pxn); dma_w(0, cn, wbn); }
-      ST_STAMP(5);
       __syncthreads();
-      ST_STAMP(6);
+      ST_STAMP(5);
+      // ---- intervals 2 .. K-1: T_{k-1}, and the next item's pieces ---------------------------------------------------------
       if (a.K > 2) {
-        ST_INTERVAL(2, false, py, px, tb, ta)  // ta <- T_2
+        st_contract<NB, PREC>(smem, py, wb + (unsigned)(1 * NB * 2048), mb, lane, acc);
+        ST_STAMP(6);
+        if (more) dma_group(0, nn, cn, pxn, wbn);
         ST_STAMP(7);
-        if (more) { dma_x(integral_constant<int, 2>{}, nn, cn, pxn); dma_w(1, cn, wbn); }
-        ST_STAMP(8);
         __syncthreads();
-        ST_STAMP(9);
+        ST_STAMP(8);
       }
       if (a.K > 3) {
-        ST_INTERVAL(3, false, px, py, ta, tb)  // tb <- T_3
+        st_contract<NB, PREC>(smem, px, wb + (unsigned)(2 * NB * 2048), mb, lane, acc);
+        ST_STAMP(9);
+        if (more) dma_group(1, nn, cn, pxn, wbn);
         ST_STAMP(10);
-        if (more) { dma_x(integral_constant<int, 3>{}, nn, cn, pxn); dma_w(2, cn, wbn); }
-        ST_STAMP(11);
         __syncthreads();
-        ST_STAMP(12);
+        ST_STAMP(11);
       }
       if (a.K > 4) {
-        ST_INTERVAL(4, false, py, px, tb, ta)  // ta <- T_4
+        st_contract<NB, PREC>(smem, py, wb + (unsigned)(3 * NB * 2048), mb, lane, acc);
+        ST_STAMP(12);
+        if (more) dma_group(2, nn, cn, pxn, wbn);
         ST_STAMP(13);
-        if (more) dma_x(integral_constant<int, 4>{}, nn, cn, pxn);
-        ST_STAMP(14);
         __syncthreads();
-        ST_STAMP(15);
+        ST_STAMP(14);
       }
-#undef ST_INTERVAL
       if (more) {  // pieces that the shorter recurrences have not sent yet
-        if (a.K <= 2) { dma_x(integral_constant<int, 2>{}, nn, cn, pxn); dma_w(1, cn, wbn); }
-        if (a.K <= 3) { dma_x(integral_constant<int, 3>{}, nn, cn, pxn); dma_w(2, cn, wbn); }
-        if (a.K <= 4) dma_x(integral_constant<int, 4>{}, nn, cn, pxn);
+        if (a.K <= 2) dma_group(0, nn, cn, pxn, wbn);
+        if (a.K <= 3) dma_group(1, nn, cn, pxn, wbn);
+        if (a.K <= 4) dma_group(2, nn, cn, pxn, wbn);
       }
-      {  // the last plane
-        const unsigned pl = ((a.K - 1) & 1) ? py : px;
-        st_contract<NB, PREC>(smem, pl, wb + (unsigned)((a.K - 1) * NB * 2048), mb0, mb1, lane, acc);
-      }
-      ST_STAMP(16);
-      stored = c == a.C - 1;
-      if (stored) {  // y of this map, straight from the accumulators
-        float* __restrict__ yt = a.y + ((int64_t)n * a.y_rows + row0) * a.ld;
-        // the plane that does not hold T_{K-1}: its last readers passed the barrier above
-        unsigned char* scr = smem + (((a.K - 1) & 1) ? px : py) + wave * ST_SCR_WAVE;
-        // one uniform switch per map, not one per element (the inlined activation switch is 5 k instructions otherwise)
-        if (!vec_ok) st_store<NB, -1, false>(acc, scr, yt, a.ld, sBias, wave, lane, a.Fout, a.act);
-        else if (a.act == DSPH_ACT_NONE) st_store<NB, DSPH_ACT_NONE, true>(acc, scr, yt, a.ld, sBias, wave, lane, a.Fout, a.act);
-        else if (a.act == DSPH_ACT_RELU) st_store<NB, DSPH_ACT_RELU, true>(acc, scr, yt, a.ld, sBias, wave, lane, a.Fout, a.act);
-        else st_store<NB, -1, true>(acc, scr, yt, a.ld, sBias, wave, lane, a.Fout, a.act);
-      }
-      ST_STAMP(17);
+      // T_{K-1}: left for the next item's first interval when it sits in the old X plane (K odd), which nobody touches
+      // before that interval's barrier; in the Y plane (K even) the next item's first step would overwrite it, so it is
+      // contracted now, in front of the next B_a
+      pend = true;
+      pend_plane = ((a.K - 1) & 1) ? py : px;
+      pend_w = wb + (unsigned)((a.K - 1) * NB * 2048);
+      pend_store = c == a.C - 1;
+      pend_n = n;
+      pend_row0 = row0;
+      if ((a.K - 1) & 1) flush_pending();
       px = pxn;
       wb = wbn;
       n = nn;
       c = cn;
     }
   }
+  flush_pending();
 }
 
 }  // namespace dsph

@@ -87,6 +87,12 @@ if __name__ == "__main__":
         case(64, 2, 8, 64, 1, "fp32")
         case(64, 4, 20, 40, 2, "bf16x3")
         case(128, 5, 64, 64, 1, "bf16x3", oracle=False)
+    if mode == "dbg":
+        case(128, 5, 64, 64, 4, "fp32", oracle=False)
+        case(256, 5, 64, 64, 2, "fp32", oracle=False)
+        case(256, 5, 64, 64, 4, "fp32", oracle=False)
+        case(256, 4, 64, 64, 4, "bf16x3", oracle=False)
+        case(256, 5, 16, 32, 8, "bf16x3", oracle=False)
     if mode in ("all", "time"):
         timing(256, 5, 16, 32, 8, "bf16x3")
         timing(512, 5, 64, 64, 4, "bf16x3")
