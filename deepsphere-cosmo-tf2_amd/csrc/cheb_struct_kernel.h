@@ -334,7 +334,12 @@ __device__ __forceinline__ unsigned st_piece_info(int piece, int lane, int D) {
 // The 39 x pieces of an item are issued by both roles, in proportion to the slack they have (a piece holds the issuing
 // wave for 250-300 cycles): pieces 0..19 by the eight recurrence waves (wave w: w, w+8, w+16), pieces 20..38 by the
 // four contraction waves (wave c: 20+c, 24+c, ...), which also issue the 20 weight pieces.
-constexpr int ST_GPIECES = 20;
+// (Measured, same box: 16 / 20 / 39 x pieces on the recurrence waves give 15.39 / 15.42 / - ms with the split-bf16
+// contraction and - / 23.3 / 23.9 ms with the exact-fp32 one, weights on the contraction waves throughout.)
+template <int PREC> struct StPieces {
+  static constexpr int GX = PREC == DSPH_PREC_FP32 ? 20 : 16;  // x pieces of the recurrence waves: w + 8 s
+  static constexpr int GW = 0;                                  // weight pieces of the recurrence waves: w + 8 u
+};
 
 template <int NB, int PREC, bool CHEB>
 __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a) {
@@ -372,23 +377,27 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
 #pragma unroll
     for (unsigned f = 0; f < 4; ++f) gb[f] = st_cell_off(2 * bx, 2 * by) + 16u * (q ^ f);
     // block b covers cells 2b+1, 2b+2; step j computes the region [4-(D-j), 19+(D-j)]
-    unsigned lact = 0;  // bit k: this lane's block is part of step k
+    unsigned lact = 0, wact = 0;  // bit k: this lane's block / some block of this wave is part of step k
 #pragma unroll
     for (int k = 1; k <= ST_DMAX; ++k) {
       const int lo = (ST_DMAX - (D - k) - 1) >> 1, hi = (ST_DMAX + ST_TILE - 1 + (D - k) - 1) >> 1;
       const bool on = k <= D && has_blk && bx >= lo && bx <= hi && by >= lo && by <= hi;
       lact |= on ? (1u << k) : 0u;
+      wact |= __builtin_amdgcn_ballot_w64(on) != 0 ? (1u << k) : 0u;
     }
     // where the other lanes' stores go: the pad cell (half-row index 12) of their window's second row, own slot
     const unsigned dummy = (unsigned)((2 * by + 1) * ST_P2 + ST_S / 2) * 64u + 16u * q;
 
-    // this wave's x pieces of the NEXT item: w, w + 8, w + 16 (< ST_GPIECES), one per interval 2, 3, 4
+    using std::integral_constant;
+    // this wave's x pieces of the NEXT item: w + 8 s (< GX), s = 0..4, spread over the intervals 2, 3, 4
+    constexpr int GX = StPieces<PREC>::GX, GW = StPieces<PREC>::GW;
     unsigned ginfo = 0;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 5; ++s) {
       const int piece = wave + 8 * s;
-      ginfo |= (piece < ST_GPIECES ? st_piece_info(piece, lane, D) : 0u) << (3 * s);
+      ginfo |= (piece < GX ? st_piece_info(piece, lane, D) : 0u) << (3 * s);
     }
+    const int wsliceG = a.K * NB * 2048;
     const unsigned* const sRowG = reinterpret_cast<const unsigned*>(smem + ST_LDS_ROWS);
     const bool raggedG = (a.Fin & 15) != 0;
     auto gdma = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
@@ -402,16 +411,37 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
       }
       if ((ginfo >> (3 * s)) & 4u) st_glds16_off(base, off, __builtin_amdgcn_readfirstlane(pdst + 1024u * (unsigned)piece));
     };
-    using std::integral_constant;
+    auto gdma_w = [&](int u, int c, unsigned wdst) __attribute__((always_inline)) {
+      const int j = wave + 8 * u;
+      if (j < GW && j < wsliceG / 1024)
+        st_glds16_off(a.wfrag + (size_t)c * wsliceG + 1024 * j, (unsigned)lane * 16u,
+                      __builtin_amdgcn_readfirstlane(wdst + 1024u * (unsigned)j));
+    };
+    // group g of this wave's pieces of item (n, c): x0 x1 w0 | x2 x3 w1 | x4 w2
+    auto gdma_group = [&](int g, int n, int c, unsigned pdst, unsigned wdst) __attribute__((always_inline)) {
+      if (g == 0) {
+        gdma(integral_constant<int, 0>{}, n, c, pdst);
+        if (GX > 8) gdma(integral_constant<int, 1>{}, n, c, pdst);
+        if (GW > 0) gdma_w(0, c, wdst);
+      } else if (g == 1) {
+        if (GX > 16) gdma(integral_constant<int, 2>{}, n, c, pdst);
+        if (GX > 24) gdma(integral_constant<int, 3>{}, n, c, pdst);
+        if (GW > 8) gdma_w(1, c, wdst);
+      } else {
+        if (GX > 32) gdma(integral_constant<int, 4>{}, n, c, pdst);
+        if (GW > 16) gdma_w(2, c, wdst);
+      }
+    };
     float v[4][9];
     float4 ta[4], tb[4];  // T_{k-1} and T_{k-2} of this lane's four pixels, in alternating roles
 #pragma unroll
     for (int p = 0; p < 4; ++p) ta[p] = tb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned px = 0;
     __syncthreads();  // the contraction waves' row table (prologue)
-    gdma(integral_constant<int, 0>{}, 0, 0, px);
-    gdma(integral_constant<int, 1>{}, 0, 0, px);
-    gdma(integral_constant<int, 2>{}, 0, 0, px);
+    unsigned wbG = ST_LDS_W;  // weight buffer of the current item
+    gdma_group(0, 0, 0, px, wbG);
+    gdma_group(1, 0, 0, px, wbG);
+    gdma_group(2, 0, 0, px, wbG);
     for (int t = t_begin + slot0; t < t_end; t += nslots) {
       const unsigned row0 = (unsigned)a.tiles[t] * 256u;
       {  // L~ values of this lane's four pixels (blocks that no step touches load a valid row and never use it)
@@ -438,6 +468,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
         __syncthreads();  // B_a: the whole slice and the weights have landed
         ST_STAMP(1);
         const unsigned pxn = px ^ (2u * ST_PLANE_BYTES);
+        const unsigned wbnG = wbG == (unsigned)ST_LDS_W ? (unsigned)(ST_LDS_W + ST_WSLICE_BYTES) : (unsigned)ST_LDS_W;
         const bool more = item + 1 < items || t + nslots < t_end;
         const int cn = (c + 1 == a.C || item + 1 == items) ? 0 : c + 1;
         const int nn = item + 1 == items ? 0 : (c + 1 == a.C ? n + 1 : n);
@@ -446,32 +477,34 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
         __syncthreads();
         ST_STAMP(3);
         if (a.K > 2) {
-          st_gather<false, CHEB>(smem, py, px, gb, v, tb, ta, (lact & 4u) != 0, dummy);  // ta <- T_2
-          if (more) gdma(integral_constant<int, 0>{}, nn, cn, pxn);
+          if (wact & 4u) st_gather<false, CHEB>(smem, py, px, gb, v, tb, ta, (lact & 4u) != 0, dummy);  // ta <- T_2
+          if (more) gdma_group(0, nn, cn, pxn, wbnG);
           ST_STAMP(4);
           __syncthreads();
           ST_STAMP(5);
         }
         if (a.K > 3) {
-          st_gather<false, CHEB>(smem, px, py, gb, v, ta, tb, (lact & 8u) != 0, dummy);  // tb <- T_3
-          if (more) gdma(integral_constant<int, 1>{}, nn, cn, pxn);
+          // (a wave whose blocks all lie outside this step's region -- the border blocks sit in the last waves -- skips it)
+          if (wact & 8u) st_gather<false, CHEB>(smem, px, py, gb, v, ta, tb, (lact & 8u) != 0, dummy);  // tb <- T_3
+          if (more) gdma_group(1, nn, cn, pxn, wbnG);
           ST_STAMP(6);
           __syncthreads();
           ST_STAMP(7);
         }
         if (a.K > 4) {
-          st_gather<false, CHEB>(smem, py, px, gb, v, tb, ta, (lact & 16u) != 0, dummy);  // ta <- T_4
-          if (more) gdma(integral_constant<int, 2>{}, nn, cn, pxn);
+          if (wact & 16u) st_gather<false, CHEB>(smem, py, px, gb, v, tb, ta, (lact & 16u) != 0, dummy);  // ta <- T_4
+          if (more) gdma_group(2, nn, cn, pxn, wbnG);
           ST_STAMP(8);
           __syncthreads();
           ST_STAMP(9);
         }
         if (more) {  // pieces that the shorter recurrences have not sent yet
-          if (a.K <= 2) gdma(integral_constant<int, 0>{}, nn, cn, pxn);
-          if (a.K <= 3) gdma(integral_constant<int, 1>{}, nn, cn, pxn);
-          if (a.K <= 4) gdma(integral_constant<int, 2>{}, nn, cn, pxn);
+          if (a.K <= 2) gdma_group(0, nn, cn, pxn, wbnG);
+          if (a.K <= 3) gdma_group(1, nn, cn, pxn, wbnG);
+          if (a.K <= 4) gdma_group(2, nn, cn, pxn, wbnG);
         }
         px = pxn;
+        wbG = wbnG;
         n = nn;
         c = cn;
       }
@@ -495,10 +528,11 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     mb[pb] = st_cell_off(gx, gy) + 16u * ((2 * mh) ^ st_cell_f(gx, gy));
   }
   // LDS-DMA: wave c issues x pieces c, c+4, ...; lane l fills slot l & 3 of cell 16 piece + (l >> 2) of the plane
-  constexpr int NPX = (ST_DMA_PIECES - ST_GPIECES + ST_CONTRACT_WAVES - 1) / ST_CONTRACT_WAVES;  // 5
+  constexpr int GX = StPieces<PREC>::GX, GW = StPieces<PREC>::GW;
+  constexpr int NPX = (ST_DMA_PIECES - GX + ST_CONTRACT_WAVES - 1) / ST_CONTRACT_WAVES;  // 6 (split bf16), 0 (fp32)
   unsigned dinfo = 0;  // per piece s: bits 3s..3s+1 logical slot, bit 3s+2 valid
 #pragma unroll
-  for (int s = 0; s < NPX; ++s) dinfo |= st_piece_info(ST_GPIECES + cw + ST_CONTRACT_WAVES * s, lane, D) << (3 * s);
+  for (int s = 0; s < (NPX > 0 ? NPX : 1) && s < NPX; ++s) dinfo |= st_piece_info(GX + cw + ST_CONTRACT_WAVES * s, lane, D) << (3 * s);
   const int wslice = a.K * NB * 2048;  // bytes of one slice's fragments
   const int wpieces = wslice / 1024;
   const bool vec_ok = (a.Fout % 4 == 0) && (a.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
@@ -524,7 +558,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   auto dma_x = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
     constexpr int s = decltype(s_c)::value;
     const float* __restrict__ base = a.x + ((int64_t)n * a.x_rows * a.Fin + c * 16);
-    constexpr int piece_base = ST_GPIECES + ST_CONTRACT_WAVES * s;
+    constexpr int piece_base = GX + ST_CONTRACT_WAVES * s;
     unsigned off = sRow[16 * (piece_base + cw) + (lane >> 2)] + 16u * ((dinfo >> (3 * s)) & 3u);
     if (ragged) {
       const int ch0 = c * 16 + 4 * (int)((dinfo >> (3 * s)) & 3u);
@@ -535,7 +569,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   };
   // piece u of this wave's share of the weight fragments of slice c -> buffer at wdst
   auto dma_w = [&](int u, int c, unsigned wdst) __attribute__((always_inline)) {
-    const int j = cw + ST_CONTRACT_WAVES * u;
+    const int j = GW + cw + ST_CONTRACT_WAVES * u;
     if (j < wpieces)
       st_glds16_off(a.wfrag + (size_t)c * wslice + 1024 * j, (unsigned)lane * 16u,
                     __builtin_amdgcn_readfirstlane(wdst + 1024u * (unsigned)j));
@@ -544,13 +578,16 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   // that ends interval 1 the previous item's last plane and weights are still being contracted out of those buffers)
   auto dma_group = [&](int g, int n, int c, unsigned pdst, unsigned wdst) __attribute__((always_inline)) {
     if (g == 0) {
-      dma_x(integral_constant<int, 0>{}, n, c, pdst); dma_x(integral_constant<int, 1>{}, n, c, pdst);
+      if (NPX > 0) dma_x(integral_constant<int, 0>{}, n, c, pdst);
+      if (NPX > 1) dma_x(integral_constant<int, 1>{}, n, c, pdst);
       dma_w(0, c, wdst); dma_w(1, c, wdst);
     } else if (g == 1) {
-      dma_x(integral_constant<int, 2>{}, n, c, pdst); dma_x(integral_constant<int, 3>{}, n, c, pdst);
+      if (NPX > 2) dma_x(integral_constant<int, 2>{}, n, c, pdst);
+      if (NPX > 3) dma_x(integral_constant<int, 3>{}, n, c, pdst);
       dma_w(2, c, wdst); dma_w(3, c, wdst);
     } else {
-      dma_x(integral_constant<int, 4>{}, n, c, pdst);
+      if (NPX > 4) dma_x(integral_constant<int, 4>{}, n, c, pdst);
+      if (NPX > 5) dma_x(integral_constant<int, 5>{}, n, c, pdst);
       dma_w(4, c, wdst);
     }
   };
