@@ -331,14 +331,19 @@ __device__ __forceinline__ unsigned st_piece_info(int piece, int lane, int D) {
   const bool ok = piece < ST_DMA_PIECES && gxh < ST_S / 2 && (int)gx >= lo && (int)gx <= hi && (int)gy >= lo && (int)gy <= hi;
   return ((lane & 3u) ^ st_cell_f(gx, gy)) | (ok ? 4u : 0u);
 }
-// The 39 x pieces of an item are issued by both roles, in proportion to the slack they have (a piece holds the issuing
-// wave for 250-300 cycles): pieces 0..19 by the eight recurrence waves (wave w: w, w+8, w+16), pieces 20..38 by the
-// four contraction waves (wave c: 20+c, 24+c, ...), which also issue the 20 weight pieces.
-// (Measured, same box: 16 / 20 / 39 x pieces on the recurrence waves give 15.39 / 15.42 / - ms with the split-bf16
-// contraction and - / 23.3 / 23.9 ms with the exact-fp32 one, weights on the contraction waves throughout.)
+// The 39 x pieces and 20 weight pieces of an item are issued by both roles (a piece holds the issuing wave for up to
+// 250-300 cycles): x pieces 0 .. GX-1 and weight pieces 0 .. GW-1 by the eight recurrence waves, the rest by the four
+// contraction waves.
+// (Measured, same box, split-bf16 / exact-fp32 ms at the headline config: x 16 + w 0 on the recurrence waves 15.44 /
+// 23.26; x 0 + w 20: 15.38 / 23.11; x 8 + w 8: 15.36 / 23.32; x 8 + w 20: 15.19 / 22.99 -- the split hardly matters,
+// the kernel is bound by the recurrence waves' instruction issue, not by the pieces.)
 template <int PREC> struct StPieces {
-  static constexpr int GX = PREC == DSPH_PREC_FP32 ? 20 : 16;  // x pieces of the recurrence waves: w + 8 s
-  static constexpr int GW = 0;                                  // weight pieces of the recurrence waves: w + 8 u
+#if defined(DSPH_ST_GX) && defined(DSPH_ST_GW)
+  static constexpr int GX = DSPH_ST_GX, GW = DSPH_ST_GW;  // (tuning build)
+#else
+  static constexpr int GX = 8;   // x pieces of the recurrence waves: piece w (one per wave)
+  static constexpr int GW = 20;  // weight pieces of the recurrence waves: w + 8 u (contiguous 1 KiB: cheap to issue)
+#endif
 };
 
 template <int NB, int PREC, bool CHEB>
@@ -576,18 +581,25 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   };
   // a group of pieces of the next item; groups 0, 1, 2 go out in the intervals 2, 3, 4 (not earlier: until the barrier
   // that ends interval 1 the previous item's last plane and weights are still being contracted out of those buffers)
+  // group g (0, 1, 2 -> intervals 2, 3, 4) of this wave's pieces: x pieces 4g .. 4g+3 (the last group takes the rest),
+  // weight pieces 2g, 2g+1
   auto dma_group = [&](int g, int n, int c, unsigned pdst, unsigned wdst) __attribute__((always_inline)) {
     if (g == 0) {
       if (NPX > 0) dma_x(integral_constant<int, 0>{}, n, c, pdst);
       if (NPX > 1) dma_x(integral_constant<int, 1>{}, n, c, pdst);
+      if (NPX > 2) dma_x(integral_constant<int, 2>{}, n, c, pdst);
+      if (NPX > 6) dma_x(integral_constant<int, 3>{}, n, c, pdst);
       dma_w(0, c, wdst); dma_w(1, c, wdst);
     } else if (g == 1) {
-      if (NPX > 2) dma_x(integral_constant<int, 2>{}, n, c, pdst);
-      if (NPX > 3) dma_x(integral_constant<int, 3>{}, n, c, pdst);
+      if (NPX > 6) { dma_x(integral_constant<int, 4>{}, n, c, pdst); dma_x(integral_constant<int, 5>{}, n, c, pdst); dma_x(integral_constant<int, 6>{}, n, c, pdst); }
+      else if (NPX > 3) dma_x(integral_constant<int, 3>{}, n, c, pdst);
+      if (NPX > 7) dma_x(integral_constant<int, 7>{}, n, c, pdst);
+      if (NPX <= 6 && NPX > 4) dma_x(integral_constant<int, 4>{}, n, c, pdst);
       dma_w(2, c, wdst); dma_w(3, c, wdst);
     } else {
-      if (NPX > 4) dma_x(integral_constant<int, 4>{}, n, c, pdst);
-      if (NPX > 5) dma_x(integral_constant<int, 5>{}, n, c, pdst);
+      if (NPX > 8) dma_x(integral_constant<int, 8>{}, n, c, pdst);
+      if (NPX > 9) dma_x(integral_constant<int, 9>{}, n, c, pdst);
+      if (NPX <= 6 && NPX > 5) dma_x(integral_constant<int, 5>{}, n, c, pdst);
       dma_w(4, c, wdst);
     }
   };
