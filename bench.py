@@ -359,7 +359,7 @@ def main():
                 "frac_of_measured_copy_6290": round(achieved / 6290.0, 4),
                 "median_forward_ms_hip_events": round(float(np.median(per_fwd_ms)), 4),
                 "traffic": traffic,
-                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of tools/measure_round.sh; not re-measured in this run)" if traffic else None,
+                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of tools/measure_round2.sh; not re-measured in this run)" if traffic else None,
                 "algorithmic_bytes": b_alg,
                 "avg_forward_ms_hip_events": round(dev_ms, 4),
             },
