@@ -402,6 +402,18 @@ __global__ __launch_bounds__(256) void fused_wprep_kernel(const float* __restric
   }
 }
 
+// Diagnostic build only (make ABLATE=1): DSPH_DBG_ONLY=s / b launches only the structured-tile / only the BFS-tile kernel
+// (wrong results by construction: the other tiles of y stay unwritten).  The shipped library always launches both.
+static inline bool dbg_only(char which) {
+#ifdef DSPH_ABLATE
+  const char* e = getenv("DSPH_DBG_ONLY");
+  return e && e[0] == which;
+#else
+  (void)which;
+  return false;
+#endif
+}
+
 static int launch_fused_common(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
@@ -535,7 +547,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   // ---- class-R tiles: the structured-tile kernel (forward only) ------------------------------------------------
   if (!planes_mode && ft.n_r > 0) {
     const int nr = part == 0 ? ft.n_r : (part == 1 ? ft.n_r_interior : ft.n_r - ft.n_r_interior);
-    if (nr > 0 && !(getenv("DSPH_DBG_ONLY") && getenv("DSPH_DBG_ONLY")[0] == 'b')) {
+    if (nr > 0 && !dbg_only('b')) {
       StructLaunch sl;
       sl.x = x; sl.w = w; sl.bias = bias; sl.y = y;
       sl.wfrag = static_cast<unsigned char*>(workspace) + wb;
@@ -553,7 +565,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       if (rc != DSPH_OK) return rc;
     }
     const int ng = part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior);
-    if (ng == 0 || (getenv("DSPH_DBG_ONLY") && getenv("DSPH_DBG_ONLY")[0] == 's')) return DSPH_OK;
+    if (ng == 0 || dbg_only('s')) return DSPH_OK;
   }
   if (!planes_mode) {
     hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,

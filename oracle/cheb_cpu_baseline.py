@@ -111,7 +111,15 @@ def load_port():
     here = os.path.dirname(os.path.abspath(__file__))
     out_dir = os.path.join(here, "_build")
     os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "libcheb_port.so")
+    # -march=native code must not travel between hosts: one library per CPU model
+    import hashlib
+
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((ln for ln in f if ln.startswith("flags")), "")
+    except OSError:
+        cpu = ""
+    so = os.path.join(out_dir, "libcheb_port_%s.so" % hashlib.sha1(cpu.encode()).hexdigest()[:10])
     src = os.path.join(here, "cheb_port.c")
     cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", src, "-o", so]
     lib = None
