@@ -228,8 +228,10 @@ def main():
     else:
         from deepsphere import sharding
 
-        shard = sharding.ShardedChebyshev(cols, vals, K, Fout=Fout, rank=rank, world=world, device=device,
-                                          precision=args.precision, algo=args.algo, kernel=w_np)
+        # the ELL as a row producer: the rank reads its own rows and halo only, and learns its send lists from the
+        # set-up gather of every rank's requests (sharding.ShardLayout)
+        shard = sharding.ShardedChebyshev(lambda ids: (cols[ids], vals[ids]), None, K, Fout=Fout, rank=rank, world=world,
+                                          device=device, precision=args.precision, algo=args.algo, kernel=w_np, M=M)
         gen = torch.Generator(device=device).manual_seed(11 + rank)
         # this rank's rows live in the extended buffer the kernel reads (own rows, then halo rows): a producer
         # layer would write them there; no per-step copy

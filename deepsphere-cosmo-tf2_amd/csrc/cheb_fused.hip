@@ -341,13 +341,17 @@ static bool supported_impl(const dsph_plan* plan, int32_t Fin, int32_t Fout, int
   return lds <= (size_t)LDS_BYTES;
 }
 
+// The forward takes any Fin >= 1: channel counts that are not a multiple of four are zero-padded into the workspace first
+// (fused_pad_kernel; the kernels load x in 16-byte pieces).  The first layer of every reference model has Fin = 1.
+static inline int32_t pad4(int32_t Fin) { return (Fin + 3) & ~3; }
+
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
-  return supported_impl(plan, Fin, Fout, K, false);
+  return Fin >= 1 && supported_impl(plan, pad4(Fin), Fout, K, false);
 }
 
 int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags) {
   if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return DSPH_OK;  // nothing to build: the unfused path serves it
-  (void)get_tiles(plan, K - 1, want_full(plan, Fin, false));
+  (void)get_tiles(plan, K - 1, want_full(plan, pad4(std::max(Fin, 1)), false));
   if (flags & DSPH_PREPARE_BACKWARD) (void)get_tiles(plan, K - 1, true);
   if (flags & DSPH_PREPARE_RELEASE_HOST) {
     FusedPlan* fp = plan->fused;
@@ -370,8 +374,25 @@ bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int6
 }
 
 // two fragment layouts: the BFS-tile kernel's and, behind it, the structured-tile kernel's
-size_t fused_workspace_bytes(const dsph_plan*, int64_t, int32_t Fin, int32_t Fout, int32_t K, int32_t) {
-  return wfrag_bytes(Fin, std::min(Fout, 64), K) + struct_wfrag_bytes(Fin, std::min(Fout, 64), K);
+size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t) {
+  const int32_t Fp = pad4(Fin);
+  const size_t frag = wfrag_bytes(Fp, std::min(Fout, 64), K) + struct_wfrag_bytes(Fp, std::min(Fout, 64), K);
+  return frag + (Fp != Fin ? (size_t)N * (size_t)plan->n_cols * (size_t)Fp * 4 : 0);  // + the zero-padded copy of x
+}
+
+__global__ __launch_bounds__(256) void fused_pad_kernel(const float* __restrict__ x, float4* __restrict__ out, int64_t rows,
+                                                        int Fin, int Q) {  // out[r][q] <- x[r][4q .. 4q+3], zeros past Fin
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * Q; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / Q;
+    const int c = 4 * (int)(i - r * Q);
+    const float* __restrict__ src = x + r * Fin + c;
+    float4 v;
+    v.x = src[0];
+    v.y = c + 1 < Fin ? src[1] : 0.f;
+    v.z = c + 2 < Fin ? src[2] : 0.f;
+    v.w = c + 3 < Fin ? src[3] : 0.f;
+    out[i] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -418,7 +439,8 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream,
-                               const float* dy = nullptr, float* dw = nullptr, int32_t ld = 0, int32_t part = 0);
+                               const float* dy = nullptr, float* dw = nullptr, int32_t ld = 0, int32_t part = 0,
+                               int32_t Fin_w = 0);
 
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
@@ -430,17 +452,38 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
   // and one elementwise pass finishes y (only when class-R tiles exist: the BFS-tile kernel knows every activation).
   bool defer_act = false;
   if (act != DSPH_ACT_NONE && act != DSPH_ACT_RELU && K - 1 <= FUSED_DMAX && K >= 2) {
-    const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
+    const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
     defer_act = ft.ok && ft.n_r > 0;
   }
   if (defer_act && part != 0) {
     set_error("cheb_fused: interior / boundary launches support the activations NONE and RELU only");
     return DSPH_E_UNSUPPORTED;
   }
+  // Fin not a multiple of four: a zero-padded copy of x behind the weight fragments in the workspace (with a two-part
+  // launch both parts copy: the halo rows arrive between them)
+  const int32_t Fin_w = Fin;
+  if (Fin != pad4(Fin)) {
+    const int32_t Fp = pad4(Fin);
+    const size_t frag = wfrag_bytes(Fp, std::min(Fout, 64), K) + struct_wfrag_bytes(Fp, std::min(Fout, 64), K);
+    const size_t need = frag + (size_t)N * (size_t)plan->n_cols * (size_t)Fp * 4;
+    if (!workspace || workspace_bytes < need) {
+      set_error("cheb_fused: workspace %zu < %zu", workspace_bytes, need);
+      return DSPH_E_WORKSPACE;
+    }
+    float* xp = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + frag);
+    const int64_t rows = N * plan->n_cols;
+    const int64_t work = rows * (Fp / 4);
+    hipLaunchKernelGGL(fused_pad_kernel, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 65536)), dim3(256), 0, stream, x,
+                       reinterpret_cast<float4*>(xp), rows, (int)Fin, (int)(Fp / 4));
+    DSPH_HIP(hipGetLastError());
+    x = xp;
+    Fin = Fp;
+  }
   for (int32_t cb = 0; cb < Fout; cb += 64) {
     const int rc = launch_fused_common(plan, x, w + cb, bias ? bias + cb : nullptr, y + cb, nullptr, N, Fin,
                                        std::min<int32_t>(64, Fout - cb), K, defer_act ? DSPH_ACT_NONE : act, precision,
-                                       alpha_rest, beta_rest, workspace, workspace_bytes, stream, nullptr, nullptr, Fout, part);
+                                       alpha_rest, beta_rest, workspace, workspace_bytes, stream, nullptr, nullptr, Fout, part,
+                                       Fin_w);
     if (rc != DSPH_OK) return rc;
   }
   if (defer_act) {
@@ -523,8 +566,9 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream, const float* dy,
-                               float* dw, int32_t ld, int32_t part) {
-  if (ld <= 0) ld = Fout;  // row stride of w, bias-less y / dy / dw: the layer's Fout when this is one column block
+                               float* dw, int32_t ld, int32_t part, int32_t Fin_w) {
+  if (ld <= 0) ld = Fout;
+  if (Fin_w <= 0) Fin_w = Fin;  // channels of w; smaller than Fin when x is a zero-padded copy  // row stride of w, bias-less y / dy / dw: the layer's Fout when this is one column block
   const bool wgrad_mode = dy != nullptr;  // y then carries the slab workspace
   const bool planes_mode = planes_out != nullptr || wgrad_mode;
   if (!supported_impl(plan, Fin, Fout, K, planes_mode)) {
@@ -558,7 +602,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       sl.y_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
       sl.N = N;
       sl.ntiles = nr;
-      sl.Fin = Fin; sl.Fout = Fout; sl.K = K; sl.act = act; sl.precision = precision; sl.ld = ld;
+      sl.Fin = Fin; sl.Fin_w = Fin_w; sl.Fout = Fout; sl.K = K; sl.act = act; sl.precision = precision; sl.ld = ld;
       sl.num_cu = plan->fused->num_cu;
       sl.cheb = beta_rest != 0.f;
       const int rc = launch_cheb_struct(sl, stream);
@@ -569,7 +613,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   }
   if (!planes_mode) {
     hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,
-                       static_cast<unsigned char*>(workspace), (int)Fin, (int)Fout, (int)K, C, NB,
+                       static_cast<unsigned char*>(workspace), (int)Fin_w, (int)Fout, (int)K, C, NB,
                        (int)precision, (int)ld);
     DSPH_HIP(hipGetLastError());
   }

@@ -161,7 +161,7 @@ size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
 
 int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   const int C = (s.Fin + 15) / 16, NB = (s.Fout + 31) / 32;
-  hipLaunchKernelGGL(struct_wprep_kernel, dim3(C * s.K * NB), dim3(256), 0, stream, s.w, s.wfrag, (int)s.Fin, (int)s.Fout,
+  hipLaunchKernelGGL(struct_wprep_kernel, dim3(C * s.K * NB), dim3(256), 0, stream, s.w, s.wfrag, (int)s.Fin_w, (int)s.Fout,
                      (int)s.K, C, NB, (int)s.precision, (int)s.ld);
   DSPH_HIP(hipGetLastError());
   StructArgs a;

@@ -150,6 +150,19 @@ __device__ __forceinline__ void st_glds16_off(const void* sbase_in, unsigned vof
       : "memory");
 }
 
+// Tuning builds only (tools/ab_ablate.sh; the results are wrong by construction, the shipped library defines neither):
+// -DDSPH_ST_ABL_DIRS=n sums n of the 8 directions, -DDSPH_ST_ABL_READS=1 reads only window row 0 from LDS.
+#ifdef DSPH_ST_ABL_DIRS
+#define ST_ABL_DIRS DSPH_ST_ABL_DIRS
+#else
+#define ST_ABL_DIRS 8
+#endif
+#ifdef DSPH_ST_ABL_READS
+#define ST_ABL_READS 1
+#else
+#define ST_ABL_READS 0
+#endif
+
 // One recurrence step for this lane's 2x2 block (gather waves): window from plane `pin` (byte offset), T_k to `pout`.
 //   FIRST: T_1 = L~ T_0, the block's own T_0 is read too (16 reads) and kept in `cur`; otherwise the centre of the
 //          window is `cur` (T_{k-1} of the lane's own pixels, in registers since the previous step)
@@ -167,6 +180,9 @@ __device__ __forceinline__ void st_gather(const unsigned char* __restrict__ smem
     ob[p] = (wr ? gb[st_cell_f((p & 1) + 1, (p >> 1) + 1)] + st_woff((p & 1) + 1, (p >> 1) + 1) : dummy) + pout;
   float4 W[4][4];
   auto rd = [&](int wx, int wy) {
+#if ST_ABL_READS
+    if (wy > 0 && !(FIRST && (wy == 1 || wy == 2) && (wx == 1 || wx == 2))) { W[wy][wx] = W[0][wx]; return; }
+#endif
     W[wy][wx] = *reinterpret_cast<const float4*>(smem + (gb[st_cell_f(wx, wy)] + pin) + st_woff(wx, wy));
   };
   // The sum of a pixel runs in the unfused kernel's order: the diagonal, then the eight directions.
@@ -179,7 +195,7 @@ __device__ __forceinline__ void st_gather(const unsigned char* __restrict__ smem
     s.z = fmaf(v[p][0], c.z, s.z);
     s.w = fmaf(v[p][0], c.w, s.w);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
+    for (int d = 0; d < ST_ABL_DIRS; ++d) {
       const float4 u = W[j + 1 + kDirY[d]][i + 1 + kDirX[d]];
       const float w = v[p][d + 1];
       s.x = fmaf(w, u.x, s.x);
@@ -422,7 +438,10 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
         st_glds16_off(a.wfrag + (size_t)c * wsliceG + 1024 * j, (unsigned)lane * 16u,
                       __builtin_amdgcn_readfirstlane(wdst + 1024u * (unsigned)j));
     };
-    // group g of this wave's pieces of item (n, c): x0 x1 w0 | x2 x3 w1 | x4 w2
+    // group g of this wave's pieces of item (n, c): x0 x1 w0 | x2 x3 w1 | x4 w2.  With K = 5 (early) the third group
+    // goes out with the second, in interval 3: every piece then lands before the barrier that ends interval 4, which
+    // so doubles as the next item's "slice has landed" barrier.
+    const bool early = a.K >= 5;
     auto gdma_group = [&](int g, int n, int c, unsigned pdst, unsigned wdst) __attribute__((always_inline)) {
       if (g == 0) {
         gdma(integral_constant<int, 0>{}, n, c, pdst);
@@ -447,6 +466,10 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     gdma_group(0, 0, 0, px, wbG);
     gdma_group(1, 0, 0, px, wbG);
     gdma_group(2, 0, 0, px, wbG);
+    if (early) {  // the first item's slice: the only one waited for outside the item loop
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     for (int t = t_begin + slot0; t < t_end; t += nslots) {
       const unsigned row0 = (unsigned)a.tiles[t] * 256u;
       {  // L~ values of this lane's four pixels (blocks that no step touches load a valid row and never use it)
@@ -469,8 +492,10 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
         const bool stamp_on = wave < 7 && blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
 #endif
         ST_STAMP(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the item's x slice
-        __syncthreads();  // B_a: the whole slice and the weights have landed
+        if (!early) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the item's x slice
+          __syncthreads();  // B_a: the whole slice and the weights have landed
+        }
         ST_STAMP(1);
         const unsigned pxn = px ^ (2u * ST_PLANE_BYTES);
         const unsigned wbnG = wbG == (unsigned)ST_LDS_W ? (unsigned)(ST_LDS_W + ST_WSLICE_BYTES) : (unsigned)ST_LDS_W;
@@ -492,14 +517,16 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
           // (a wave whose blocks all lie outside this step's region -- the border blocks sit in the last waves -- skips it)
           if (wact & 8u) st_gather<false, CHEB>(smem, px, py, gb, v, ta, tb, (lact & 8u) != 0, dummy);  // tb <- T_3
           if (more) gdma_group(1, nn, cn, pxn, wbnG);
+          if (more && early) gdma_group(2, nn, cn, pxn, wbnG);
           ST_STAMP(6);
           __syncthreads();
           ST_STAMP(7);
         }
         if (a.K > 4) {
           if (wact & 16u) st_gather<false, CHEB>(smem, py, px, gb, v, tb, ta, (lact & 16u) != 0, dummy);  // ta <- T_4
-          if (more) gdma_group(2, nn, cn, pxn, wbnG);
+          if (more && !early) gdma_group(2, nn, cn, pxn, wbnG);
           ST_STAMP(8);
+          if (early) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (issued an interval ago: long landed)
           __syncthreads();
           ST_STAMP(9);
         }
@@ -620,6 +647,11 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   dma_group(0, 0, 0, px, wb);
   dma_group(1, 0, 0, px, wb);
   dma_group(2, 0, 0, px, wb);
+  const bool early = a.K >= 5;  // (see the recurrence waves)
+  if (early) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   // the last plane of the previous item, still to be contracted (under the first step of the current one)
   bool pend = false, pend_store = false;
   unsigned pend_plane = 0, pend_w = 0, pend_row0 = 0;
@@ -650,9 +682,11 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
 #endif
       ST_STAMP(0);
       // ---- B_a: this wave's pieces of the item's x slice and weights have landed ----------------------------------------
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ST_STAMP(1);
-      __syncthreads();
+      if (!early) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ST_STAMP(1);
+        __syncthreads();
+      }
       ST_STAMP(2);
       const unsigned pxn = px ^ (2u * ST_PLANE_BYTES);
       const unsigned wbn = wb == (unsigned)ST_LDS_W ? (unsigned)(ST_LDS_W + ST_WSLICE_BYTES) : (unsigned)ST_LDS_W;
@@ -681,6 +715,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
         st_contract<NB, PREC>(smem, px, wb + (unsigned)(2 * NB * 2048), mb, lane, acc);
         ST_STAMP(9);
         if (more) dma_group(1, nn, cn, pxn, wbn);
+        if (more && early) dma_group(2, nn, cn, pxn, wbn);
         ST_STAMP(10);
         __syncthreads();
         ST_STAMP(11);
@@ -688,8 +723,9 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
       if (a.K > 4) {
         st_contract<NB, PREC>(smem, py, wb + (unsigned)(3 * NB * 2048), mb, lane, acc);
         ST_STAMP(12);
-        if (more) dma_group(2, nn, cn, pxn, wbn);
+        if (more && !early) dma_group(2, nn, cn, pxn, wbn);
         ST_STAMP(13);
+        if (early) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pieces (an interval old) and this wave's y stores
         __syncthreads();
         ST_STAMP(14);
       }

@@ -99,6 +99,7 @@ struct StructLaunch {
   const float* gvals8; const float* gdiag;
   int64_t x_rows, y_rows, N;
   int32_t ntiles, Fin, Fout, K, act, precision, ld, num_cu;
+  int32_t Fin_w;             // channels of w (< Fin when x was zero-padded to a multiple of four channels)
   bool cheb;
 };
 int struct_build_rows(const dsph_plan* plan, float** gvals8, float** gdiag, unsigned char** flag);

@@ -11,8 +11,9 @@ ordered by hop distance (``dsph_plan_set_levels``): step k is evaluated only on 
 needed.  One exchange of the (K-1)-ring halo per forward instead of K-1 one-ring exchanges: the
 same bytes in one message round, and the fused single-launch kernel keeps working.
 
-Every rank holds the whole (prepared, padded-ELL) Laplacian on the host and derives all send
-and receive lists from it deterministically, so no set-up communication is needed.
+A rank walks the hop levels of its own range only and reads only the ELL rows of its own rows and halo (the ELL may be
+given as a row producer); which of its rows the others need it learns from one ``all_gather_object`` at set-up.
+Without a process group (single-process tests) the send lists are derived by walking the other ranges on the whole ELL.
 """
 
 import numpy as np
@@ -31,24 +32,40 @@ def row_ranges(M, world):
 class ShardLayout:
     """What one rank needs to know: its rows, its halo by hop distance, who sends what to whom.
 
+    ``ell_cols`` / ``ell_vals``: the prepared Laplacian in padded ELL form -- either the whole ``[M, W]`` arrays or,
+    with ``M`` given, a callable ``ell_cols(ids) -> (cols[len(ids), W], vals[len(ids), W])`` that produces rows on
+    demand (then ``ell_vals`` is ignored and the rank never holds more than its own rows and halo).  The rank walks
+    the K-1 hop levels of ITS OWN range only; which of its rows the other ranks need is either told to it
+    (``set_peer_requests``: every rank's ``requests`` gathered once at set-up, see ``ShardedChebyshev``) or, in
+    single-process use with the whole ELL at hand, derived by walking the other ranges too (``peer_requests_replicated``).
+
     All index arrays are numpy int64 of *global* row ids unless called ``*_local``.
     """
 
-    def __init__(self, ell_cols, ell_vals, K, rank, world):
-        cols = np.asarray(ell_cols)
-        vals = np.asarray(ell_vals)
-        M = cols.shape[0]
+    def __init__(self, ell_cols, ell_vals, K, rank, world, M=None, peer_requests="replicated"):
+        if callable(ell_cols):
+            if M is None:
+                raise ValueError("a row producer needs the number of rows M")
+            fetch = ell_cols
+            self._whole = None
+        else:
+            cols = np.asarray(ell_cols)
+            vals = np.asarray(ell_vals)
+            M = cols.shape[0]
+            self._whole = (cols, vals)
+
+            def fetch(ids):
+                return cols[ids], vals[ids]
+        M = int(M)
         self.M, self.K, self.rank, self.world = M, int(K), int(rank), int(world)
         self.ranges = row_ranges(M, world)
         depth = max(self.K - 1, 0)
-        # hop levels of every rank's range (cheap: after the first hop only boundaries are touched)
-        self.halo = []  # per rank: list over levels 1..depth of sorted global ids
-        for (a, b) in self.ranges:
-            self.halo.append(self._levels(cols, vals, a, b, depth))
         a, b = self.ranges[rank]
         self.own = (a, b)
         self.n_own = b - a
-        my = self.halo[rank]
+        # hop levels of this rank's range (after the first hop only the boundary is touched); the ELL rows fetched on
+        # the way are kept: they are exactly the rows of the local plan
+        my, row_ids, row_cols, row_vals = self._levels(fetch, M, a, b, depth)
         self.halo_ids = np.concatenate(my) if my else np.zeros(0, np.int64)
         # local order: own rows, then level 1, level 2, ... (each ascending)
         self.local_ids = np.concatenate([np.arange(a, b, dtype=np.int64), self.halo_ids])
@@ -59,53 +76,112 @@ class ShardLayout:
         self.n_rows = int(counts[depth - 1]) if depth >= 1 else self.n_own
         # plan levels: rows_at_level[j] for j = 0..K-2 (step k is evaluated on level K-1-k)
         self.levels = counts[:depth].astype(np.int64) if depth >= 1 else np.array([self.n_own], np.int64)
-        # local ELL with remapped columns
-        lut = np.full(M, -1, dtype=np.int64)
-        lut[self.local_ids] = np.arange(self.n_cols, dtype=np.int64)
-        rows = self.local_ids[: self.n_rows]
-        lc = lut[cols[rows]]
-        lv = vals[rows].astype(np.float32)
-        if depth == 0:  # K = 1: no product with L~ is ever taken, the local matrix is a placeholder
-            lv = np.zeros_like(lv)
+        # local ELL with remapped columns (a sparse global -> local map: nothing of size M is allocated per rank
+        # beyond the BFS's bitmap)
+        order = np.argsort(self.local_ids, kind="stable")
+        sorted_ids = self.local_ids[order]
+
+        def to_local(g):
+            pos = np.searchsorted(sorted_ids, g)
+            pos = np.minimum(pos, sorted_ids.size - 1)
+            hit = sorted_ids[pos] == g
+            return np.where(hit, order[pos], -1)
+
+        self._to_local = to_local
+        if depth >= 1:
+            rc = np.concatenate(row_cols[:depth]) if self.n_rows else np.zeros((0, 1), np.int64)
+            rv = np.concatenate(row_vals[:depth]) if self.n_rows else np.zeros((0, 1), np.float32)
+            assert np.array_equal(np.concatenate(row_ids[:depth]), self.local_ids[: self.n_rows])
+        else:  # K = 1: no product with L~ is ever taken, the local matrix is a placeholder
+            rc, rv = fetch(np.arange(a, b, dtype=np.int64))
+            rv = np.zeros_like(rv)
+        lv = np.asarray(rv, dtype=np.float32)
+        lc = to_local(np.asarray(rc, dtype=np.int64))
         dead = lv == 0
         lc = np.where(dead, np.arange(self.n_rows, dtype=np.int64)[:, None], lc)
         if (lc < 0).any():
             raise RuntimeError("a row within K-2 hops has a neighbour outside the K-1 hop halo")
         self.local_cols = lc.astype(np.int32)
         self.local_vals = lv
-        # exchange lists: what I send to p = halo(p) ∩ own(me); what I receive from p = halo(me) ∩ own(p)
-        self.send_local = {}  # p -> local row indices (into my own rows) to pack, ascending global id
+        # what I receive from p = halo(me) ∩ own(p): also the request p has to serve
+        self.requests = {}    # p -> global ids (ascending) of p's rows this rank needs
         self.recv_local = {}  # p -> local positions (>= n_own) the rows from p land in
         for p in range(world):
             if p == rank:
                 continue
-            hp = np.concatenate(self.halo[p]) if self.halo[p] else np.zeros(0, np.int64)
-            mine = np.sort(hp[(hp >= a) & (hp < b)])
-            if mine.size:
-                self.send_local[p] = (mine - a).astype(np.int64)
             pa, pb = self.ranges[p]
             theirs = np.sort(self.halo_ids[(self.halo_ids >= pa) & (self.halo_ids < pb)])
             if theirs.size:
-                self.recv_local[p] = lut[theirs]
+                self.requests[p] = theirs
+                self.recv_local[p] = to_local(theirs)
+        # what I send to p = halo(p) ∩ own(me) = p's request to me
+        self.send_local = {} if world == 1 else None  # p -> local row indices (into my own rows) to pack, ascending global id
+        if world == 1:
+            pass
+        elif isinstance(peer_requests, str) and peer_requests == "replicated":
+            if self._whole is not None:
+                self.set_peer_requests(self.peer_requests_replicated())
+        elif peer_requests is not None:
+            self.set_peer_requests(peer_requests)
+
+    def set_peer_requests(self, peer_requests):
+        """``peer_requests[p]`` = the global ids (of this rank's rows) that rank p asked for."""
+        a, b = self.own
+        self.send_local = {}
+        for p, ids in peer_requests.items():
+            if p == self.rank or ids is None:
+                continue
+            ids = np.sort(np.asarray(ids, dtype=np.int64))
+            if ids.size == 0:
+                continue
+            if ids[0] < a or ids[-1] >= b:
+                raise ValueError(f"rank {p} asked rank {self.rank} for rows it does not own")
+            self.send_local[p] = ids - a
+
+    def peer_requests_replicated(self):
+        """Single-process stand-in for the set-up gather: walk every other rank's range on the whole ELL (world x the
+        work; what ``ShardedChebyshev`` avoids when a process group exists)."""
+        if self._whole is None:
+            raise RuntimeError("the other ranks' requests need the whole ELL or a set-up gather")
+        cols, vals = self._whole
+        a, b = self.own
+        depth = max(self.K - 1, 0)
+        out = {}
+        for p, (pa, pb) in enumerate(self.ranges):
+            if p == self.rank:
+                continue
+            lv, _, _, _ = self._levels(lambda ids: (cols[ids], vals[ids]), self.M, pa, pb, depth)
+            hp = np.concatenate(lv) if lv else np.zeros(0, np.int64)
+            out[p] = np.sort(hp[(hp >= a) & (hp < b)])
+        return out
 
     @staticmethod
-    def _levels(cols, vals, a, b, depth):
-        M = cols.shape[0]
+    def _levels(fetch, M, a, b, depth):
+        """Hop levels 1..depth of the row range [a, b) and the ELL rows read on the way: ids / cols / vals of level
+        0 (the range itself), 1, ..., depth-1."""
         seen = np.zeros(M, dtype=bool)
         seen[a:b] = True
-        out = []
+        out, row_ids, row_cols, row_vals = [], [], [], []
         frontier = np.arange(a, b, dtype=np.int64)
         for _ in range(depth):
             if frontier.size == 0:
                 out.append(np.zeros(0, np.int64))
+                row_ids.append(frontier)
+                row_cols.append(np.zeros((0, row_cols[0].shape[1] if row_cols else 1), np.int64))
+                row_vals.append(np.zeros((0, row_vals[0].shape[1] if row_vals else 1), np.float32))
                 continue
-            c = cols[frontier]
-            nb = np.unique(c[vals[frontier] != 0])
+            c, v = fetch(frontier)
+            c = np.asarray(c)
+            v = np.asarray(v)
+            row_ids.append(frontier)
+            row_cols.append(c.astype(np.int64))
+            row_vals.append(v.astype(np.float32))
+            nb = np.unique(c[v != 0])
             new = nb[~seen[nb]].astype(np.int64)
             seen[new] = True
             out.append(new)
             frontier = new
-        return out
+        return out, row_ids, row_cols, row_vals
 
 
 def _pack(src, idx):
@@ -126,8 +202,8 @@ def _unpack(dst, idx, buf):
 class ShardedChebyshev:
     """One rank's share of a Chebyshev layer whose map is split over ``world`` processes.
 
-    ``ell_cols`` / ``ell_vals``: the whole prepared Laplacian in padded ELL form (every rank passes
-    the same arrays).  ``kernel``: the layer's [Fin*K, Fout] weights (same on every rank).
+    ``ell_cols`` / ``ell_vals``: the prepared Laplacian in padded ELL form -- the whole arrays (every rank passes
+    the same ones) or, with ``M``, a callable producing rows on demand (``ShardLayout``).  ``kernel``: the layer's [Fin*K, Fout] weights (same on every rank).
     Call with this rank's rows ``x_local`` of shape (N, own_rows, Fin); returns (N, own_rows, Fout).
     ``group``: a torch.distributed process group (default: the world group).
     ``_compute``: test seam -- a callable ``(layout, x_ext, kernel) -> y`` replacing the HIP forward so
@@ -135,8 +211,19 @@ class ShardedChebyshev:
     """
 
     def __init__(self, ell_cols, ell_vals, K, Fout=None, rank=0, world=1, device=None, precision="fp32",
-                 algo="auto", kernel=None, bias=None, act=_native.ACT_NONE, group=None, _compute=None):
-        self.layout = ShardLayout(ell_cols, ell_vals, K, rank, world)
+                 algo="auto", kernel=None, bias=None, act=_native.ACT_NONE, group=None, _compute=None, M=None):
+        import torch.distributed as dist
+
+        gather = int(world) > 1 and dist.is_available() and dist.is_initialized()
+        self.layout = ShardLayout(ell_cols, ell_vals, K, rank, world, M=M, peer_requests=None if gather else "replicated")
+        if gather:
+            # set-up only: every rank publishes which rows it needs from whom; a rank learns its send lists from that
+            # instead of walking the other ranks' ranges (world x the work, and the whole ELL on every rank)
+            everyone = [None] * int(world)
+            dist.all_gather_object(everyone, {int(p): v for p, v in self.layout.requests.items()}, group=group)
+            self.layout.set_peer_requests({p: everyone[p].get(int(rank)) for p in range(int(world)) if p != int(rank)})
+        if self.layout.send_local is None:
+            raise RuntimeError("ShardedChebyshev with a row producer needs an initialised process group (or world = 1)")
         self.K, self.rank, self.world = int(K), int(rank), int(world)
         self.own_rows = self.layout.n_own
         self.device = torch.device(device) if device is not None else torch.device("cpu")

@@ -133,11 +133,31 @@ def test_fused_kernel(graph, nside, N, Fin, Fout, K, prec, tol):
 
 
 def test_fused_refuses_what_it_cannot_tile():
-    c = load_case("dense3")
-    plan = _plan(c["Lt"])
-    assert not plan.fused_ok(7, 3, 4)
+    """A graph whose (K-1)-ring regions outgrow the LDS planes (random 8-regular: an expander) is refused by the fused
+    path, loudly, and served by the unfused one; the reference tests' dense 3x3 L with 7 input channels (refused in
+    round 1 for its channel count) is now tiled."""
+    rng = np.random.default_rng(5)
+    M = 8192
+    nb = rng.integers(0, M, size=(M, 8))
+    A = sparse.csr_matrix((np.ones(M * 8), (np.repeat(np.arange(M), 8), nb.reshape(-1))), shape=(M, M))
+    A = ((A + A.T) > 0).astype(np.float64)
+    A.setdiag(0)
+    A.eliminate_zeros()
+    L = sparse.diags(np.asarray(A.sum(1)).ravel()) - A
+    Lt = utils.rescale_L(sparse.csr_matrix(L), lmax=2.0 * float(A.sum(1).max()), scale=0.75)
+    plan = _plan(Lt)
+    assert not plan.fused_ok(8, 8, 5)
+    x = rng.standard_normal((1, M, 8)).astype(np.float32)
+    W = rng.standard_normal((8 * 5, 8)).astype(np.float32) * 0.1
     with pytest.raises(RuntimeError):
-        _native.cheb_forward(plan, _dev(c["x"]), _dev(c["kernel"]), None, c["K"], algo=_native.ALGO_FUSED)
+        _native.cheb_forward(plan, _dev(x), _dev(W), None, 5, algo=_native.ALGO_FUSED)
+    y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), None, 5)
+    assert rel_err(y.cpu().numpy(), orc.chebyshev_forward(Lt, x, W, 5)) < TOL_FP32
+    c = load_case("dense3")
+    plan3 = _plan(c["Lt"])
+    assert plan3.fused_ok(7, 3, 4)
+    y3, _ = _native.cheb_forward(plan3, _dev(c["x"]), _dev(c["kernel"]), None, c["K"], algo=_native.ALGO_FUSED)
+    assert rel_err(y3.cpu().numpy(), orc.chebyshev_forward(c["Lt"], c["x"], c["kernel"], c["K"])) < TOL_FP32
 
 
 def test_bitwise_determinism():

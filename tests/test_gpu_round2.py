@@ -310,3 +310,46 @@ def test_batch_norm_default_is_inference_like_the_reference():
     y1 = layer(x, training=True)
     assert float(layer.bn.running_mean.abs().max()) > 0.0
     assert not torch.allclose(y0, y1)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("nside,N,Fin,Fout,K,graph", [
+    (64, 1, 1, 16, 5, "grid"),    # BASELINE configs[0]: the first layer of every reference model has one input channel
+    (64, 2, 3, 8, 4, "grid"),
+    (64, 2, 5, 70, 5, "grid"),    # one padded quad in the second 16-byte piece, two column blocks
+    (32, 3, 7, 12, 3, "grid"),    # below the structured kernel's size: BFS tiles only
+    (16, 2, 2, 5, 5, "knn"),      # ELL width 11, no structured tiles
+    (64, 1, 33, 20, 5, "grid"),   # three slices, the last with one real channel
+])
+def test_fused_forward_channel_counts_not_multiple_of_four(nside, N, Fin, Fout, K, graph, prec):
+    """VERDICT r1 item 8: Fin in {1, 2, 3} and Fin % 4 != 0 take the fused path (x is zero-padded into the workspace);
+    whole map against the float64 oracle, and AUTO must pick the fused path for them."""
+    if graph == "grid":
+        cols, vals = _grid_ell(nside)
+    else:
+        Lt, _ = utils.prepare_L(healpix.healpix_laplacian(nside, mode="knn"))
+        cols, vals = utils.csr_to_ell(Lt)
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    assert plan.fused_ok(Fin, Fout, K)
+    rng = np.random.default_rng(7 * nside + Fin)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    ref = orc.chebyshev_forward(_csr(cols, vals), x, W, K, bias=b, activation="relu")
+    P = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3}[prec]
+    y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=P, algo=_native.ALGO_FUSED)
+    err = rel_err(y.cpu().numpy(), ref)
+    print(f"padded channels nside={nside} {Fin}->{Fout} K={K} {graph} {prec}: rel err {err:.2e}")
+    assert err < TOL
+    ya, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=P, algo=_native.ALGO_AUTO)
+    assert torch.equal(ya, y)  # AUTO = the fused path whenever fused_ok (dsphere_api.hip resolve_algo)
+    yu, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=P, algo=_native.ALGO_UNFUSED)
+    assert rel_err(yu.cpu().numpy(), ref) < TOL
+    # NaN in the bytes behind the last real channel must not leak in: x as a view with garbage between rows is not
+    # representable at this boundary (x is dense), but the padded copy must not read past the last row either
+    xs = torch.full((N * M * Fin + 64,), float("nan"), device="cuda")
+    xs[: N * M * Fin] = _dev(x).reshape(-1)
+    y3, _ = _native.cheb_forward(plan, xs[: N * M * Fin].view(N, M, Fin), _dev(W), _dev(b), K, act=_native.ACT_RELU,
+                                 precision=P, algo=_native.ALGO_FUSED)
+    assert torch.equal(y3, y)

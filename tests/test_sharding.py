@@ -86,7 +86,18 @@ def _worker(rank, world, port, K, partial, out):
         Fin, Fout, N = 3, 4, 2
         x = rng.standard_normal((N, M, Fin)).astype(np.float32)
         W = rng.standard_normal((Fin * K, Fout)).astype(np.float32)
-        sh = sharding.ShardedChebyshev(cols, vals, K, rank=rank, world=world, kernel=W, _compute=_oracle_compute)
+        fetched = []
+        if partial:
+            sh = sharding.ShardedChebyshev(cols, vals, K, rank=rank, world=world, kernel=W, _compute=_oracle_compute)
+        else:  # the ELL as a row producer: this rank must read its own rows and halo only, and no other rank's range
+            def producer(ids):
+                fetched.append(np.asarray(ids))
+                return cols[ids], vals[ids]
+
+            sh = sharding.ShardedChebyshev(producer, None, K, rank=rank, world=world, kernel=W, _compute=_oracle_compute, M=M)
+            got = np.concatenate(fetched) if fetched else np.zeros(0, np.int64)
+            assert got.size == np.unique(got).size <= sh.layout.n_cols  # every row once, nothing outside own + halo
+            assert set(got.tolist()) <= set(sh.layout.local_ids.tolist())
         a, b = sh.layout.own
         if partial:  # second form of the input: written straight into the extended buffer (no copy of own rows)
             view = sh.own_rows_view(N, Fin)
@@ -133,3 +144,27 @@ def test_sharded_layer_refuses_cpu_compute():
     _, cols, vals = _prepared_ell(4, "knn")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         sharding.ShardedChebyshev(cols, vals, 3, rank=0, world=1, kernel=np.zeros((9, 2), np.float32))
+
+
+@pytest.mark.parametrize("world,K", [(4, 5), (8, 8), (3, 1)])
+def test_layout_from_row_producer_and_gathered_requests(world, K):
+    """A rank that sees only a row producer and the other ranks' requests builds the same layout as one that walks
+    every range on the whole ELL."""
+    _, cols, vals = _prepared_ell(8, "knn")
+    M = cols.shape[0]
+    ref = [sharding.ShardLayout(cols, vals, K, r, world) for r in range(world)]
+    own = [sharding.ShardLayout(lambda ids: (cols[ids], vals[ids]), None, K, r, world, M=M, peer_requests=None)
+           for r in range(world)]
+    for r in range(world):
+        assert own[r].send_local is None
+        own[r].set_peer_requests({p: own[p].requests.get(r) for p in range(world) if p != r})
+        for name in ("local_ids", "local_cols", "local_vals", "levels"):
+            assert np.array_equal(getattr(own[r], name), getattr(ref[r], name)), name
+        assert own[r].n_rows == ref[r].n_rows and own[r].n_cols == ref[r].n_cols
+        assert set(own[r].send_local) == set(ref[r].send_local) and set(own[r].recv_local) == set(ref[r].recv_local)
+        for p in ref[r].send_local:
+            assert np.array_equal(own[r].send_local[p], ref[r].send_local[p])
+        for p in ref[r].recv_local:
+            assert np.array_equal(own[r].recv_local[p], ref[r].recv_local[p])
+    with pytest.raises(ValueError, match="does not own"):
+        own[0].set_peer_requests({1: np.array([M - 1])})
