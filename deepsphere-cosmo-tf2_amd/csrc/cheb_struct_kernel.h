@@ -39,6 +39,26 @@
 
 namespace dsph {
 
+// Tuning builds only (tools/ab_ablate.sh; the results are wrong by construction, the shipped library defines neither):
+// -DDSPH_ST_ABL_DIRS=n sums n of the 8 directions, -DDSPH_ST_ABL_READS=1 reads only window row 0 from LDS.
+#ifdef DSPH_ST_ABL_DIRS
+#define ST_ABL_DIRS DSPH_ST_ABL_DIRS
+#else
+#define ST_ABL_DIRS 8
+#endif
+#ifdef DSPH_ST_ABL_READS
+#define ST_ABL_READS 1
+#else
+#define ST_ABL_READS 0
+#endif
+// -DDSPH_ST_ABL_SKIP=bits: 1 no recurrence step at all, 2 no contraction, 4 no LDS-DMA, 8 no y store
+#ifdef DSPH_ST_ABL_SKIP
+#define ST_ABL_SKIP DSPH_ST_ABL_SKIP
+#else
+#define ST_ABL_SKIP 0
+#endif
+
+
 constexpr int ST_TILE = 16;                     // tile side in pixels: 256 consecutive NEST rows
 constexpr int ST_DMAX = 4;                      // halo rings held: K <= 5
 constexpr int ST_S = ST_TILE + 2 * ST_DMAX;     // plane side, 24 cells
@@ -142,6 +162,7 @@ __device__ __forceinline__ void st_glds16_off(const void* sbase_in, unsigned vof
   const unsigned long long ubits = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bits) |
                                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bits >> 32)) << 32);
   const void* sbase = reinterpret_cast<const void*>(ubits);
+  if (ST_ABL_SKIP & 4) return;
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -149,19 +170,6 @@ __device__ __forceinline__ void st_glds16_off(const void* sbase_in, unsigned vof
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
 }
-
-// Tuning builds only (tools/ab_ablate.sh; the results are wrong by construction, the shipped library defines neither):
-// -DDSPH_ST_ABL_DIRS=n sums n of the 8 directions, -DDSPH_ST_ABL_READS=1 reads only window row 0 from LDS.
-#ifdef DSPH_ST_ABL_DIRS
-#define ST_ABL_DIRS DSPH_ST_ABL_DIRS
-#else
-#define ST_ABL_DIRS 8
-#endif
-#ifdef DSPH_ST_ABL_READS
-#define ST_ABL_READS 1
-#else
-#define ST_ABL_READS 0
-#endif
 
 // One recurrence step for this lane's 2x2 block (gather waves): window from plane `pin` (byte offset), T_k to `pout`.
 //   FIRST: T_1 = L~ T_0, the block's own T_0 is read too (16 reads) and kept in `cur`; otherwise the centre of the
@@ -174,6 +182,7 @@ template <bool FIRST, bool CHEB>
 __device__ __forceinline__ void st_gather(const unsigned char* __restrict__ smem, unsigned pin, unsigned pout,
                                           const unsigned (&gb)[4], const float (&v)[4][9], float4 (&cur)[4],
                                           float4 (&prev)[4], bool wr, unsigned dummy) {
+  if (ST_ABL_SKIP & 1) return;
   unsigned ob[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
@@ -241,6 +250,7 @@ __device__ __forceinline__ void st_gather(const unsigned char* __restrict__ smem
 template <int NB, int PREC>
 __device__ __forceinline__ void st_contract(const unsigned char* __restrict__ smem, unsigned plane, unsigned wblk,
                                             const unsigned (&mb)[2], int lane, st_f32x16 (&acc)[2][NB]) {
+  if (ST_ABL_SKIP & 2) return;
   float4 a[2][2];
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb) {
@@ -300,6 +310,7 @@ template <int NB>
 __device__ __forceinline__ void st_store(const st_f32x16 (&acc)[2][NB], unsigned char* __restrict__ smem, unsigned plane,
                                          int cw, float* __restrict__ ytile, int ld, const float* __restrict__ sBias,
                                          int lane, int Fout, float floor_v, bool vec) {
+  if (ST_ABL_SKIP & 8) return;
   const unsigned r = lane & 31, h = lane >> 5, j = lane & 7, pq = lane >> 3;
   // byte a of the 4 KiB block lives in chunk a >> 9 (512 B = the 8 cells of one column parity of one tile pixel row)
   auto scr = [&](unsigned a) -> unsigned {
