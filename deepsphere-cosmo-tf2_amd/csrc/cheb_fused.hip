@@ -59,6 +59,11 @@ struct FusedTiles {
   // class-R tiles (cheb_struct_kernel.h), interior ones first; empty in a full table
   int32_t* d_rlist = nullptr;
   int n_r = 0, n_r_interior = 0;
+  // class-T tiles (structured kernel with per-tile tables, embed_tile below), interior ones first
+  int32_t* d_tlist = nullptr;
+  int32_t* d_tabrow = nullptr;  // [n_t][ST_CELLS] row of every plane cell
+  float* d_tabvals = nullptr;   // [n_t][ST_CELLS][ST_TABV] diagonal + eight directions of L~ per cell, in the tile's frame
+  int n_t = 0, n_t_interior = 0;
 };
 
 struct FusedPlan {
@@ -90,6 +95,9 @@ static void free_tiles(FusedTiles& ft) {
   if (ft.d_lvals) (void)hipFree(ft.d_lvals);
   if (ft.d_part) (void)hipFree(ft.d_part);
   if (ft.d_rlist) (void)hipFree(ft.d_rlist);
+  if (ft.d_tlist) (void)hipFree(ft.d_tlist);
+  if (ft.d_tabrow) (void)hipFree(ft.d_tabrow);
+  if (ft.d_tabvals) (void)hipFree(ft.d_tabvals);
   ft = FusedTiles();
 }
 
@@ -120,6 +128,135 @@ void fused_plan_invalidate(FusedPlan* fp) {
   std::lock_guard<std::mutex> lock(fp->mu);
   for (auto& kv : fp->by_depth) free_tiles(kv.second);
   fp->by_depth.clear();
+}
+
+// Class-T tiles: a tile whose own 256 rows are a 16x16 Morton square and whose D-ring region can be laid out as a
+// (16+2D)^2 square of a 9-point stencil although the ROW NUMBERS of the halo are not a Morton continuation (the next base
+// pixel of the sphere, possibly rotated; the halo rows of a sharded plan, numbered by hop distance).  The layout is
+// found from the graph alone, ring by ring: a new cell is the one row that all of its already-placed neighbours have in
+// common and that is not placed yet.  It is then VERIFIED, not trusted: every row that a step evaluates (rings 0..D-1)
+// must have each non-zero of L~ on itself or on one of its eight neighbouring cells; only then do the tables exist.
+// Anything else (the eight 7-neighbour corners of the sphere, mask edges, ragged tiles, k-NN graphs) stays class G.
+// row: [ST_CELLS] row of every plane cell (plane-cell order, pads and cells outside the region: the tile's first row);
+// val: [ST_CELLS][ST_TABV] diagonal, then the directions in the order of kDirX / kDirY.
+static bool embed_tile(const dsph_plan* plan, const int32_t* cols, const float* vals, int W, int t, int D, int64_t out_rows,
+                       int32_t* row, float* val, bool* interior, std::vector<int32_t>& key, std::vector<int32_t>& slot) {
+  const int64_t r0 = (int64_t)t * FUSED_P;
+  if (r0 + FUSED_P > out_rows) return false;  // ragged last tile
+  constexpr int S = ST_S;
+  int32_t A[S][S];
+  for (int y = 0; y < S; ++y)
+    for (int x = 0; x < S; ++x) A[x][y] = -1;
+  // open-addressing map row -> cell (x + S * y); 2048 slots for at most 576 entries
+  constexpr int HN = 2048;
+  key.assign(HN, -1);
+  slot.assign(HN, 0);
+  auto hput = [&](int32_t r, int cell) {
+    unsigned h = ((unsigned)r * 2654435761u) >> 21;
+    while (key[h] != -1) h = (h + 1) & (HN - 1);
+    key[h] = r;
+    slot[h] = cell;
+  };
+  auto hget = [&](int32_t r) -> int {
+    unsigned h = ((unsigned)r * 2654435761u) >> 21;
+    while (key[h] != -1) {
+      if (key[h] == r) return slot[h];
+      h = (h + 1) & (HN - 1);
+    }
+    return -1;
+  };
+  for (unsigned y = 0; y < 16; ++y)
+    for (unsigned x = 0; x < 16; ++x) {
+      const int32_t r = (int32_t)(r0 + st_morton(x, y));
+      A[ST_DMAX + x][ST_DMAX + y] = r;
+      hput(r, (ST_DMAX + x) + S * (ST_DMAX + y));
+    }
+  // the one unplaced row adjacent to every placed neighbour of cell (x, y); -1 if there is none or more than one
+  auto propose = [&](int x, int y) -> int32_t {
+    int32_t cand[16];
+    int nc = -1;  // -1: no anchor seen yet
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ax = x + dx, ay = y + dy;
+        if ((dx == 0 && dy == 0) || ax < 0 || ay < 0 || ax >= S || ay >= S || A[ax][ay] < 0) continue;
+        const int32_t ar = A[ax][ay];
+        if (ar >= plan->n_rows) continue;  // an input-only row has no list of neighbours: not an anchor
+        const int32_t* c = cols + (size_t)ar * W;
+        const float* v = vals + (size_t)ar * W;
+        if (nc < 0) {
+          nc = 0;
+          for (int j = 0; j < W; ++j)
+            if (v[j] != 0.f && c[j] != ar && hget(c[j]) < 0 && nc < 16) cand[nc++] = c[j];
+        } else {
+          int m = 0;
+          for (int i = 0; i < nc; ++i) {
+            bool in = false;
+            for (int j = 0; j < W && !in; ++j) in = v[j] != 0.f && c[j] == cand[i];
+            if (in) cand[m++] = cand[i];
+          }
+          nc = m;
+        }
+      }
+    return nc == 1 ? cand[0] : -1;
+  };
+  auto place = [&](int x, int y) -> bool {
+    const int32_t r = propose(x, y);
+    if (r < 0) return false;
+    A[x][y] = r;
+    hput(r, x + S * y);
+    return true;
+  };
+  for (int rho = 1; rho <= D; ++rho) {
+    const int lo = ST_DMAX - rho, hi = ST_DMAX + ST_TILE - 1 + rho;
+    // the four sides without their corners, from the middle outwards (so that each new cell has placed neighbours on
+    // the inner ring and, after the first, on its own side), then the corners
+    const int mid = (lo + hi) / 2;
+    for (int k = 0; k <= hi - lo; ++k) {
+      const int off = (k + 1) / 2 * ((k & 1) ? 1 : -1);  // 0, +1, -1, +2, -2, ...
+      const int u = mid + off;
+      if (u <= lo || u >= hi) continue;
+      if (!place(u, hi) || !place(u, lo) || !place(lo, u) || !place(hi, u)) return false;
+    }
+    if (!place(lo, lo) || !place(hi, lo) || !place(lo, hi) || !place(hi, hi)) return false;
+  }
+  // tables + verification
+  const int blo = ST_DMAX - D, bhi = ST_DMAX + ST_TILE - 1 + D;
+  for (int p = 0; p < ST_CELLS; ++p) {
+    row[p] = (int32_t)r0;
+    for (int j = 0; j < ST_TABV; ++j) val[(size_t)p * ST_TABV + j] = 0.f;
+  }
+  *interior = true;
+  for (int y = blo; y <= bhi; ++y)
+    for (int x = blo; x <= bhi; ++x) {
+      const int32_t r = A[x][y];
+      const unsigned p = st_cell_off((unsigned)x, (unsigned)y) / 64u;
+      row[p] = r;
+      if (r >= out_rows) *interior = false;
+      if (x == blo || x == bhi || y == blo || y == bhi) continue;  // outermost ring: input only
+      if (r >= plan->n_rows) return false;  // a row that a step evaluates has no row of L~
+      const int32_t* c = cols + (size_t)r * W;
+      const float* v = vals + (size_t)r * W;
+      float* o = val + (size_t)p * ST_TABV;
+      unsigned seen = 0;
+      for (int j = 0; j < W; ++j) {
+        if (v[j] == 0.f) continue;
+        int d = -1;
+        if (c[j] == r) d = 0;
+        else {
+          const int cell = hget(c[j]);
+          if (cell < 0) return false;
+          const int dx = cell % S - x, dy = cell / S - y;
+          static const int ddx[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, ddy[8] = {0, 1, 1, 1, 0, -1, -1, -1};  // = kDirX / kDirY
+          for (int q = 0; q < 8; ++q)
+            if (ddx[q] == dx && ddy[q] == dy) d = q + 1;
+          if (d < 0) return false;  // a non-zero that is not on one of the eight neighbouring cells
+        }
+        if (seen & (1u << d)) return false;
+        seen |= 1u << d;
+        o[d] = v[j];
+      }
+    }
+  return true;
 }
 
 // Breadth-first rings of every tile; uploads the tables.  Returns a reference to the cached entry.
@@ -170,6 +307,11 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
     if (fp->d_rowflag && struct_classify_tiles(plan, fp->d_rowflag, ntiles, D, out_rows, cls.data()) != DSPH_OK)
       std::fill(cls.begin(), cls.end(), 0);
   }
+  // class-T candidates: whatever the classification left over, when the structured kernel is in play at all
+  const bool try_tables = !full && D <= ST_DMAX && getenv("DSPH_NO_STRUCT") == nullptr && getenv("DSPH_NO_TABLES") == nullptr &&
+                          fp->d_rowflag != nullptr;
+  std::vector<int32_t> t_interior, t_boundary, trow_i, trow_b, e_row(ST_CELLS), h_key, h_slot;
+  std::vector<float> tval_i, tval_b, e_val((size_t)ST_CELLS * ST_TABV);
   int rmax = 0, emax = 0;
   int64_t ell_rows = 0;
   for (int t = 0; t < ntiles; ++t) {
@@ -181,6 +323,19 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
       ((cls[t] & 2) ? r_interior : r_boundary).push_back(t);
       ell_off[t] = ell_rows;
       continue;
+    }
+    if (try_tables) {  // class T: the structured kernel with per-tile tables
+      bool inner = false;
+      if (embed_tile(plan, cols, vals, W, t, D, out_rows, e_row.data(), e_val.data(), &inner, h_key, h_slot)) {
+        std::vector<int32_t>& lst = inner ? t_interior : t_boundary;
+        std::vector<int32_t>& rw = inner ? trow_i : trow_b;
+        std::vector<float>& vl = inner ? tval_i : tval_b;
+        lst.push_back(t);
+        rw.insert(rw.end(), e_row.begin(), e_row.end());
+        vl.insert(vl.end(), e_val.begin(), e_val.end());
+        ell_off[t] = ell_rows;
+        continue;
+      }
     }
     ring.clear();
     for (int64_t r = r0; r < r1; ++r) {
@@ -290,7 +445,16 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   r_interior.insert(r_interior.end(), r_boundary.begin(), r_boundary.end());
   ft.n_r = (int)r_interior.size();
   if (r_interior.empty()) r_interior.push_back(0);
-  bool good = up((void**)&ft.d_tile_off, tile_off.data(), tile_off.size() * 4) &&
+  ft.n_t_interior = (int)t_interior.size();
+  t_interior.insert(t_interior.end(), t_boundary.begin(), t_boundary.end());
+  trow_i.insert(trow_i.end(), trow_b.begin(), trow_b.end());
+  tval_i.insert(tval_i.end(), tval_b.begin(), tval_b.end());
+  ft.n_t = (int)t_interior.size();
+  if (t_interior.empty()) { t_interior.push_back(0); trow_i.push_back(0); tval_i.push_back(0.f); }
+  bool good = up((void**)&ft.d_tlist, t_interior.data(), t_interior.size() * 4) &&
+              up((void**)&ft.d_tabrow, trow_i.data(), trow_i.size() * 4) &&
+              up((void**)&ft.d_tabvals, tval_i.data(), tval_i.size() * 4) &&
+              up((void**)&ft.d_tile_off, tile_off.data(), tile_off.size() * 4) &&
               up((void**)&ft.d_ring_end, ring_end.data(), ring_end.size() * 4) &&
               up((void**)&ft.d_ell_off, ell_off.data(), ell_off.size() * 8) &&
               up((void**)&ft.d_region, region.data(), region.size() * 4) &&
@@ -333,7 +497,7 @@ static bool supported_impl(const dsph_plan* plan, int32_t Fin, int32_t Fout, int
   if (Fin % 4 != 0 || Fin < 4 || Fout < 1) return false;  // Fout > 64: one launch per 64-column block
   const FusedTiles& ft = get_tiles(plan, K - 1, full);
   if (!ft.ok) return false;
-  if (ft.n_r > 0 && !struct_shape_ok(Fin, std::min(Fout, 64), K)) return false;
+  if (ft.n_r + ft.n_t > 0 && !struct_shape_ok(Fin, std::min(Fout, 64), K)) return false;
   if (ft.n_part == 0) return true;  // every tile is class R
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   if (pr == 0) return false;
@@ -368,7 +532,7 @@ bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int6
   if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return false;
   const FusedTiles& ft = get_tiles(plan, K - 1, false);
   if (!ft.ok) return false;
-  *n_struct = ft.n_r;
+  *n_struct = ft.n_r + ft.n_t;
   *n_bfs = ft.n_part;
   return true;
 }
@@ -453,7 +617,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
   bool defer_act = false;
   if (act != DSPH_ACT_NONE && act != DSPH_ACT_RELU && K - 1 <= FUSED_DMAX && K >= 2) {
     const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
-    defer_act = ft.ok && ft.n_r > 0;
+    defer_act = ft.ok && ft.n_r + ft.n_t > 0;
   }
   if (defer_act && part != 0) {
     set_error("cheb_fused: interior / boundary launches support the activations NONE and RELU only");
@@ -588,23 +752,37 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     return DSPH_E_BADARG;
   }
   const int C = (Fin + FUSED_CH - 1) / FUSED_CH, NB = (Fout + 31) / 32;
-  // ---- class-R tiles: the structured-tile kernel (forward only) ------------------------------------------------
-  if (!planes_mode && ft.n_r > 0) {
+  // ---- class-R and class-T tiles: the structured-tile kernel (forward only), without and with per-tile tables ----------
+  if (!planes_mode && ft.n_r + ft.n_t > 0) {
+    StructLaunch sl;
+    sl.x = x; sl.w = w; sl.bias = bias; sl.y = y;
+    sl.wfrag = static_cast<unsigned char*>(workspace) + wb;
+    sl.gvals8 = plan->fused->d_gvals8;
+    sl.gdiag = plan->fused->d_gdiag;
+    sl.x_rows = plan->n_cols;
+    sl.y_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
+    sl.N = N;
+    sl.Fin = Fin; sl.Fin_w = Fin_w; sl.Fout = Fout; sl.K = K; sl.act = act; sl.precision = precision; sl.ld = ld;
+    sl.num_cu = plan->fused->num_cu;
+    sl.cheb = beta_rest != 0.f;
+    sl.prep_weights = true;  // the first of the two launches packs the fragments
     const int nr = part == 0 ? ft.n_r : (part == 1 ? ft.n_r_interior : ft.n_r - ft.n_r_interior);
     if (nr > 0 && !dbg_only('b')) {
-      StructLaunch sl;
-      sl.x = x; sl.w = w; sl.bias = bias; sl.y = y;
-      sl.wfrag = static_cast<unsigned char*>(workspace) + wb;
       sl.tiles = part == 2 ? ft.d_rlist + ft.n_r_interior : ft.d_rlist;
-      sl.gvals8 = plan->fused->d_gvals8;
-      sl.gdiag = plan->fused->d_gdiag;
-      sl.x_rows = plan->n_cols;
-      sl.y_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
-      sl.N = N;
+      sl.tabrow = nullptr;
+      sl.tabvals = nullptr;
       sl.ntiles = nr;
-      sl.Fin = Fin; sl.Fin_w = Fin_w; sl.Fout = Fout; sl.K = K; sl.act = act; sl.precision = precision; sl.ld = ld;
-      sl.num_cu = plan->fused->num_cu;
-      sl.cheb = beta_rest != 0.f;
+      const int rc = launch_cheb_struct(sl, stream);
+      if (rc != DSPH_OK) return rc;
+      sl.prep_weights = false;
+    }
+    const int nt = part == 0 ? ft.n_t : (part == 1 ? ft.n_t_interior : ft.n_t - ft.n_t_interior);
+    if (nt > 0 && !dbg_only('b')) {
+      const size_t first = part == 2 ? (size_t)ft.n_t_interior : 0;
+      sl.tiles = ft.d_tlist + first;
+      sl.tabrow = ft.d_tabrow + first * ST_CELLS;
+      sl.tabvals = ft.d_tabvals + first * ST_CELLS * ST_TABV;
+      sl.ntiles = nt;
       const int rc = launch_cheb_struct(sl, stream);
       if (rc != DSPH_OK) return rc;
     }

@@ -161,9 +161,11 @@ size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
 
 int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   const int C = (s.Fin + 15) / 16, NB = (s.Fout + 31) / 32;
-  hipLaunchKernelGGL(struct_wprep_kernel, dim3(C * s.K * NB), dim3(256), 0, stream, s.w, s.wfrag, (int)s.Fin_w, (int)s.Fout,
-                     (int)s.K, C, NB, (int)s.precision, (int)s.ld);
-  DSPH_HIP(hipGetLastError());
+  if (s.prep_weights) {
+    hipLaunchKernelGGL(struct_wprep_kernel, dim3(C * s.K * NB), dim3(256), 0, stream, s.w, s.wfrag, (int)s.Fin_w, (int)s.Fout,
+                       (int)s.K, C, NB, (int)s.precision, (int)s.ld);
+    DSPH_HIP(hipGetLastError());
+  }
   StructArgs a;
   a.x = s.x;
   a.bias = s.bias;
@@ -172,6 +174,8 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   a.tiles = s.tiles;
   a.gvals8 = s.gvals8;
   a.gdiag = s.gdiag;
+  a.tabrow = s.tabrow;
+  a.tabvals = s.tabvals;
   a.x_rows = s.x_rows;
   a.y_rows = s.y_rows;
   a.ntiles = s.ntiles;
@@ -191,10 +195,13 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   a.stamps = d_stamps;
 #endif
   void (*kern)(StructArgs) = nullptr;
-#define DSPH_ST_PICK(P, CH) (NB == 1 ? cheb_struct_kernel<1, P, CH> : cheb_struct_kernel<2, P, CH>)
+  const bool tab = s.tabrow != nullptr;
+#define DSPH_ST_PICK2(P, CH, TB) (NB == 1 ? cheb_struct_kernel<1, P, CH, TB> : cheb_struct_kernel<2, P, CH, TB>)
+#define DSPH_ST_PICK(P, CH) (tab ? DSPH_ST_PICK2(P, CH, true) : DSPH_ST_PICK2(P, CH, false))
   if (s.precision == DSPH_PREC_BF16X3) kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_BF16X3, true) : DSPH_ST_PICK(DSPH_PREC_BF16X3, false);
   else kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_FP32, true) : DSPH_ST_PICK(DSPH_PREC_FP32, false);
 #undef DSPH_ST_PICK
+#undef DSPH_ST_PICK2
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), 0, stream, a);
   DSPH_HIP(hipGetLastError());
 #ifdef DSPH_STAMPS

@@ -75,6 +75,7 @@ constexpr int ST_LDS_BIAS = ST_LDS_W + 2 * ST_WSLICE_BYTES;  // 160,768
 constexpr int ST_LDS_ROWS = ST_LDS_BIAS + 256;               // byte offset, inside a map, of the x row of every plane cell
 constexpr int ST_LDS_TOTAL = ST_LDS_ROWS + ST_CELLS * 4;     // 163,520 of 163,840
 constexpr int ST_DMA_PIECES = ST_CELLS / 16;    // 39 wave-instructions of 1 KiB fill a plane
+constexpr int ST_TABV = 12;                     // floats per cell of a class-T tile's value table (9 used: 3 x 16 B)
 
 typedef float st_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
@@ -87,6 +88,8 @@ struct StructArgs {
   const int32_t* tiles;        // the class-R tiles this launch handles
   const float* gvals8;         // [rows][8] values of L~ by direction (order of kDirX / kDirY below)
   const float* gdiag;          // [rows]    diagonal of L~
+  const int32_t* tabrow;       // TAB kernels (class-T tiles): [ntiles][ST_CELLS] row of every plane cell, and
+  const float* tabvals;        //   [ntiles][ST_CELLS][ST_TABV] diagonal + eight directions of every cell's row of L~
   int64_t x_rows, y_rows;
   int ntiles, N, Fin, Fout, K, C, act, ld;
 #ifdef DSPH_STAMPS
@@ -373,7 +376,10 @@ template <int PREC> struct StPieces {
 #endif
 };
 
-template <int NB, int PREC, bool CHEB>
+// TAB: the rows of the plane cells and their values of L~ come from per-tile tables (class-T tiles: the region is a
+// stencil square, but the row numbers of its halo are not a Morton continuation of the tile's) instead of Morton
+// arithmetic + gvals8 / gdiag (class R).  Everything else is the same code.
+template <int NB, int PREC, bool CHEB, bool TAB>
 __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[ST_LDS_TOTAL];
   float* const sBias = reinterpret_cast<float*>(smem + ST_LDS_BIAS);
@@ -489,12 +495,21 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const unsigned gx = 2 * bx + 1 + (p & 1), gy = 2 * by + 1 + (p >> 1);
-          const unsigned rid = ld_ok ? st_morton(X0 + gx - ST_DMAX, Y0 + gy - ST_DMAX) : row0;
-          const float4 n0 = *reinterpret_cast<const float4*>(a.gvals8 + (size_t)rid * 8);
-          const float4 n1 = *reinterpret_cast<const float4*>(a.gvals8 + (size_t)rid * 8 + 4);
-          v[p][0] = a.gdiag[rid];
-          v[p][1] = n0.x; v[p][2] = n0.y; v[p][3] = n0.z; v[p][4] = n0.w;
-          v[p][5] = n1.x; v[p][6] = n1.y; v[p][7] = n1.z; v[p][8] = n1.w;
+          if (TAB) {  // (cells that no step evaluates hold zeros in the table)
+            const float4* __restrict__ q =
+                reinterpret_cast<const float4*>(a.tabvals + ((size_t)t * ST_CELLS + st_cell_off(gx, gy) / 64u) * ST_TABV);
+            const float4 n0 = q[0], n1 = q[1], n2 = q[2];
+            v[p][0] = n0.x; v[p][1] = n0.y; v[p][2] = n0.z; v[p][3] = n0.w;
+            v[p][4] = n1.x; v[p][5] = n1.y; v[p][6] = n1.z; v[p][7] = n1.w;
+            v[p][8] = n2.x;
+          } else {
+            const unsigned rid = ld_ok ? st_morton(X0 + gx - ST_DMAX, Y0 + gy - ST_DMAX) : row0;
+            const float4 n0 = *reinterpret_cast<const float4*>(a.gvals8 + (size_t)rid * 8);
+            const float4 n1 = *reinterpret_cast<const float4*>(a.gvals8 + (size_t)rid * 8 + 4);
+            v[p][0] = a.gdiag[rid];
+            v[p][1] = n0.x; v[p][2] = n0.y; v[p][3] = n0.z; v[p][4] = n0.w;
+            v[p][5] = n1.x; v[p][6] = n1.y; v[p][7] = n1.z; v[p][8] = n1.w;
+          }
         }
       }
       int n = 0, c = 0;  // map and slice of the current item
@@ -592,7 +607,8 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     for (unsigned p = (unsigned)(tid - 64 * ST_GATHER_WAVES); p < (unsigned)ST_CELLS; p += 64 * ST_CONTRACT_WAVES) {
       const unsigned par = p / ST_HP, rem = p % ST_HP, gxh = rem % ST_P2, gy = rem / ST_P2, gx = 2 * gxh + par;
       const bool ok = gxh < ST_S / 2 && (int)gx >= lo && (int)gx <= hi && (int)gy >= lo && (int)gy <= hi;
-      const unsigned rid = ok ? st_morton(X0 + gx - ST_DMAX, Y0 + gy - ST_DMAX) : row0;
+      const unsigned rid = TAB ? (unsigned)a.tabrow[(size_t)tpos * ST_CELLS + p]
+                               : (ok ? st_morton(X0 + gx - ST_DMAX, Y0 + gy - ST_DMAX) : row0);
       sRow[p] = rid * (unsigned)a.Fin * 4u;
     }
   };

@@ -101,6 +101,9 @@ struct StructLaunch {
   int32_t ntiles, Fin, Fout, K, act, precision, ld, num_cu;
   int32_t Fin_w;             // channels of w (< Fin when x was zero-padded to a multiple of four channels)
   bool cheb;
+  const int32_t* tabrow = nullptr;  // class-T tiles: [ntiles][ST_CELLS] rows and [ntiles][ST_CELLS][ST_TABV] values
+  const float* tabvals = nullptr;   // (null: class-R tiles, rows by Morton arithmetic, values from gvals8 / gdiag)
+  bool prep_weights = true;         // pack the weight fragments first (false: an earlier launch of this forward did)
 };
 int struct_build_rows(const dsph_plan* plan, float** gvals8, float** gdiag, unsigned char** flag);
 int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, int ntiles, int D, int64_t out_rows,

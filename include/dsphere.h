@@ -109,8 +109,10 @@ int64_t dsph_plan_out_rows(const dsph_plan* plan, int32_t K); /* rows y is produ
 int dsph_plan_fused_ok(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 
 /* How the fused forward with K terms splits the plan's 256-row tiles between its two kernels: *n_struct tiles whose
- * (K-1)-ring region was verified to be a plain square of a 2-D 9-point stencil in Z-order (structured-tile kernel,
- * csrc/cheb_struct_kernel.h) and *n_bfs tiles handled through breadth-first ring tables (csrc/cheb_fused_kernel.h).
+ * (K-1)-ring region was verified to be a square of a 2-D 9-point stencil (structured-tile kernel,
+ * csrc/cheb_struct_kernel.h: either the rows of the region are a plain Z-order continuation of the tile's, or the
+ * region was laid out from the graph and is addressed through per-tile tables -- base-pixel borders of the sphere, halo
+ * rows of a sharded plan) and *n_bfs tiles handled through breadth-first ring tables (csrc/cheb_fused_kernel.h).
  * DSPH_E_UNSUPPORTED when neither kernel can run the plan (the unfused path then serves dsph_cheb_forward). */
 int dsph_plan_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
 

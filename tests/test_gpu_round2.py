@@ -353,3 +353,36 @@ def test_fused_forward_channel_counts_not_multiple_of_four(nside, N, Fin, Fout, 
     y3, _ = _native.cheb_forward(plan, xs[: N * M * Fin].view(N, M, Fin), _dev(W), _dev(b), K, act=_native.ACT_RELU,
                                  precision=P, algo=_native.ALGO_FUSED)
     assert torch.equal(y3, y)
+
+
+@pytest.mark.parametrize("nside", [64, 128])
+def test_table_tiles_cover_base_pixel_borders(nside):
+    """Tiles on the borders of the 12 base pixels run on the structured kernel through per-tile tables (their halo is a
+    stencil square whose row numbers are not a Morton continuation -- rotated across the polar base pixels): only the
+    24 tiles that touch one of the eight 7-neighbour vertices stay with the BFS-tile kernel.  Whole map against the
+    float64 oracle, bias + ReLU, both precisions; the same on a plan whose halo rows are numbered by hop distance."""
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    K, Fin, Fout, N = 5, 16, 24, 2
+    n_struct, n_bfs = plan.tile_counts(K)
+    assert (n_struct, n_bfs) == (M // 256 - 24, 24)
+    rng = np.random.default_rng(nside)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    ref = orc.chebyshev_forward(_csr(cols, vals), x, W, K, bias=b, activation="relu")
+    for P in (_native.PREC_FP32, _native.PREC_BF16X3):
+        y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=P, algo=_native.ALGO_FUSED)
+        assert rel_err(y.cpu().numpy(), ref) < TOL
+    # a shard of the same map: own rows in NEST order, halo rows appended by hop distance
+    from deepsphere import sharding
+
+    lay = sharding.ShardLayout(cols, vals, K, 1, 4)
+    sp = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols, device=0, levels=lay.levels)
+    s_struct, s_bfs = sp.tile_counts(K)
+    assert s_struct + s_bfs == lay.n_own // 256 and s_bfs <= 6  # this rank's share of the 24
+    xe = _dev(x[:, lay.local_ids])
+    ys, _ = _native.cheb_forward(sp, xe, _dev(W), _dev(b), K, act=_native.ACT_RELU, algo=_native.ALGO_FUSED)
+    a, e = lay.own
+    assert rel_err(ys.cpu().numpy(), ref[:, a:e]) < TOL
