@@ -199,6 +199,63 @@ def _unpack(dst, idx, buf):
     return dst
 
 
+class _ShardedConvFunction(torch.autograd.Function):
+    """The sharded forward as a differentiable op (no bias, no activation), so that ``ShardedChebyshev`` can train.
+
+    For an upstream gradient dy on this rank's rows (L~ symmetric, as every graph Laplacian is):
+    * dx on the rank's rows = the same forward applied to dy with the weights re-indexed ``[o*K + k, f]`` -- it needs dy
+      on the (K-1)-ring halo, i.e. ONE more halo exchange with the very send / receive lists of the forward;
+    * dkernel = the rank's partial sum ``sum_{n, m in own rows} (T_k x)[n,m,f] dy[n,m,o]`` (``dsph_cheb_backward_weights`` on the
+      local plan, whose planes are exact on the own rows) followed by ONE all-reduce of the ``[Fin*K, Fout]`` array (80 KiB
+      at K 5, 64 -> 64) -- the only collective of the whole path.  The weights are replicated, so every rank ends up with
+      the same gradient.
+    The reference trains these layers on one device (``examples/advanced_tutorial.ipynb``) and has no distributed code."""
+
+    @staticmethod
+    def forward(ctx, x_local, kernel, shard):
+        y = shard._forward(x_local, kernel.detach(), None, _native.ACT_NONE)
+        # the extended input is needed again for dkernel: keep this buffer, the next forward gets a fresh one
+        ctx.x_ext = shard._x_ext
+        shard._x_ext = None
+        ctx.shard = shard
+        ctx.save_for_backward(kernel)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shard = ctx.shard
+        (kernel,) = ctx.saved_tensors
+        K = shard.K
+        x_ext = ctx.x_ext
+        Fin = x_ext.shape[2]
+        Fout = kernel.shape[1]
+        dy = dy.contiguous()
+        dx = dk = None
+        if ctx.needs_input_grad[0]:
+            kernel_t = kernel.detach().reshape(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()
+            dx = shard._forward(dy, kernel_t, None, _native.ACT_NONE, buf="_dy_ext")
+        if ctx.needs_input_grad[1]:
+            dk = shard._wgrad_local(x_ext, dy)
+            shard._all_reduce(dk)
+        ctx.x_ext = None
+        return dx, dk, None
+
+
+class _ReplicatedGrad(torch.autograd.Function):
+    """Identity on a replicated parameter (the bias) whose gradient is the sum of the ranks' partial gradients."""
+
+    @staticmethod
+    def forward(ctx, p, shard):
+        ctx.shard = shard
+        return p.view_as(p)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        ctx.shard._all_reduce(g)
+        return g, None
+
+
 class ShardedChebyshev:
     """One rank's share of a Chebyshev layer whose map is split over ``world`` processes.
 
@@ -207,11 +264,15 @@ class ShardedChebyshev:
     Call with this rank's rows ``x_local`` of shape (N, own_rows, Fin); returns (N, own_rows, Fout).
     ``group``: a torch.distributed process group (default: the world group).
     ``_compute``: test seam -- a callable ``(layout, x_ext, kernel) -> y`` replacing the HIP forward so
-    that the exchange logic can be exercised under gloo on CPU; never set by product code.
+    that the exchange logic can be exercised under gloo on CPU; never set by product code (``_compute_wgrad``:
+    the same for the rank's partial weight gradient, ``(layout, x_ext, dy) -> dkernel``).
+    Pass ``kernel`` (and ``bias``) as torch tensors that require grad and the call is differentiable: see
+    ``_ShardedConvFunction`` (one more halo exchange for dx, one all-reduce of dkernel).
     """
 
     def __init__(self, ell_cols, ell_vals, K, Fout=None, rank=0, world=1, device=None, precision="fp32",
-                 algo="auto", kernel=None, bias=None, act=_native.ACT_NONE, group=None, _compute=None, M=None):
+                 algo="auto", kernel=None, bias=None, act=_native.ACT_NONE, group=None, _compute=None, M=None,
+                 _compute_wgrad=None):
         import torch.distributed as dist
 
         gather = int(world) > 1 and dist.is_available() and dist.is_initialized()
@@ -232,8 +293,11 @@ class ShardedChebyshev:
         self.precision = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3}[precision]
         self.algo = {"auto": _native.ALGO_AUTO, "unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}[algo]
         self.act = act
-        self.kernel = None if kernel is None else torch.as_tensor(np.asarray(kernel), dtype=torch.float32).to(self.device)
-        self.bias = None if bias is None else torch.as_tensor(np.asarray(bias), dtype=torch.float32).reshape(-1).to(self.device)
+        # a torch tensor (e.g. a Parameter that requires grad) is kept as it is: calling the layer is then differentiable
+        self.kernel = (kernel if isinstance(kernel, torch.Tensor) else
+                       None if kernel is None else torch.as_tensor(np.asarray(kernel), dtype=torch.float32).to(self.device))
+        self.bias = (bias if isinstance(bias, torch.Tensor) else
+                     None if bias is None else torch.as_tensor(np.asarray(bias), dtype=torch.float32).reshape(-1).to(self.device))
         self.Fout = Fout if Fout is not None else (None if self.kernel is None else int(self.kernel.shape[1]))
         lay = self.layout
         self._send_idx = {p: torch.as_tensor(v.astype(np.int32)).to(self.device) for p, v in lay.send_local.items()}
@@ -246,7 +310,10 @@ class ShardedChebyshev:
             self.plan = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols,
                                               device=self.device.index, levels=lay.levels)
         self._x_ext = None
+        self._dy_ext = None
         self._workspace = None
+        self._workspace_w = None
+        self._compute_wgrad = _compute_wgrad
 
     def own_rows_view(self, N, F):
         """The (N, own, F) window of the extended input buffer that holds this rank's rows.  A producer that
@@ -257,13 +324,13 @@ class ShardedChebyshev:
             self._x_ext = torch.empty((N, lay.n_cols, F), dtype=torch.float32, device=self.device)
         return self._x_ext[:, : lay.n_own]
 
-    def exchange(self, x_local):
+    def exchange(self, x_local, buf="_x_ext"):
         """(N, own, F) -> (N, n_cols, F): own rows followed by the halo rows fetched from their owners."""
-        x_ext, finish = self.exchange_start(x_local)
+        x_ext, finish = self.exchange_start(x_local, buf)
         finish()
         return x_ext
 
-    def exchange_start(self, x_local):
+    def exchange_start(self, x_local, buf="_x_ext"):
         """Starts the halo exchange and returns ``(x_ext, finish)``: the transfers are in flight until ``finish()``
         (wait + unpack into the halo rows of ``x_ext``) -- work that touches no halo row can be issued in between."""
         import torch.distributed as dist
@@ -272,11 +339,13 @@ class ShardedChebyshev:
         N, own, F = x_local.shape
         if own != lay.n_own:
             raise ValueError(f"this rank owns {lay.n_own} rows, got {own}")
-        in_place = (self._x_ext is not None and tuple(self._x_ext.shape) == (N, lay.n_cols, F)
-                    and x_local.data_ptr() == self._x_ext.data_ptr() and x_local.stride() == self._x_ext.stride())
-        if self._x_ext is None or tuple(self._x_ext.shape) != (N, lay.n_cols, F):
-            self._x_ext = torch.empty((N, lay.n_cols, F), dtype=torch.float32, device=x_local.device)
-        x_ext = self._x_ext
+        cur = getattr(self, buf)  # "_x_ext" for the input, "_dy_ext" for the upstream gradient of the backward pass
+        in_place = (cur is not None and tuple(cur.shape) == (N, lay.n_cols, F)
+                    and x_local.data_ptr() == cur.data_ptr() and x_local.stride() == cur.stride())
+        if cur is None or tuple(cur.shape) != (N, lay.n_cols, F):
+            cur = torch.empty((N, lay.n_cols, F), dtype=torch.float32, device=x_local.device)
+            setattr(self, buf, cur)
+        x_ext = cur
         if not in_place:
             x_ext[:, :own].copy_(x_local)
         if self.world == 1 or not (self._send_idx or self._recv_idx):
@@ -314,22 +383,58 @@ class ShardedChebyshev:
         return p if self.group is None else dist.get_global_rank(self.group, p)
 
     def __call__(self, x_local):
+        train = torch.is_grad_enabled() and (x_local.requires_grad or (self.kernel is not None and self.kernel.requires_grad)
+                                             or (self.bias is not None and self.bias.requires_grad))
+        if not train:
+            return self._forward(x_local, self.kernel, self.bias, self.act)
+        # differentiable: the convolution through _ShardedConvFunction, bias and activation by the host framework
+        y = _ShardedConvFunction.apply(x_local, self.kernel, self)
+        if self.bias is not None:
+            y = y + _ReplicatedGrad.apply(self.bias, self).reshape(1, 1, -1)
+        if self.act != _native.ACT_NONE:
+            y = {_native.ACT_RELU: torch.relu, _native.ACT_ELU: torch.nn.functional.elu, _native.ACT_SIGMOID: torch.sigmoid,
+                 _native.ACT_TANH: torch.tanh}[self.act](y)
+        return y
+
+    def _forward(self, x_local, kernel, bias, act, buf="_x_ext"):
         if self._compute is not None:
-            return self._compute(self.layout, self.exchange(x_local), self.kernel)
+            return self._compute(self.layout, self.exchange(x_local, buf), kernel)
         Fin = x_local.shape[2]
-        self.fused = self.plan.fused_ok(Fin, int(self.kernel.shape[1]), self.K) and self.algo != _native.ALGO_UNFUSED
-        kw = dict(act=self.act, precision=self.precision, algo=self.algo)
+        self.fused = self.plan.fused_ok(Fin, int(kernel.shape[1]), self.K) and self.algo != _native.ALGO_UNFUSED
+        kw = dict(act=act, precision=self.precision, algo=self.algo)
         if not self.fused or self.world == 1:
-            x_ext = self.exchange(x_local)
-            y, self._workspace = _native.cheb_forward(self.plan, x_ext, self.kernel, self.bias, self.K,
+            x_ext = self.exchange(x_local, buf)
+            y, self._workspace = _native.cheb_forward(self.plan, x_ext, kernel, bias, self.K,
                                                       workspace=self._workspace, **kw)
             return y
         # the tiles that read no halo row run while the halo rows are on the wire (RCCL works on its own stream),
         # the boundary tiles after they have landed: the exchange hides behind the interior
-        x_ext, finish = self.exchange_start(x_local)
-        y, self._workspace = _native.cheb_forward(self.plan, x_ext, self.kernel, self.bias, self.K,
+        x_ext, finish = self.exchange_start(x_local, buf)
+        y, self._workspace = _native.cheb_forward(self.plan, x_ext, kernel, bias, self.K,
                                                   workspace=self._workspace, part=_native.PART_INTERIOR, **kw)
         finish()
-        y, self._workspace = _native.cheb_forward(self.plan, x_ext, self.kernel, self.bias, self.K,
+        y, self._workspace = _native.cheb_forward(self.plan, x_ext, kernel, bias, self.K,
                                                   workspace=self._workspace, part=_native.PART_BOUNDARY, out=y, **kw)
         return y
+
+    def _wgrad_local(self, x_ext, dy):
+        """This rank's partial weight gradient: sum over its own rows of (T_k x) dy^T."""
+        if self._compute_wgrad is not None:
+            return self._compute_wgrad(self.layout, x_ext, dy)
+        dk, self._workspace_w = _native.cheb_backward_weights(self.plan, x_ext, dy, self.K, algo=self.algo,
+                                                              workspace=self._workspace_w, precision=self.precision)
+        return dk
+
+    def _all_reduce(self, t):
+        """Sum over the ranks, in place (RCCL; host-staged under a gloo group like the halo exchange)."""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return t
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
+        return t

@@ -386,3 +386,47 @@ def test_table_tiles_cover_base_pixel_borders(nside):
     ys, _ = _native.cheb_forward(sp, xe, _dev(W), _dev(b), K, act=_native.ACT_RELU, algo=_native.ALGO_FUSED)
     a, e = lay.own
     assert rel_err(ys.cpu().numpy(), ref[:, a:e]) < TOL
+
+
+@pytest.mark.parametrize("world,K", [(4, 5), (2, 3)])
+def test_sharded_backward_pieces_on_one_gpu(world, K):
+    """What ShardedChebyshev's backward does per rank, with every rank's plan run on this GPU and the halo taken from the
+    global arrays by indexing: dx of a rank = the forward kernel on dy_ext with the re-indexed weights = the unsharded
+    dx rows; the ranks' partial dkernel sum to the unsharded dkernel (the all-reduce); both against the float64 oracle.
+    Then the real module at world 1 through autograd."""
+    from deepsphere import sharding
+
+    nside = 32
+    cols, vals = _grid_ell(nside)
+    M, Fin, Fout, N = cols.shape[0], 8, 12, 2
+    rng = np.random.default_rng(world + K)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    g = rng.standard_normal((N, M, Fout)).astype(np.float32)
+    dx_ref, dW_ref = orc.chebyshev_backward(_csr(cols, vals), x, W, K, g)
+    Wt = np.ascontiguousarray(W.reshape(Fin, K, Fout).transpose(2, 1, 0).reshape(Fout * K, Fin))
+    dW_sum = torch.zeros((Fin * K, Fout), device="cuda")
+    for r in range(world):
+        lay = sharding.ShardLayout(cols, vals, K, r, world)
+        plan = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols, device=0, levels=lay.levels)
+        a, b = lay.own
+        dx, _ = _native.cheb_forward(plan, _dev(g[:, lay.local_ids]), _dev(Wt), None, K)
+        assert np.abs(dx.cpu().numpy() - dx_ref[:, a:b]).max() < 2e-5 * np.abs(dx_ref).max()
+        dk, _ = _native.cheb_backward_weights(plan, _dev(x[:, lay.local_ids]), _dev(g[:, a:b]), K)
+        dW_sum += dk
+    assert np.abs(dW_sum.cpu().numpy() - dW_ref).max() < 2e-5 * np.abs(dW_ref).max()
+    # the module itself (world 1: no process group needed), differentiable call
+    with torch.enable_grad():
+        kernel = torch.nn.Parameter(_dev(W))
+        bias = torch.nn.Parameter(torch.zeros(Fout, device="cuda"))
+        sh = sharding.ShardedChebyshev(cols, vals, K, rank=0, world=1, device="cuda:0", kernel=kernel, bias=bias,
+                                       act=_native.ACT_RELU)
+        xl = _dev(x).requires_grad_(True)
+        y = sh(xl)
+        (y * _dev(g)).sum().backward()
+    pre = orc.chebyshev_forward(_csr(cols, vals), x, W, K)
+    gm = g * (pre > 0)
+    dx1, dW1 = orc.chebyshev_backward(_csr(cols, vals), x, W, K, gm)
+    assert np.abs(xl.grad.cpu().numpy() - dx1).max() < 2e-5 * np.abs(dx1).max()
+    assert np.abs(kernel.grad.cpu().numpy() - dW1).max() < 2e-5 * np.abs(dW1).max()
+    assert np.abs(bias.grad.cpu().numpy() - gm.sum((0, 1))).max() < 2e-5 * np.abs(gm.sum((0, 1))).max()

@@ -168,3 +168,79 @@ def test_layout_from_row_producer_and_gathered_requests(world, K):
             assert np.array_equal(own[r].recv_local[p], ref[r].recv_local[p])
     with pytest.raises(ValueError, match="does not own"):
         own[0].set_peer_requests({1: np.array([M - 1])})
+
+
+def _planes_local(layout, x_ext):
+    """T_k x on the shard's extended graph (float64), (K, N, n_cols, F): exact on the rank's own rows."""
+    n = layout.n_cols
+    rows = np.repeat(np.arange(layout.n_rows), layout.local_cols.shape[1])
+    A = sparse.csr_matrix((layout.local_vals.reshape(-1).astype(np.float64), (rows, layout.local_cols.reshape(-1))),
+                          shape=(n, n))
+    return orc.chebyshev_planes(A, x_ext.numpy().astype(np.float64), layout.K)
+
+
+def _oracle_compute_f32(layout, x_ext, kernel):
+    return _oracle_compute(layout, x_ext, kernel).float()
+
+
+def _oracle_wgrad(layout, x_ext, dy):
+    planes = _planes_local(layout, x_ext)[:, :, : layout.n_own]
+    dW = np.einsum("knmf,nmo->fko", planes, dy.numpy().astype(np.float64))
+    return torch.from_numpy(dW.reshape(-1, dy.shape[2])).float()
+
+
+def _train_worker(rank, world, port, K, out):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Lt, cols, vals = _prepared_ell(8, "knn")
+        M = cols.shape[0]
+        rng = np.random.default_rng(3)
+        Fin, Fout, N = 3, 4, 2
+        x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+        W = rng.standard_normal((Fin * K, Fout)).astype(np.float32)
+        b = rng.standard_normal(Fout).astype(np.float32)
+        g = rng.standard_normal((N, M, Fout)).astype(np.float32)
+        kernel = torch.nn.Parameter(torch.from_numpy(W.copy()))
+        bias = torch.nn.Parameter(torch.from_numpy(b.copy()))
+        sh = sharding.ShardedChebyshev(cols, vals, K, rank=rank, world=world, kernel=kernel, bias=bias,
+                                       _compute=_oracle_compute_f32, _compute_wgrad=_oracle_wgrad)
+        a, e = sh.layout.own
+        xl = torch.from_numpy(x[:, a:e].copy()).requires_grad_(True)
+        y = sh(xl)
+        (y * torch.from_numpy(g[:, a:e].copy())).sum().backward()
+        dx_ref, dW_ref = orc.chebyshev_backward(Lt, x, W, K, g)
+        errs = [float(np.abs(xl.grad.numpy() - dx_ref[:, a:e]).max() / np.abs(dx_ref).max()),
+                float(np.abs(kernel.grad.numpy() - dW_ref).max() / np.abs(dW_ref).max()),
+                float(np.abs(bias.grad.numpy() - g.sum((0, 1))).max() / np.abs(g.sum((0, 1))).max()),
+                float(np.abs(y.detach().numpy() - (orc.chebyshev_forward(Lt, x, W, K) + b)[:, a:e]).max())]
+        res = torch.tensor(errs, dtype=torch.float64)
+        gathered = [torch.zeros(4, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, res)
+        if rank == 0:
+            out.put([t.tolist() for t in gathered])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K", [(2, 5), (4, 3)])
+def test_sharded_training_gloo(world, K):
+    """Autograd through the sharded layer: dx from one more halo exchange (of dy), dkernel from the ranks' partial sums
+    and ONE all-reduce; both against the unsharded float64 oracle gradients."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, K, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for e_dx, e_dw, e_db, e_y in res:
+        assert e_dx < 1e-5 and e_dw < 1e-5 and e_db < 1e-5 and e_y < 1e-4
