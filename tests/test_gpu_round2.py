@@ -430,3 +430,46 @@ def test_sharded_backward_pieces_on_one_gpu(world, K):
     assert np.abs(xl.grad.cpu().numpy() - dx1).max() < 2e-5 * np.abs(dx1).max()
     assert np.abs(kernel.grad.cpu().numpy() - dW1).max() < 2e-5 * np.abs(dW1).max()
     assert np.abs(bias.grad.cpu().numpy() - gm.sum((0, 1))).max() < 2e-5 * np.abs(gm.sum((0, 1))).max()
+
+
+def test_healpy_gcnn_values_against_the_oracle_composition():
+    """a HealpyGCNN (Chebyshev -> average pool -> Chebyshev -> max pool -> Monomial, partial sky, the
+    reference's 8-nearest-neighbour graphs) evaluated on the GPU equals the same network assembled from the float64
+    oracle layers and NEST child pooling, layer by layer -- values, not only shapes."""
+    from deepsphere import healpy_layers, healpy_networks
+
+    nside = 16
+    indices = healpix.extend_indices(healpix.cap_indices(nside, fraction=0.3), nside, 4)
+    layers = [healpy_layers.HealpyChebyshev(K=5, Fout=8, activation="relu", use_bias=True),
+              healpy_layers.HealpyPool(p=1, pool_type="AVG"),
+              healpy_layers.HealpyChebyshev(K=3, Fout=6, activation="elu"),
+              healpy_layers.HealpyPool(p=1, pool_type="MAX"),
+              healpy_layers.HealpyMonomial(K=3, Fout=4, use_bias=True)]
+    torch.manual_seed(5)
+    model = healpy_networks.HealpyGCNN(nside=nside, indices=indices, layers=layers).cuda()
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2, len(indices), 3)).astype(np.float32)
+    with torch.no_grad():
+        y = model(_dev(x)).cpu().numpy()
+    # the same walk with the oracle
+    cur, cur_nside, cur_idx = x.astype(np.float64), nside, np.asarray(indices)
+    for spec, mod in zip(layers, model):
+        if isinstance(spec, healpy_layers.HealpyPool):
+            g = cur.reshape(cur.shape[0], -1, 4 ** spec.p, cur.shape[2])
+            cur = g.mean(2) if spec.pool_type == "AVG" else g.max(2)
+            cur_idx = np.unique(cur_idx // 4 ** spec.p)
+            cur_nside //= 2 ** spec.p
+            continue
+        L = healpix.healpix_laplacian(cur_nside, indices=cur_idx, n_neighbors=8, mode="knn")
+        Wk = mod.kernel.detach().cpu().numpy().astype(np.float64)
+        b = mod.bias.detach().cpu().numpy().reshape(-1).astype(np.float64) if mod.use_bias else None
+        if isinstance(spec, healpy_layers.HealpyMonomial):
+            Lt, _ = orc.prepare_L(L, scale=1.0)
+            cur = orc.monomial_forward(Lt, cur, Wk, spec.K, bias=b, activation=spec.activation)
+        else:
+            Lt, _ = orc.prepare_L(L)
+            cur = orc.chebyshev_forward(Lt, cur, Wk, spec.K, bias=b, activation=spec.activation)
+    assert y.shape == cur.shape == (2, len(indices) // 16, 4)
+    err = rel_err(y, cur)
+    print(f"HealpyGCNN vs oracle composition: rel err {err:.2e}")
+    assert err < 1e-5
