@@ -253,20 +253,32 @@ def main():
     # must not lose the measurement: fall back to independent replicas of the whole map and say so in the line.
     replicas_note = None
     if world > 1:
+        def agree(err):
+            flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float32, device=device if args.backend == "nccl" else "cpu")
+            try:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                return flag.item() > 0, err
+            except Exception as exc:  # noqa: BLE001
+                return True, err or repr(exc)
+
+        # 1. everything local first (no point-to-point operation yet): a rank that cannot run its own plan says so
+        #    before its peers post receives they would wait on forever
         err = None
         try:
             if os.environ.get("DSPH_BENCH_FAIL_SHARD"):  # exercises the fallback below
                 raise RuntimeError("forced by DSPH_BENCH_FAIL_SHARD")
-            run()
-            torch.cuda.synchronize()
+            shard.dry_run(N, Fin)
         except Exception as exc:  # noqa: BLE001
             err = repr(exc)
-        flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float32, device=device if args.backend == "nccl" else "cpu")
-        try:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            failed = flag.item() > 0
-        except Exception as exc:  # noqa: BLE001
-            failed, err = True, err or repr(exc)
+        failed, err = agree(err)
+        # 2. the first real step, with the exchange
+        if not failed:
+            try:
+                run()
+                torch.cuda.synchronize()
+            except Exception as exc:  # noqa: BLE001
+                err = repr(exc)
+            failed, err = agree(err)
         if failed and not args.allow_replicas:
             if rank == 0:
                 print(f"bench.py: the sharded forward failed ({err or 'on another rank'}); pass --allow-replicas to time "

@@ -324,6 +324,20 @@ class ShardedChebyshev:
             self._x_ext = torch.empty((N, lay.n_cols, F), dtype=torch.float32, device=self.device)
         return self._x_ext[:, : lay.n_own]
 
+    def dry_run(self, N, Fin):
+        """One forward of the local plan on the extended buffer as it is, WITHOUT the exchange: whatever fails locally
+        (allocation, unsupported shape, kernel launch) fails here, before this rank posts or skips a point-to-point
+        operation that its peers would wait on forever.  Callers agree on the outcome (an all-reduce of a flag) and
+        only then run the first real step; ``bench.py`` does."""
+        if self._compute is not None:
+            return
+        self.own_rows_view(N, Fin)  # creates the extended buffer if it does not exist yet
+        y, self._workspace = _native.cheb_forward(self.plan, self._x_ext, self.kernel.detach(), None, self.K,
+                                                  act=_native.ACT_NONE, precision=self.precision, algo=self.algo,
+                                                  workspace=self._workspace)
+        torch.cuda.synchronize(self.device)
+        return tuple(y.shape)
+
     def exchange(self, x_local, buf="_x_ext"):
         """(N, own, F) -> (N, n_cols, F): own rows followed by the halo rows fetched from their owners."""
         x_ext, finish = self.exchange_start(x_local, buf)
