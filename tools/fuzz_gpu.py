@@ -39,7 +39,7 @@ for it in range(cases):
     Lt, plan = plans[key]
     M = Lt.shape[0]
     K = int(rng.integers(2, 10))
-    Fin = 4 * int(rng.integers(1, 19))
+    Fin = 4 * int(rng.integers(1, 19)) if rng.random() < 0.6 else int(rng.integers(1, 40))  # also channel counts that get padded
     Fout = int(rng.integers(1, 141))
     N = int(rng.integers(1, 4))
     if not plan.fused_ok(Fin, Fout, K):
@@ -54,19 +54,25 @@ for it in range(cases):
     yf, _ = _native.cheb_forward(plan, xd, Wd, bd, K, act=act, algo=_native.ALGO_FUSED, basis=basis, precision=_native.PREC_FP32)
     yb, _ = _native.cheb_forward(plan, xd, Wd, bd, K, act=act, algo=_native.ALGO_FUSED, basis=basis, precision=_native.PREC_BF16X3)
     e1, e2 = rel(yf.cpu().numpy(), yu.cpu().numpy()), rel(yb.cpu().numpy(), yu.cpu().numpy())
-    pf = _native.cheb_planes(plan, xd, K, basis=basis, algo=_native.ALGO_FUSED)
-    pu = _native.cheb_planes(plan, xd, K, basis=basis, algo=_native.ALGO_UNFUSED)
-    same = all(torch.equal(a, b2) for a, b2 in zip(pf, pu))
+    same = True
+    if Fin % 4 == 0:  # (the planes / weight-gradient modes of the BFS kernel take whole 16-byte pieces only)
+        pf = _native.cheb_planes(plan, xd, K, basis=basis, algo=_native.ALGO_FUSED)
+        pu = _native.cheb_planes(plan, xd, K, basis=basis, algo=_native.ALGO_UNFUSED)
+        same = all(torch.equal(a, b2) for a, b2 in zip(pf, pu))
     du, _ = _native.cheb_backward_weights(plan, xd, dyd, K, basis=basis, algo=_native.ALGO_UNFUSED)
     e3 = e4 = -1.0
     try:
+        if Fin % 4 != 0:
+            raise RuntimeError("fused weight gradient cannot run: Fin % 4")
         df, _ = _native.cheb_backward_weights(plan, xd, dyd, K, basis=basis, algo=_native.ALGO_FUSED)
         dbf, _ = _native.cheb_backward_weights(plan, xd, dyd, K, basis=basis, algo=_native.ALGO_FUSED, precision=_native.PREC_BF16X3)
         e3, e4 = rel(df.cpu().numpy(), du.cpu().numpy()), rel(dbf.cpu().numpy(), du.cpu().numpy())
     except RuntimeError as exc:  # accumulators do not fit beside the planes: refused loudly, fine
         if "cannot run" not in str(exc):
             raise
-    ok = e1 < 2e-5 and e2 < 1e-4 and same and e3 < 2e-5 and e4 < 1e-4
+    # the split-bf16 contraction is held to 2e-5 of max|y|; behind tanh the reference scale shrinks to <= 1 while the error
+    # of the pre-activation (a few 1e-6 of ITS maximum) passes through with slope <= 1, so the ratio is looser there
+    ok = e1 < 2e-5 and e2 < (1e-4 if act == _native.ACT_TANH else 2e-5) and same and e3 < 2e-5 and e4 < 1e-4
     bad += not ok
     print(f"{'ok ' if ok else 'BAD'} nside={nside} {mode} M={M} K={K} {Fin}->{Fout} N={N} act={act} basis={basis}: fwd {e1:.1e} {e2:.1e} planes {same} dW {e3:.1e} {e4:.1e}",
           flush=True)
