@@ -58,6 +58,13 @@ def _resolve_activation(activation):
     raise ValueError(f"Could not find activation <{activation}> in tf.keras.activations...")
 
 
+# The contraction arithmetic a layer uses when the caller does not say: exact fp32.  The 3-term split-bf16 form ("bf16x3") is
+# 1.55 x faster at the headline shape and measures 2-6e-6 of max|y| wherever the inner dimension K*Fin is large, but it has
+# no worst-case guarantee at the 1e-5 of SURVEY 8c: a product can be off by 3 * 2^-18 = 1.1e-5, and with five terms per
+# output (Fin = 1, K = 5: BASELINE configs[0] on the whole map) 1.02e-5 was measured -- so it stays opt-in.
+DEFAULT_PRECISION = "fp32"
+
+
 class _ChebConvFunction(torch.autograd.Function):
     """y = sum_k T_k(L~) x W_k as a differentiable op (no bias, no activation).
 
@@ -149,8 +156,9 @@ class Chebyshev(torch.nn.Module):
             TensorFlow-GPU's sparse-matmul size limit, the HIP kernel has none
         :param kwargs: the reference forwards these to ``add_weight`` (regularizer, ...); stored in
             ``self.kwargs``.  Three keys are consumed here: ``device`` (torch device of the layer,
-            default: current CUDA device), ``precision`` ("fp32" exact | "bf16x3" split-bf16 MFMA
-            contraction) and ``algo`` ("auto" | "unfused" | "fused").
+            default: current CUDA device), ``precision`` ("fp32", the default: exact-fp32 MFMA contraction, 3-7e-7 of max|y| from the
+            float64 oracle | "bf16x3": three bf16 MFMAs per product with fp32 accumulation, 2-6e-6 at the BASELINE shapes
+            with 16 or more input channels, 1.55 x faster at the headline shape; the recurrence is fp32 either way) and ``algo`` ("auto" | "unfused" | "fused").
         """
         super().__init__()
         self.L = L
@@ -165,7 +173,7 @@ class Chebyshev(torch.nn.Module):
         self.activation, self._act_code = _resolve_activation(activation)
         self.n_matmul_splits = n_matmul_splits
         device = kwargs.pop("device", None)
-        precision = kwargs.pop("precision", "fp32")
+        precision = kwargs.pop("precision", DEFAULT_PRECISION)
         algo = kwargs.pop("algo", "auto")
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
@@ -341,7 +349,7 @@ class Chebyshev(torch.nn.Module):
         self.activation, self._act_code = _resolve_activation(kwargs.pop("activation", None))
         self.n_matmul_splits = kwargs.pop("n_matmul_splits", 1)
         device = kwargs.pop("device", None)
-        self.precision = kwargs.pop("precision", "fp32")
+        self.precision = kwargs.pop("precision", DEFAULT_PRECISION)
         self.algo = kwargs.pop("algo", "auto")
         if self.precision not in _PRECISIONS or self.algo not in _ALGOS:
             raise ValueError("unknown precision or algo")
