@@ -336,6 +336,14 @@ def main():
                 err_note = f"measured max err {e_rel:.2e} of max|y| on {n_pts} (map, row) outputs of the timed run vs the float64 oracle"
             except Exception as exc:  # noqa: BLE001
                 err_note = f"error measurement failed: {exc!r}"
+        def measured_error_of(yq):
+            if os.environ.get("DSPH_BENCH_NO_CHECK"):
+                return None
+            try:
+                return float("%.3g" % measured_error(cols, vals, x, yq, w_np, K, nside)[0])
+            except Exception as exc:  # noqa: BLE001
+                return repr(exc)
+
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -383,24 +391,33 @@ def main():
                 "min_max_forward_ms_hip_events": [round(float(np.min(per_fwd_ms)), 4), round(float(np.max(per_fwd_ms)), 4)],
             },
         }
-        if world == 1 and args.precision != "fp32":
-            # the same forward with the exact-fp32 MFMA contraction, for the record
-            layer.precision = "fp32"
-            for _ in range(2):
-                run()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                run()
-            torch.cuda.synchronize()
-            ms32 = (time.perf_counter() - t1) / 5 * 1e3
+        if world == 1:
+            # the same forward with the two fp32-accurate contractions, for the record: exact-fp32 MFMA (bitwise an fp32 fma
+            # chain) and the six-term bf16 split (fp32-equivalent, the layer's default); both against the fp32-MFMA roofline
             f_d = 2.0 * N * M * K * Fin * Fout  # flops of the dense contraction
-            tf32 = f_d / (ms32 * 1e-3) / 1e12
-            out["fp32_exact"] = {"ms_per_step": round(ms32, 4), "value": round(N * M * Fout / ms32 / 1e3, 2),
-                                 "note": "the layer's default precision: contraction on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain)",
-                                 "roofline": {"bound": "mfma_f32", "achieved": round(tf32, 2), "peak": 157.3, "unit": "TFLOP/s",
-                                              "frac": round(tf32 / 157.3, 4), "flops": f_d,
-                                              "hbm_frac": round(b_alg / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+            for key, prec_name, note in (
+                    ("fp32_exact", "fp32", "contraction on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain)"),
+                    ("fp32_split", "bf16x6", "the layer's default precision: fp32-equivalent six-term split on v_mfma_f32_32x32x16_bf16 "
+                                             "(operands split exactly into 8 + 8 + 8 mantissa bits, products down to 2^-16 kept)")):
+                if args.precision == prec_name:
+                    continue
+                layer.precision = prec_name
+                for _ in range(2):
+                    run()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    yq = run()
+                torch.cuda.synchronize()
+                msq = (time.perf_counter() - t1) / 5 * 1e3
+                tfq = f_d / (msq * 1e-3) / 1e12
+                out[key] = {"ms_per_step": round(msq, 4), "value": round(N * M * Fout / msq / 1e3, 2), "note": note,
+                            "measured_error": measured_error_of(yq),
+                            "roofline": {"bound": "mfma_f32", "achieved": round(tfq, 2), "peak": 157.3, "unit": "TFLOP/s",
+                                         "frac": round(tfq / 157.3, 4), "flops": f_d,
+                                         "hbm_frac": round(b_alg / (msq * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+                del yq
+            layer.precision = args.precision
         if world == 1:
             # one run with bias + ReLU fused into the kernel epilogue
             layer.precision = args.precision

@@ -789,6 +789,8 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     const int ng = part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior);
     if (ng == 0 || dbg_only('s')) return DSPH_OK;
   }
+  // the BFS-tile kernel has two contraction arithmetics; the six-term split of the structured kernel is fp32-equivalent
+  if (precision == DSPH_PREC_BF16X6) precision = DSPH_PREC_FP32;
   if (!planes_mode) {
     hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,
                        static_cast<unsigned char*>(workspace), (int)Fin_w, (int)Fout, (int)K, C, NB,

@@ -87,12 +87,20 @@ __global__ __launch_bounds__(256) void struct_wprep_kernel(const float* __restri
                                                            int Fin, int Fout, int K, int C, int NB, int prec, int ld) {
   const int blk = blockIdx.x;  // (c*K + k)*NB + nb
   const int nb = blk % NB, k = (blk / NB) % K, c = blk / (NB * K);
-  unsigned char* base = out + (size_t)blk * 2048;
+  unsigned char* base = out + (size_t)blk * (prec == DSPH_PREC_BF16X6 ? ST_WBLK3 : 2048);
   for (int e = threadIdx.x; e < 512; e += 256) {
     const int l = e >> 3, j = e & 7;
     const int ch = c * 16 + 8 * (l >> 5) + j, col = 32 * nb + (l & 31);
     const float v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
-    if (prec == DSPH_PREC_BF16X3) {
+    if (prec == DSPH_PREC_BF16X6) {  // exact three-way split by truncation (st_contract): hi | mid | lo, 1 KiB each
+      const unsigned u = __float_as_uint(v);
+      const float r = v - __uint_as_float(u & 0xffff0000u);
+      const unsigned s = __float_as_uint(r);
+      const float q = r - __uint_as_float(s & 0xffff0000u);
+      reinterpret_cast<unsigned short*>(base)[l * 8 + j] = (unsigned short)(u >> 16);
+      reinterpret_cast<unsigned short*>(base + 1024)[l * 8 + j] = (unsigned short)(s >> 16);
+      reinterpret_cast<unsigned short*>(base + 2048)[l * 8 + j] = (unsigned short)(__float_as_uint(q) >> 16);
+    } else if (prec == DSPH_PREC_BF16X3) {
       const __bf16 hi = (__bf16)v;
       const __bf16 lo = (__bf16)(v - (float)hi);
       reinterpret_cast<__bf16*>(base)[l * 8 + j] = hi;
@@ -154,16 +162,20 @@ bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K) {
          K * NB * 2048 <= ST_WSLICE_BYTES;
 }
 
-size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
+size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {  // (sized for the largest block form, DSPH_PREC_BF16X6)
   const int C = (Fin + 15) / 16, NB = (Fout + 31) / 32;
-  return (size_t)C * K * NB * 2048;
+  return (size_t)C * K * NB * ST_WBLK3;
 }
 
 int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   const int C = (s.Fin + 15) / 16, NB = (s.Fout + 31) / 32;
+  // the six-term split needs 3 KiB weight blocks: double-buffered while a slice has at most six of them, replaced in place
+  // for K = 5 with 64 columns (cheb_struct_kernel.h); the one shape in between (K = 4, 64 columns) runs exact fp32
+  int prec = s.precision;
+  if (prec == DSPH_PREC_BF16X6 && !(s.K * NB <= 6 || (s.K == 5 && NB == 2))) prec = DSPH_PREC_FP32;
   if (s.prep_weights) {
     hipLaunchKernelGGL(struct_wprep_kernel, dim3(C * s.K * NB), dim3(256), 0, stream, s.w, s.wfrag, (int)s.Fin_w, (int)s.Fout,
-                       (int)s.K, C, NB, (int)s.precision, (int)s.ld);
+                       (int)s.K, C, NB, prec, (int)s.ld);
     DSPH_HIP(hipGetLastError());
   }
   StructArgs a;
@@ -198,7 +210,8 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   const bool tab = s.tabrow != nullptr;
 #define DSPH_ST_PICK2(P, CH, TB) (NB == 1 ? cheb_struct_kernel<1, P, CH, TB> : cheb_struct_kernel<2, P, CH, TB>)
 #define DSPH_ST_PICK(P, CH) (tab ? DSPH_ST_PICK2(P, CH, true) : DSPH_ST_PICK2(P, CH, false))
-  if (s.precision == DSPH_PREC_BF16X3) kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_BF16X3, true) : DSPH_ST_PICK(DSPH_PREC_BF16X3, false);
+  if (prec == DSPH_PREC_BF16X3) kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_BF16X3, true) : DSPH_ST_PICK(DSPH_PREC_BF16X3, false);
+  else if (prec == DSPH_PREC_BF16X6) kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_BF16X6, true) : DSPH_ST_PICK(DSPH_PREC_BF16X6, false);
   else kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_FP32, true) : DSPH_ST_PICK(DSPH_PREC_FP32, false);
 #undef DSPH_ST_PICK
 #undef DSPH_ST_PICK2

@@ -75,6 +75,7 @@ constexpr int ST_LDS_BIAS = ST_LDS_W + 2 * ST_WSLICE_BYTES;  // 160,768
 constexpr int ST_LDS_ROWS = ST_LDS_BIAS + 256;               // byte offset, inside a map, of the x row of every plane cell
 constexpr int ST_LDS_TOTAL = ST_LDS_ROWS + ST_CELLS * 4;     // 163,520 of 163,840
 constexpr int ST_DMA_PIECES = ST_CELLS / 16;    // 39 wave-instructions of 1 KiB fill a plane
+constexpr int ST_WBLK3 = 3072;                  // DSPH_PREC_BF16X6: a weight block is 3 KiB (hi | mid | lo)
 constexpr int ST_TABV = 12;                     // floats per cell of a class-T tile's value table (9 used: 3 x 16 B)
 
 typedef float st_f32x16 __attribute__((ext_vector_type(16)));
@@ -254,6 +255,48 @@ template <int NB, int PREC>
 __device__ __forceinline__ void st_contract(const unsigned char* __restrict__ smem, unsigned plane, unsigned wblk,
                                             const unsigned (&mb)[2], int lane, st_f32x16 (&acc)[2][NB]) {
   if (ST_ABL_SKIP & 2) return;
+  if (PREC == DSPH_PREC_BF16X6) {
+    // fp32-equivalent on the bf16 pipe: v = h + m + l with 8 + 8 + 8 mantissa bits, six products (hh, hm, mh, mm, hl, lh).
+    // The weights arrive pre-split (struct_wprep_kernel: 3 KiB per block, hi | mid | lo; `wblk`: the order's first block,
+    // the second one 3 KiB behind it).  The plane fragment is split here, exactly, by TRUNCATION: h = the top 16 bits of v
+    // (a bf16), r = v - h exactly, m = the top 16 bits of r, l = r - m, which has at most 8 significant bits left:
+    // v = h + m + l with no rounding anywhere.
+    typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const float4 a0 = *reinterpret_cast<const float4*>(smem + plane + mb[pb]);
+      const float4 a1 = *reinterpret_cast<const float4*>(smem + plane + (mb[pb] ^ 16u));
+      const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      st_u32x4 hp, mp, lp;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned u0 = __float_as_uint(v[2 * j]), u1 = __float_as_uint(v[2 * j + 1]);
+        const float r0 = v[2 * j] - __uint_as_float(u0 & 0xffff0000u), r1 = v[2 * j + 1] - __uint_as_float(u1 & 0xffff0000u);
+        const unsigned s0 = __float_as_uint(r0), s1 = __float_as_uint(r1);
+        const float q0 = r0 - __uint_as_float(s0 & 0xffff0000u), q1 = r1 - __uint_as_float(s1 & 0xffff0000u);
+        hp[j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // {hi16(u1), hi16(u0)}
+        mp[j] = __builtin_amdgcn_perm(s1, s0, 0x07060302u);
+        lp[j] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+      }
+      const st_bf16x8 th = __builtin_bit_cast(st_bf16x8, hp), tm = __builtin_bit_cast(st_bf16x8, mp),
+                      tl = __builtin_bit_cast(st_bf16x8, lp);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const unsigned char* __restrict__ wq = smem + wblk + b * ST_WBLK3 + lane * 16;
+        const st_bf16x8 wh = *reinterpret_cast<const st_bf16x8*>(wq);
+        const st_bf16x8 wm = *reinterpret_cast<const st_bf16x8*>(wq + 1024);
+        const st_bf16x8 wl = *reinterpret_cast<const st_bf16x8*>(wq + 2048);
+        // small terms first
+        acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, th, acc[pb][b], 0, 0, 0);
+        acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, tl, acc[pb][b], 0, 0, 0);
+        acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, tm, acc[pb][b], 0, 0, 0);
+        acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, th, acc[pb][b], 0, 0, 0);
+        acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, tm, acc[pb][b], 0, 0, 0);
+        acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, th, acc[pb][b], 0, 0, 0);
+      }
+    }
+    return;
+  }
   float4 a[2][2];
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb) {
@@ -435,7 +478,26 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
       const int piece = wave + 8 * s;
       ginfo |= (piece < GX ? st_piece_info(piece, lane, D) : 0u) << (3 * s);
     }
-    const int wsliceG = a.K * NB * 2048;
+    const int wblkG = PREC == DSPH_PREC_BF16X6 ? ST_WBLK3 : 2048;
+    const int wsliceG = a.K * NB * wblkG;
+    // DSPH_PREC_BF16X6 with 10 blocks of 3 KiB per slice (K = 5, 64 columns): two buffers do not fit the 40 KiB weight
+    // area, so the orders are replaced IN PLACE as soon as they have been contracted -- order k of an item in that item's
+    // interval k + 1, the last one in the next item's interval 1 -- and only order 3, whose slot frees last, has a second
+    // slot (items alternate).  Slot of (order k, block b) of the workgroup's item number `it`: 2k + b, or 10 + b for
+    // order 3 of an odd item.  What goes out when (all of it in flight before the barrier that ends the item):
+    //   interval 2: order 4 of THIS item (its slot held the previous item's last order until interval 1), order 0 of the next
+    //   interval 3: orders 1 and 3 of the next item          interval 4 (at its start): order 2 of the next item
+    // Smaller slices (K * NB <= 6) are double-buffered like the other precisions.
+    const bool stag = PREC == DSPH_PREC_BF16X6 && a.K * NB > 6;  // (the host admits only K = 5, NB = 2 here)
+    int itG = 0;  // this workgroup's item counter
+    auto worder = [&](int k, int it_t, int c_t, int rot) __attribute__((always_inline)) {
+      const unsigned slot0 = (k == 3 && (it_t & 1)) ? 10u : (unsigned)(2 * k);
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+        if (((p + rot) & 7) == wave)
+          st_glds16_off(a.wfrag + ((size_t)(c_t * a.K + k) * 2) * ST_WBLK3 + 1024 * p, (unsigned)lane * 16u,
+                        __builtin_amdgcn_readfirstlane((unsigned)ST_LDS_W + slot0 * ST_WBLK3 + 1024u * (unsigned)p));
+    };
     const unsigned* const sRowG = reinterpret_cast<const unsigned*>(smem + ST_LDS_ROWS);
     const bool raggedG = (a.Fin & 15) != 0;
     auto gdma = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
@@ -451,7 +513,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     };
     auto gdma_w = [&](int u, int c, unsigned wdst) __attribute__((always_inline)) {
       const int j = wave + 8 * u;
-      if (j < GW && j < wsliceG / 1024)
+      if (!stag && j < GW && j < wsliceG / 1024)
         st_glds16_off(a.wfrag + (size_t)c * wsliceG + 1024 * j, (unsigned)lane * 16u,
                       __builtin_amdgcn_readfirstlane(wdst + 1024u * (unsigned)j));
     };
@@ -483,6 +545,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     gdma_group(0, 0, 0, px, wbG);
     gdma_group(1, 0, 0, px, wbG);
     gdma_group(2, 0, 0, px, wbG);
+    if (stag) { worder(0, 0, 0, 0); worder(1, 0, 0, 6); worder(2, 0, 0, 4); worder(3, 0, 0, 2); }
     if (early) {  // the first item's slice: the only one waited for outside the item loop
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -535,6 +598,10 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
         if (a.K > 2) {
           if (wact & 4u) st_gather<false, CHEB>(smem, py, px, gb, v, tb, ta, (lact & 4u) != 0, dummy);  // ta <- T_2
           if (more) gdma_group(0, nn, cn, pxn, wbnG);
+          if (stag) {
+            worder(4, itG, c, 0);
+            if (more) worder(0, itG + 1, cn, 6);
+          }
           ST_STAMP(4);
           __syncthreads();
           ST_STAMP(5);
@@ -544,11 +611,13 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
           if (wact & 8u) st_gather<false, CHEB>(smem, px, py, gb, v, ta, tb, (lact & 8u) != 0, dummy);  // tb <- T_3
           if (more) gdma_group(1, nn, cn, pxn, wbnG);
           if (more && early) gdma_group(2, nn, cn, pxn, wbnG);
+          if (stag && more) { worder(1, itG + 1, cn, 4); worder(3, itG + 1, cn, 2); }
           ST_STAMP(6);
           __syncthreads();
           ST_STAMP(7);
         }
         if (a.K > 4) {
+          if (stag && more) worder(2, itG + 1, cn, 0);  // (first: the blocks need the interval to land)
           if (wact & 16u) st_gather<false, CHEB>(smem, py, px, gb, v, tb, ta, (lact & 16u) != 0, dummy);  // ta <- T_4
           if (more && !early) gdma_group(2, nn, cn, pxn, wbnG);
           ST_STAMP(8);
@@ -561,6 +630,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
           if (a.K <= 3) gdma_group(1, nn, cn, pxn, wbnG);
           if (a.K <= 4) gdma_group(2, nn, cn, pxn, wbnG);
         }
+        ++itG;
         px = pxn;
         wbG = wbnG;
         n = nn;
@@ -591,7 +661,10 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   unsigned dinfo = 0;  // per piece s: bits 3s..3s+1 logical slot, bit 3s+2 valid
 #pragma unroll
   for (int s = 0; s < (NPX > 0 ? NPX : 1) && s < NPX; ++s) dinfo |= st_piece_info(GX + cw + ST_CONTRACT_WAVES * s, lane, D) << (3 * s);
-  const int wslice = a.K * NB * 2048;  // bytes of one slice's fragments
+  const int wblkB = PREC == DSPH_PREC_BF16X6 ? ST_WBLK3 : 2048;
+  const int wslice = a.K * NB * wblkB;  // bytes of one slice's fragments
+  const bool stag = PREC == DSPH_PREC_BF16X6 && a.K * NB > 6;  // in-place replacement of the weight orders (recurrence waves)
+  unsigned itC = 0;  // this workgroup's item counter
   const int wpieces = wslice / 1024;
   const bool vec_ok = (a.Fout % 4 == 0) && (a.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
   const bool ragged = (a.Fin & 15) != 0;  // the last slice has channels past Fin: they are read from valid channels
@@ -629,7 +702,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   // piece u of this wave's share of the weight fragments of slice c -> buffer at wdst
   auto dma_w = [&](int u, int c, unsigned wdst) __attribute__((always_inline)) {
     const int j = GW + cw + ST_CONTRACT_WAVES * u;
-    if (j < wpieces)
+    if (!stag && j < wpieces)
       st_glds16_off(a.wfrag + (size_t)c * wslice + 1024 * j, (unsigned)lane * 16u,
                     __builtin_amdgcn_readfirstlane(wdst + 1024u * (unsigned)j));
   };
@@ -682,6 +755,11 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   // the last plane of the previous item, still to be contracted (under the first step of the current one)
   bool pend = false, pend_store = false;
   unsigned pend_plane = 0, pend_w = 0, pend_row0 = 0;
+  // byte offset of the fragments of order k of the current item
+  auto wof = [&](int k) __attribute__((always_inline)) -> unsigned {
+    if (stag) return (unsigned)ST_LDS_W + ((k == 3 && (itC & 1u)) ? 10u : (unsigned)(2 * k)) * ST_WBLK3;
+    return wb + (unsigned)(k * NB * wblkB);
+  };
   int pend_n = 0;
   auto flush_pending = [&]() __attribute__((always_inline)) {
     if (!pend) return;
@@ -725,13 +803,13 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
       if (item + 1 == items && more) build_rows(t + nslots);
       flush_pending();
       ST_STAMP(3);
-      st_contract<NB, PREC>(smem, px, wb, mb, lane, acc);
+      st_contract<NB, PREC>(smem, px, wof(0), mb, lane, acc);
       ST_STAMP(4);
       __syncthreads();
       ST_STAMP(5);
       // ---- intervals 2 .. K-1: T_{k-1}, and the next item's pieces ---------------------------------------------------------
       if (a.K > 2) {
-        st_contract<NB, PREC>(smem, py, wb + (unsigned)(1 * NB * 2048), mb, lane, acc);
+        st_contract<NB, PREC>(smem, py, wof(1), mb, lane, acc);
         ST_STAMP(6);
         if (more) dma_group(0, nn, cn, pxn, wbn);
         ST_STAMP(7);
@@ -739,7 +817,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
         ST_STAMP(8);
       }
       if (a.K > 3) {
-        st_contract<NB, PREC>(smem, px, wb + (unsigned)(2 * NB * 2048), mb, lane, acc);
+        st_contract<NB, PREC>(smem, px, wof(2), mb, lane, acc);
         ST_STAMP(9);
         if (more) dma_group(1, nn, cn, pxn, wbn);
         if (more && early) dma_group(2, nn, cn, pxn, wbn);
@@ -748,7 +826,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
         ST_STAMP(11);
       }
       if (a.K > 4) {
-        st_contract<NB, PREC>(smem, py, wb + (unsigned)(3 * NB * 2048), mb, lane, acc);
+        st_contract<NB, PREC>(smem, py, wof(3), mb, lane, acc);
         ST_STAMP(12);
         if (more && !early) dma_group(2, nn, cn, pxn, wbn);
         ST_STAMP(13);
@@ -766,11 +844,12 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
       // contracted now, in front of the next B_a
       pend = true;
       pend_plane = ((a.K - 1) & 1) ? py : px;
-      pend_w = wb + (unsigned)((a.K - 1) * NB * 2048);
+      pend_w = wof(a.K - 1);
       pend_store = c == a.C - 1;
       pend_n = n;
       pend_row0 = row0;
       if ((a.K - 1) & 1) flush_pending();
+      ++itC;
       px = pxn;
       wb = wbn;
       n = nn;

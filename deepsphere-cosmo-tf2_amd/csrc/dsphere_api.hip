@@ -228,7 +228,7 @@ int dsph_poly_forward_part(const dsph_plan* p, const float* x, const float* w, c
     return DSPH_E_BADARG;
   }
   if (act < DSPH_ACT_NONE || act > DSPH_ACT_TANH) { set_error("cheb_forward: unknown activation %d", act); return DSPH_E_BADARG; }
-  if (precision != DSPH_PREC_FP32 && precision != DSPH_PREC_BF16X3) { set_error("cheb_forward: unknown precision %d", precision); return DSPH_E_BADARG; }
+  if (precision != DSPH_PREC_FP32 && precision != DSPH_PREC_BF16X3 && precision != DSPH_PREC_BF16X6) { set_error("cheb_forward: unknown precision %d", precision); return DSPH_E_BADARG; }
   if (!p->levels.empty() && (int)p->levels.size() < K - 1) {
     set_error("cheb_forward: plan has %d levels, K = %d needs %d", (int)p->levels.size(), K, K - 1);
     return DSPH_E_BADARG;
@@ -338,6 +338,7 @@ size_t dsph_backward_weights_workspace_bytes(const dsph_plan* p, int64_t N, int3
 int dsph_cheb_backward_weights(const dsph_plan* p, const float* x, const float* dy, float* dw, int64_t N,
                                int32_t Fin, int32_t Fout, int32_t K, int32_t basis, int32_t precision, int32_t algo,
                                void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (precision == DSPH_PREC_BF16X6) precision = DSPH_PREC_FP32;  // (only the structured forward kernel has the 6-term form)
   if (precision != DSPH_PREC_FP32 && precision != DSPH_PREC_BF16X3) {
     set_error("backward_weights: unknown precision %d", precision);
     return DSPH_E_BADARG;

@@ -37,7 +37,7 @@ _ACT_BY_NAME = {
     "softmax": (lambda t: torch.softmax(t, dim=-1), None),
 }
 
-_PRECISIONS = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3}
+_PRECISIONS = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}
 _ALGOS = {"auto": _native.ALGO_AUTO, "unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}
 
 
@@ -58,11 +58,14 @@ def _resolve_activation(activation):
     raise ValueError(f"Could not find activation <{activation}> in tf.keras.activations...")
 
 
-# The contraction arithmetic a layer uses when the caller does not say: exact fp32.  The 3-term split-bf16 form ("bf16x3") is
-# 1.55 x faster at the headline shape and measures 2-6e-6 of max|y| wherever the inner dimension K*Fin is large, but it has
-# no worst-case guarantee at the 1e-5 of SURVEY 8c: a product can be off by 3 * 2^-18 = 1.1e-5, and with five terms per
-# output (Fin = 1, K = 5: BASELINE configs[0] on the whole map) 1.02e-5 was measured -- so it stays opt-in.
-DEFAULT_PRECISION = "fp32"
+# The contraction arithmetic a layer uses when the caller does not say: "bf16x6", the fp32-EQUIVALENT six-term split on the
+# bf16 matrix pipe (both operands split exactly into 8 + 8 + 8 mantissa bits, the six products down to 2^-16 kept, fp32
+# accumulation): 2-7e-7 of max|y| from the float64 oracle at every tested shape -- the figures of "fp32", the bitwise
+# fp32-fma-chain MFMA, which costs 1.2 x the time at the headline shape and stays available.  The 3-term split ("bf16x3",
+# 1.3 x faster again, what bench.py times) measures 2-6e-6 wherever the inner dimension K*Fin is large, but has no
+# worst-case guarantee at the 1e-5 of SURVEY 8c: a product can be off by 3 * 2^-18 = 1.1e-5, and with five terms per output
+# (Fin = 1, K = 5: BASELINE configs[0] on the whole map) 1.02e-5 was measured -- so it stays opt-in.
+DEFAULT_PRECISION = "bf16x6"
 
 
 class _ChebConvFunction(torch.autograd.Function):
@@ -156,9 +159,10 @@ class Chebyshev(torch.nn.Module):
             TensorFlow-GPU's sparse-matmul size limit, the HIP kernel has none
         :param kwargs: the reference forwards these to ``add_weight`` (regularizer, ...); stored in
             ``self.kwargs``.  Three keys are consumed here: ``device`` (torch device of the layer,
-            default: current CUDA device), ``precision`` ("fp32", the default: exact-fp32 MFMA contraction, 3-7e-7 of max|y| from the
-            float64 oracle | "bf16x3": three bf16 MFMAs per product with fp32 accumulation, 2-6e-6 at the BASELINE shapes
-            with 16 or more input channels, 1.55 x faster at the headline shape; the recurrence is fp32 either way) and ``algo`` ("auto" | "unfused" | "fused").
+            default: current CUDA device), ``precision`` ("bf16x6", the default: fp32-equivalent six-term bf16 split, 2-7e-7 of max|y|
+            from the float64 oracle | "fp32": exact-fp32 MFMA, bitwise an fp32 fma chain, same accuracy, 1.2 x the time |
+            "bf16x3": three-term split, 2-6e-6 at shapes with 16 or more input channels, 1.3 x faster; the recurrence is
+            fp32 in all three) and ``algo`` ("auto" | "unfused" | "fused").
         """
         super().__init__()
         self.L = L

@@ -290,7 +290,7 @@ class ShardedChebyshev:
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.group = group
         self._compute = _compute
-        self.precision = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3}[precision]
+        self.precision = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}[precision]
         self.algo = {"auto": _native.ALGO_AUTO, "unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}[algo]
         self.act = act
         # a torch tensor (e.g. a Parameter that requires grad) is kept as it is: calling the layer is then differentiable

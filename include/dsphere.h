@@ -47,6 +47,11 @@ extern "C" {
 /* arithmetic of the dense [K*Fin]x[Fout] contraction (the recurrence is always fp32) */
 #define DSPH_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain        */
 #define DSPH_PREC_BF16X3 1 /* hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+/* fp32-equivalent on the bf16 matrix pipe: both operands split three ways (8 + 8 + 8 mantissa bits), the six products
+ * down to 2^-16 kept (hh, hm, mh, mm, hl, lh), fp32 accumulate: what is dropped is 2^-23 of a product, the size of an
+ * fp32 rounding.  A third of the matrix-pipe time of DSPH_PREC_FP32.  The structured-tile kernel implements it; every
+ * other kernel (BFS tiles, unfused, weight gradient) runs DSPH_PREC_FP32 when asked for it. */
+#define DSPH_PREC_BF16X6 2
 
 /* polynomial basis of the recurrence: T_1 = L~ x in both;
  *   Chebyshev: T_k = 2 L~ T_{k-1} - T_{k-2}   (reference gnn_layers.Chebyshev, gnn_layers.py:137-143)

@@ -24,7 +24,7 @@ def case(nside, K, Fin, Fout, N, prec, oracle=True, act=0, bias=False):
     x = torch.randn((N, M, Fin), device=dev, generator=g)
     w = torch.randn((Fin * K, Fout), device=dev, generator=g) / np.sqrt(Fin * (K + 0.5) / 2)
     b = torch.randn((Fout,), device=dev, generator=g) if bias else None
-    P = _native.PREC_BF16X3 if prec == "bf16x3" else _native.PREC_FP32
+    P = {"bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}.get(prec, _native.PREC_FP32)
     ok = (plan.fused_ok(Fin, Fout, K), plan.tile_counts(K))
     y_f, _ = _native.cheb_forward(plan, x, w, b, K, act=act, precision=P, algo=_native.ALGO_FUSED)
     y_u, _ = _native.cheb_forward(plan, x, w, b, K, act=act, precision=_native.PREC_FP32, algo=_native.ALGO_UNFUSED)
@@ -59,7 +59,7 @@ def timing(nside, K, Fin, Fout, N, prec, reps=10):
     plan = _native.LaplacianPlan(cols, vals, device=0)
     x = torch.randn((N, M, Fin), device=dev)
     w = torch.randn((Fin * K, Fout), device=dev) / np.sqrt(Fin * (K + 0.5) / 2)
-    P = _native.PREC_BF16X3 if prec == "bf16x3" else _native.PREC_FP32
+    P = {"bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}.get(prec, _native.PREC_FP32)
     ws = None
     out = None
     print("tiles (struct, bfs):", plan.tile_counts(K), flush=True)
