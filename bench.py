@@ -172,8 +172,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
-                    help="contraction arithmetic: bf16x3 = 3-pass split-bf16 MFMA with fp32 accumulate (error 4-6e-6 of max|y|, inside the fp32 tolerance); fp32 = exact fp32 MFMA")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16x6"],
+                    help="contraction arithmetic: bf16x3 = 3-term split-bf16 MFMA with fp32 accumulate (2-3e-6 of max|y| at the "
+                         "headline shape, measured in the line); bf16x6 = fp32-equivalent 6-term split (the layers' default); "
+                         "fp32 = exact fp32 MFMA")
     ap.add_argument("--algo", default="auto", choices=["auto", "unfused", "fused"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = halo rows "
@@ -363,8 +365,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak" if replicas_note else "strong",
             "vs_baseline": None,
-            "dtype": ("f32 (recurrence and contraction exact f32: v_mfma_f32_32x32x2_f32" if args.precision == "fp32" else
-                      "f32 (recurrence f32; contraction 3-pass split-bf16 MFMA with f32 accumulate") + (f"; {err_note})" if err_note else ")"),
+            "dtype": ({"fp32": "f32 (recurrence and contraction exact f32: v_mfma_f32_32x32x2_f32",
+                       "bf16x6": "f32 (recurrence f32; contraction fp32-equivalent: 6-term exact split on the bf16 MFMA with f32 accumulate",
+                       "bf16x3": "f32 (recurrence f32; contraction 3-pass split-bf16 MFMA with f32 accumulate"}[args.precision]
+                      + (f"; {err_note})" if err_note else ")")),
             "data": "synthetic",
             "config": {
                 "workload": f"nside={nside} {'partial sky (cap of 1/3 of the sphere, nside-8 superpixels)' if args.config in MASKED else 'full-sphere'}, K={K}, Fin={Fin}, Fout={Fout}, batch={N} ({args.config})",

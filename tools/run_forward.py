@@ -14,7 +14,7 @@ import bench  # noqa: E402
 from deepsphere import _native  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
-prec = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3}[sys.argv[2] if len(sys.argv) > 2 else "bf16x3"]
+prec = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}[sys.argv[2] if len(sys.argv) > 2 else "bf16x3"]
 algo = {"auto": 0, "unfused": 1, "fused": 2}[sys.argv[3] if len(sys.argv) > 3 else "auto"]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 nside, K, Fin, Fout, N = bench.CONFIGS[cfg]
