@@ -156,6 +156,44 @@ int launch_struct_act(float* y, int64_t rows, int32_t cols, int32_t ld, int32_t 
   return DSPH_OK;
 }
 
+// Skip connection of a residual block in one pass (dsph_residual_epilogue): four floats per thread where the pointers allow.
+template <bool BEFORE>
+__global__ __launch_bounds__(256) void residual_epilogue_kernel(float* __restrict__ y, const float* __restrict__ skip, int64_t n,
+                                                                float alpha, int act, int vec) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      float4 a = reinterpret_cast<float4*>(y)[i];
+      const float4 b = reinterpret_cast<const float4*>(skip)[i];
+      if (BEFORE) {
+        a.x = apply_act(a.x, act) + alpha * b.x; a.y = apply_act(a.y, act) + alpha * b.y;
+        a.z = apply_act(a.z, act) + alpha * b.z; a.w = apply_act(a.w, act) + alpha * b.w;
+      } else {
+        a.x = apply_act(a.x + alpha * b.x, act); a.y = apply_act(a.y + alpha * b.y, act);
+        a.z = apply_act(a.z + alpha * b.z, act); a.w = apply_act(a.w + alpha * b.w, act);
+      }
+      reinterpret_cast<float4*>(y)[i] = a;
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+      y[i] = BEFORE ? apply_act(y[i], act) + alpha * skip[i] : apply_act(y[i] + alpha * skip[i], act);
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+      y[i] = BEFORE ? apply_act(y[i], act) + alpha * skip[i] : apply_act(y[i] + alpha * skip[i], act);
+  }
+}
+
+int launch_residual_epilogue(float* y, const float* skip, int64_t n, float alpha, int32_t act, bool before, hipStream_t stream) {
+  if (n <= 0) return DSPH_OK;
+  const int vec = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(skip)) & 15) == 0;
+  const int64_t work = vec ? (n + 3) / 4 : n;
+  const unsigned grid = (unsigned)std::min<int64_t>((work + 255) / 256, 256 * 32);
+  if (before) hipLaunchKernelGGL(residual_epilogue_kernel<true>, dim3(grid), dim3(256), 0, stream, y, skip, n, alpha, (int)act, vec);
+  else hipLaunchKernelGGL(residual_epilogue_kernel<false>, dim3(grid), dim3(256), 0, stream, y, skip, n, alpha, (int)act, vec);
+  DSPH_HIP(hipGetLastError());
+  return DSPH_OK;
+}
+
 bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K) {
   const int NB = (Fout + 31) / 32;
   return K >= 2 && K - 1 <= ST_DMAX && Fin >= 4 && Fin % 4 == 0 && Fout >= 1 && Fout <= 64 &&

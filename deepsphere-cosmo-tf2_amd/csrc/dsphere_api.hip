@@ -426,4 +426,12 @@ int dsph_rows_unpack(float* dst, int64_t dst_rows, const int32_t* idx, int64_t n
   return launch_rows_pack(dst, dst_rows, idx, n_idx, const_cast<float*>(buf), N, F, true, (hipStream_t)hip_stream);
 }
 
+int dsph_residual_epilogue(float* y, const float* skip, int64_t n, float alpha, int32_t act, int32_t act_before,
+                           int device, void* hip_stream) {
+  if (!y || !skip || n < 0) { set_error("residual_epilogue: bad arguments"); return DSPH_E_BADARG; }
+  if (act < DSPH_ACT_NONE || act > DSPH_ACT_TANH) { set_error("residual_epilogue: unknown activation %d", act); return DSPH_E_BADARG; }
+  DeviceGuard guard(device);
+  return launch_residual_epilogue(y, skip, n, alpha, act, act_before != 0, (hipStream_t)hip_stream);
+}
+
 }  // extern "C"

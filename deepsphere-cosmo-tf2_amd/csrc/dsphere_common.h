@@ -112,6 +112,7 @@ bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
 size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K);
 int launch_cheb_struct(const StructLaunch& s, hipStream_t stream);
 int launch_struct_act(float* y, int64_t rows, int32_t cols, int32_t ld, int32_t act, hipStream_t stream);
+int launch_residual_epilogue(float* y, const float* skip, int64_t n, float alpha, int32_t act, bool before, hipStream_t stream);
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {

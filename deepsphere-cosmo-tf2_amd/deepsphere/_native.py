@@ -82,6 +82,7 @@ SIGNATURES = {
     ),
     "dsph_rows_pack": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_i64, _c_i32, ctypes.c_int, _c_vp]),
     "dsph_rows_unpack": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_i64, _c_i32, ctypes.c_int, _c_vp]),
+    "dsph_residual_epilogue": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_float, _c_i32, _c_i32, ctypes.c_int, _c_vp]),
 }
 
 
@@ -375,3 +376,17 @@ def rows_unpack(dst, idx, buf):
                                 dst.device.index, _stream_ptr(dst.device))
     check(rc, "dsph_rows_unpack")
     return dst
+
+
+def residual_epilogue(y, skip, alpha=1.0, act=ACT_NONE, act_before=False):
+    """In place, one pass (``dsph_residual_epilogue``): y = act(y + alpha * skip), or act(y) + alpha * skip."""
+    if not (y.is_cuda and skip.is_cuda and y.device == skip.device):
+        raise ValueError("residual_epilogue works on HIP tensors of one device")
+    if y.dtype != skip.dtype or str(y.dtype) != "torch.float32" or y.shape != skip.shape:
+        raise ValueError("y and skip must be float32 tensors of one shape")
+    if not (y.is_contiguous() and skip.is_contiguous()):
+        raise ValueError("y and skip must be contiguous")
+    rc = lib().dsph_residual_epilogue(_ptr(y), _ptr(skip), int(y.numel()), float(alpha), int(act), 1 if act_before else 0,
+                                      int(y.device.index), _stream_ptr(y.device))
+    check(rc, "dsph_residual_epilogue")
+    return y

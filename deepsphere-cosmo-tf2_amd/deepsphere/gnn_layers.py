@@ -407,7 +407,7 @@ class GCNN_ResidualLayer(torch.nn.Module):
         super().__init__()
         self.layer_type = layer_type
         self.layer_kwargs = layer_kwargs
-        self.activation, _ = _resolve_activation(activation)
+        self.activation, self._act_code = _resolve_activation(activation)
         self.act_before = act_before
         self.use_bn = use_bn
         self.norm_type = norm_type
@@ -465,6 +465,17 @@ class GCNN_ResidualLayer(torch.nn.Module):
         x = self.layer2(x, training=training)
         if self.use_bn:
             x = self._norm("bn2", x, training)
+        # inference on the GPU: skip connection and activation in ONE elementwise pass over the map (dsph_residual_epilogue)
+        # instead of the host framework's three or four; with autograd on, or an activation the kernels do not know, the
+        # host framework composes them as the reference does (gnn_layers.py:407-413)
+        native = (x.is_cuda and inp.is_cuda and inp.shape == x.shape and x.dtype == torch.float32
+                  and not (torch.is_grad_enabled() and (x.requires_grad or inp.requires_grad))
+                  and (self.activation is None or self._act_code is not None))
+        if native:
+            x = x.contiguous()
+            if self.activation is None:
+                return _native.residual_epilogue(x, inp.contiguous(), 1.0, _native.ACT_NONE, False)
+            return _native.residual_epilogue(x, inp.contiguous(), float(self.alpha), self._act_code, bool(self.act_before))
         if self.activation is None:
             return x + inp
         if self.act_before:

@@ -226,6 +226,13 @@ int dsph_rows_pack(const float* src, int64_t src_rows, const int32_t* idx, int64
 int dsph_rows_unpack(float* dst, int64_t dst_rows, const int32_t* idx, int64_t n_idx,
                      const float* buf, int64_t N, int32_t F, int device, void* hip_stream);
 
+/* Skip connection of a residual block (reference gnn_layers.GCNN_ResidualLayer.call, gnn_layers.py:407-413: tf.add and
+ * the activation, three elementwise ops over the whole map) in ONE pass, in place over n contiguous floats:
+ *   act_before == 0:  y = act(y + alpha * skip)          act_before != 0:  y = act(y) + alpha * skip
+ * act is a DSPH_ACT_* code (DSPH_ACT_NONE with alpha = 1 is the reference's activation=None case, x + input). */
+int dsph_residual_epilogue(float* y, const float* skip, int64_t n, float alpha, int32_t act, int32_t act_before,
+                           int device, void* hip_stream);
+
 const char* dsph_last_error(void);
 int dsph_abi_version(void);
 

@@ -480,3 +480,27 @@ def test_healpy_gcnn_values_against_the_oracle_composition():
     err = rel_err(y, cur)
     print(f"HealpyGCNN vs oracle composition: rel err {err:.2e}")
     assert err < 1e-5
+
+
+@pytest.mark.parametrize("activation,act_before,alpha", [(None, False, 0.3), ("relu", False, 0.5), ("elu", True, 0.5), ("tanh", False, 1.0)])
+def test_residual_block_skip_connection_in_one_pass(activation, act_before, alpha):
+    """GCNN_ResidualLayer (reference gnn_layers.py:312-413): in inference the skip connection and the activation run as
+    one in-place kernel (dsph_residual_epilogue); the result equals the host framework's composition, which autograd
+    still uses, and the raw entry point handles unaligned tails."""
+    L = healpix.healpix_laplacian(16, mode="grid")
+    rng = np.random.default_rng(4)
+    x = _dev(rng.standard_normal((2, L.shape[0], 8)).astype(np.float32))
+    torch.manual_seed(3)
+    block = gnn_layers.GCNN_ResidualLayer("CHEBY", {"L": L, "K": 3}, activation=activation, act_before=act_before, alpha=alpha).cuda()
+    with torch.no_grad():
+        y_native = block(x)
+    with torch.enable_grad():  # autograd on: the host framework composes the skip connection
+        y_torch = block(x.clone().requires_grad_(True)).detach()
+    assert torch.allclose(y_native, y_torch, rtol=1e-6, atol=1e-6)
+    # the entry point itself, odd length and a misaligned view (scalar path)
+    for n, off in [(1003, 0), (4096, 1)]:
+        a = torch.randn(n + off, device="cuda")[off:]  # off = 1: a view that starts 4 bytes past a 16-byte boundary
+        b = torch.randn(n, device="cuda")
+        ref = torch.tanh(a + 0.25 * b)
+        got = _native.residual_epilogue(a, b, 0.25, _native.ACT_TANH, False)
+        assert got.data_ptr() == a.data_ptr() and torch.allclose(got, ref, rtol=1e-6, atol=1e-6)
