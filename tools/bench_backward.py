@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Forward + backward of the layer at a benchmark config (SURVEY 8 f1 measurement).
 
-    python tools/bench_backward.py [c3|c2] [steps]
+    python tools/bench_backward.py [c3|c2] [steps] [bf16x3|bf16x6|fp32]
 Prints one JSON line: ms per forward+backward step (HIP events), and its split."""
 import json
 import os
@@ -23,7 +23,8 @@ dev = torch.device("cuda", 0)
 cols, vals, lmax = bench.build_laplacian(nside, dev)
 M = cols.shape[0]
 w_np = (np.random.default_rng(13).standard_normal((Fin * K, Fout)) / np.sqrt(Fin * (K + 0.5) / 2)).astype(np.float32)
-layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, lmax=lmax, Fout=Fout, device=dev, precision="bf16x3",
+prec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
+layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, lmax=lmax, Fout=Fout, device=dev, precision=prec,
                                                initializer=lambda t: t.copy_(torch.from_numpy(w_np)))
 x = torch.randn((N, M, Fin), device=dev).requires_grad_(True)
 dy = torch.randn((N, M, Fout), device=dev)
