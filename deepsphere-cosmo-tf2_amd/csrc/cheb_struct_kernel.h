@@ -21,6 +21,13 @@
 //     barrier interval in which step k reads it, issue every LDS-DMA piece (a vector-memory instruction holds the
 //     issuing wave for hundreds of cycles), and store y.  The last plane of an item is contracted, and a finished map
 //     stored, under the FIRST step of the next item, so nothing but the recurrence is on the critical path;
+//   * class-T tiles (TAB = true): the same kernel for tiles whose region is a stencil square but whose halo rows are not a
+//     Morton continuation of the tile's (the next base pixel of the sphere, the halo rows of a sharded plan): the row of
+//     every plane cell and the nine values of L~ of every cell come from per-tile tables (embed_tile, cheb_fused.hip);
+//   * three contraction arithmetics (st_contract): exact-fp32 MFMA, the three-term split-bf16 form, and the six-term
+//     fp32-equivalent split whose 3 KiB weight blocks are replaced in place in LDS (DSPH_PREC_BF16X6);
+//   * at K = 5 no barrier in front of the item: every LDS-DMA piece is issued at least an interval before the barrier that
+//     ends the item, each wave drains vmcnt in front of it;
 //   * the contraction is transposed (A = weight fragment, B = plane fragment): the accumulator holds 4 consecutive
 //     output channels of ONE pixel per register quad; y goes through a 4 KiB transposition block -- the wave's own
 //     64 tile cells of the plane it has just contracted -- so that eight lanes store 128 contiguous bytes.
