@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "cheb_fused_kernel.h"
+#include "cheb_strip_kernel.h"
 #include "cheb_struct_kernel.h"
 
 namespace dsph {
@@ -64,6 +65,13 @@ struct FusedTiles {
   int32_t* d_tabrow = nullptr;  // [n_t][ST_CELLS] row of every plane cell
   float* d_tabvals = nullptr;   // [n_t][ST_CELLS][ST_TABV] diagonal + eight directions of L~ per cell, in the tile's frame
   int n_t = 0, n_t_interior = 0;
+  // strip kernel (cheb_strip_kernel.h): rectangles of interior class-R tiles cut into strip pairs, and the class-R tiles
+  // they leave over (interior ones first).  Built next to d_rlist; which of the two sets a forward uses depends on its shape.
+  StripPair* d_pairs = nullptr;
+  int n_pairs = 0;
+  int64_t n_strip_tiles = 0;
+  int32_t* d_rrest = nullptr;
+  int n_rrest = 0, n_rrest_interior = 0;
 };
 
 struct FusedPlan {
@@ -98,6 +106,8 @@ static void free_tiles(FusedTiles& ft) {
   if (ft.d_tlist) (void)hipFree(ft.d_tlist);
   if (ft.d_tabrow) (void)hipFree(ft.d_tabrow);
   if (ft.d_tabvals) (void)hipFree(ft.d_tabvals);
+  if (ft.d_pairs) (void)hipFree(ft.d_pairs);
+  if (ft.d_rrest) (void)hipFree(ft.d_rrest);
   ft = FusedTiles();
 }
 
@@ -257,6 +267,111 @@ static bool embed_tile(const dsph_plan* plan, const int32_t* cols, const float* 
       }
     }
   return true;
+}
+
+// Strip kernel: which class-R tiles it takes, and in what pieces.  The interior class-R tiles are covered greedily by
+// rectangles (in the virtual Morton plane of the tile indices: tile t sits at (compress(t), compress(t >> 1))); a
+// rectangle of at least 3 x 4 tiles is cut into 32-column strips with 24 output columns each, two strips per
+// workgroup item, and into row segments sized so that the items fill the CUs evenly.  Tiles of smaller rectangles
+// stay with the tile kernels (`rest`).
+static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_cu, std::vector<StripPair>& pairs,
+                         std::vector<int32_t>& rest, int64_t* n_taken) {
+  pairs.clear();
+  rest.clear();
+  *n_taken = 0;
+  struct Rect { int tx, ty, wt, ht; };
+  std::vector<Rect> rects;
+  std::vector<uint64_t> keys(r_interior.size());
+  for (size_t i = 0; i < r_interior.size(); ++i) {
+    const unsigned t = (unsigned)r_interior[i];
+    keys[i] = ((uint64_t)st_compress(t >> 1) << 32) | st_compress(t);
+  }
+  std::sort(keys.begin(), keys.end());
+  std::vector<char> used(keys.size(), 0);
+  auto find = [&](unsigned tx, unsigned ty) -> long {
+    const uint64_t k = ((uint64_t)ty << 32) | tx;
+    auto it = std::lower_bound(keys.begin(), keys.end(), k);
+    return (it != keys.end() && *it == k) ? (long)(it - keys.begin()) : -1;
+  };
+  for (size_t i = 0; i < keys.size(); ++i) {
+    if (used[i]) continue;
+    const unsigned tx = (unsigned)(keys[i] & 0xffffffffu), ty = (unsigned)(keys[i] >> 32);
+    int wt = 1;
+    for (;; ++wt) {
+      const long j = find(tx + wt, ty);
+      if (j < 0 || used[j]) break;
+    }
+    int ht = 1;
+    for (;; ++ht) {
+      bool all = true;
+      for (int u = 0; u < wt && all; ++u) {
+        const long j = find(tx + u, ty + ht);
+        all = j >= 0 && !used[j];
+      }
+      if (!all) break;
+    }
+    for (int v = 0; v < ht; ++v)
+      for (int u = 0; u < wt; ++u) used[find(tx + u, ty + v)] = 1;
+    rects.push_back({(int)tx, (int)ty, wt, ht});
+  }
+  // rectangles worth streaming: at least one full strip pair wide, and tall enough to pay for the 2 D + 1 rows of run-in
+  std::vector<Rect> take;
+  for (const Rect& r : rects) {
+    if (r.wt >= 3 && r.ht >= 4) {
+      take.push_back(r);
+      *n_taken += (int64_t)r.wt * r.ht;
+    } else {
+      for (int v = 0; v < r.ht; ++v)
+        for (int u = 0; u < r.wt; ++u) rest.push_back((int32_t)st_morton((unsigned)(r.tx + u), (unsigned)(r.ty + v)));
+    }
+  }
+  std::sort(rest.begin(), rest.end());
+  if (take.empty()) return;
+  // segment height: the one that minimises (items per CU, rounded up) x (rows per item + run-in)
+  const int cand[] = {4096, 2048, 1024, 512, 384, 256, 192, 128, 96, 64};
+  long best_cost = -1;
+  int best_h = 256;
+  for (int h : cand) {
+    long items = 0, hmax = 0;
+    for (const Rect& r : take) {
+      const int np = ((16 * r.wt + SP_USE - 1) / SP_USE + 1) / 2, H = 16 * r.ht;
+      const int nseg = (H + h - 1) / h;
+      items += (long)np * nseg;
+      hmax = std::max<long>(hmax, (H + nseg - 1) / nseg);
+    }
+    const long cost = ((items + num_cu - 1) / num_cu) * (hmax + 2 * D + 1);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_h = h; }
+  }
+  for (const Rect& r : take) {
+    const int X0 = 16 * r.tx, X1 = 16 * (r.tx + r.wt), Y0 = 16 * r.ty, Y1 = 16 * (r.ty + r.ht);
+    const int ns = (X1 - X0 + SP_USE - 1) / SP_USE;
+    const int H = Y1 - Y0, nseg = (H + best_h - 1) / best_h;
+    for (int sg = 0; sg < nseg; ++sg) {
+      const int ya = Y0 + (int)((int64_t)H * sg / nseg), yb = Y0 + (int)((int64_t)H * (sg + 1) / nseg);
+      for (int s0 = 0; s0 < ns; s0 += 2) {
+        StripPair p;
+        for (int e = 0; e < 2; ++e) {
+          const int s = s0 + e;
+          if (s < ns) {
+            p.x0[e] = X0 + SP_USE * s;
+            p.w[e] = std::min(SP_USE, X1 - p.x0[e]);
+          } else {
+            p.x0[e] = p.x0[0];
+            p.w[e] = 0;
+          }
+        }
+        p.y0 = ya;
+        p.y1 = yb;
+        p.xlo = X0 - D;
+        p.xhi = X1 - 1 + D;
+        for (int e = 0; e < 2; ++e)  // lane 0 of the strip: D columns left of the first output column, but never past the halo
+          p.xs[e] = std::min(p.x0[e] - D, p.xhi + 1 - SP_PX);
+        p.ylo = Y0 - D;
+        p.yhi = Y1 - 1 + D;
+        pairs.push_back(p);
+      }
+    }
+  }
 }
 
 // Breadth-first rings of every tile; uploads the tables.  Returns a reference to the cached entry.
@@ -441,6 +556,19 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   interior.insert(interior.end(), boundary.begin(), boundary.end());
   ft.n_part = (int)interior.size();
   if (interior.empty()) interior.push_back(0);
+  std::vector<StripPair> pairs;
+  std::vector<int32_t> rrest;
+  ft.n_strip_tiles = 0;
+  if (!full && D <= SP_DMAX && getenv("DSPH_NO_STRIP") == nullptr)
+    build_strips(r_interior, D, fp->num_cu, pairs, rrest, &ft.n_strip_tiles);
+  else
+    rrest = r_interior;
+  ft.n_pairs = (int)pairs.size();
+  ft.n_rrest_interior = (int)rrest.size();
+  rrest.insert(rrest.end(), r_boundary.begin(), r_boundary.end());
+  ft.n_rrest = (int)rrest.size();
+  if (rrest.empty()) rrest.push_back(0);
+  if (pairs.empty()) pairs.push_back(StripPair());
   ft.n_r_interior = (int)r_interior.size();
   r_interior.insert(r_interior.end(), r_boundary.begin(), r_boundary.end());
   ft.n_r = (int)r_interior.size();
@@ -461,7 +589,9 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
               up((void**)&ft.d_lcols, lcols.data(), lcols.size() * 2) &&
               up((void**)&ft.d_lvals, lvals.data(), lvals.size() * 4) &&
               up((void**)&ft.d_part, interior.data(), interior.size() * 4) &&
-              up((void**)&ft.d_rlist, r_interior.data(), r_interior.size() * 4);
+              up((void**)&ft.d_rlist, r_interior.data(), r_interior.size() * 4) &&
+              up((void**)&ft.d_rrest, rrest.data(), rrest.size() * 4) &&
+              up((void**)&ft.d_pairs, pairs.data(), pairs.size() * sizeof(StripPair));
   if (!good) {
     FusedTiles keep = ft;
     free_tiles(ft);
@@ -483,6 +613,11 @@ static int plane_rows_for(int rmax, int emax) {
 static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
   const int C = (Fin + FUSED_CH - 1) / FUSED_CH, NB = (Fout + 31) / 32;
   return (size_t)K * C * NB * 2048;
+}
+
+// weight images of the three fused kernels, back to back in the workspace: BFS-tile | structured-tile | strip
+static size_t all_frag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
+  return wfrag_bytes(Fin, Fout, K) + struct_wfrag_bytes(Fin, Fout, K) + strip_wimg_bytes(Fin, Fout, K);
 }
 
 // The structured-tile kernel addresses x by 32-bit byte offsets inside a map: larger maps take BFS tables throughout.
@@ -540,7 +675,7 @@ bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int6
 // two fragment layouts: the BFS-tile kernel's and, behind it, the structured-tile kernel's
 size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t) {
   const int32_t Fp = pad4(Fin);
-  const size_t frag = wfrag_bytes(Fp, std::min(Fout, 64), K) + struct_wfrag_bytes(Fp, std::min(Fout, 64), K);
+  const size_t frag = all_frag_bytes(Fp, std::min(Fout, 64), K);
   return frag + (Fp != Fin ? (size_t)N * (size_t)plan->n_cols * (size_t)Fp * 4 : 0);  // + the zero-padded copy of x
 }
 
@@ -628,7 +763,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
   const int32_t Fin_w = Fin;
   if (Fin != pad4(Fin)) {
     const int32_t Fp = pad4(Fin);
-    const size_t frag = wfrag_bytes(Fp, std::min(Fout, 64), K) + struct_wfrag_bytes(Fp, std::min(Fout, 64), K);
+    const size_t frag = all_frag_bytes(Fp, std::min(Fout, 64), K);
     const size_t need = frag + (size_t)N * (size_t)plan->n_cols * (size_t)Fp * 4;
     if (!workspace || workspace_bytes < need) {
       set_error("cheb_fused: workspace %zu < %zu", workspace_bytes, need);
@@ -741,7 +876,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   }
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, planes_mode));
   const size_t wb = planes_mode ? 0 : wfrag_bytes(Fin, Fout, K);
-  const size_t wb_all = planes_mode ? 0 : wb + struct_wfrag_bytes(Fin, Fout, K);
+  const size_t wb_all = planes_mode ? 0 : all_frag_bytes(Fin, Fout, K);
   if (!planes_mode && (!workspace || workspace_bytes < wb_all)) {
     set_error("cheb_fused: workspace %zu < %zu", workspace_bytes, wb_all);
     return DSPH_E_WORKSPACE;
@@ -766,9 +901,28 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     sl.num_cu = plan->fused->num_cu;
     sl.cheb = beta_rest != 0.f;
     sl.prep_weights = true;  // the first of the two launches packs the fragments
-    const int nr = part == 0 ? ft.n_r : (part == 1 ? ft.n_r_interior : ft.n_r - ft.n_r_interior);
+    // rectangles of interior class-R tiles: the strip kernel, when it has this shape; the class-R list shrinks to the rest
+    const bool strips = ft.n_pairs > 0 && precision == DSPH_PREC_BF16X3 && strip_shape_ok(Fin, Fout, K) && Fin_w == Fin &&
+                        (reinterpret_cast<uintptr_t>(y) & 15) == 0 && ld % 4 == 0 && plan->n_cols * (int64_t)ld * 4 < (1ll << 32);
+    if (strips && part != 2 && !dbg_only('b')) {
+      StripLaunch st;
+      st.x = x; st.w = w; st.bias = bias; st.y = y;
+      st.wimg = static_cast<unsigned char*>(workspace) + wb + struct_wfrag_bytes(Fin, Fout, K);
+      st.pairs = ft.d_pairs;
+      st.gvals8 = plan->fused->d_gvals8;
+      st.gdiag = plan->fused->d_gdiag;
+      st.x_rows = sl.x_rows; st.y_rows = sl.y_rows; st.N = N;
+      st.npairs = ft.n_pairs; st.Fin = Fin; st.Fout = Fout; st.K = K; st.act = act; st.precision = precision; st.ld = ld;
+      st.num_cu = plan->fused->num_cu;
+      st.cheb = sl.cheb;
+      const int rc = launch_cheb_strip(st, stream);
+      if (rc != DSPH_OK) return rc;
+    }
+    const int32_t* rl = strips ? ft.d_rrest : ft.d_rlist;
+    const int rl_n = strips ? ft.n_rrest : ft.n_r, rl_ni = strips ? ft.n_rrest_interior : ft.n_r_interior;
+    const int nr = part == 0 ? rl_n : (part == 1 ? rl_ni : rl_n - rl_ni);
     if (nr > 0 && !dbg_only('b')) {
-      sl.tiles = part == 2 ? ft.d_rlist + ft.n_r_interior : ft.d_rlist;
+      sl.tiles = part == 2 ? rl + rl_ni : rl;
       sl.tabrow = nullptr;
       sl.tabvals = nullptr;
       sl.ntiles = nr;

@@ -114,6 +114,22 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream);
 int launch_struct_act(float* y, int64_t rows, int32_t cols, int32_t ld, int32_t act, hipStream_t stream);
 int launch_residual_epilogue(float* y, const float* skip, int64_t n, float alpha, int32_t act, bool before, hipStream_t stream);
 
+// strip kernel (cheb_strip.hip): rectangles of class-R tiles, streamed in 32-column strips
+struct StripPair;
+struct StripLaunch {
+  const float* x; const float* w; const float* bias; float* y;
+  unsigned char* wimg;       // workspace: strip_wimg_bytes()
+  const StripPair* pairs;    // device list of strip pairs
+  const float* gvals8; const float* gdiag;
+  int64_t x_rows, y_rows, N;
+  int32_t npairs, Fin, Fout, K, act, precision, ld, num_cu;
+  bool cheb;
+  bool prep_weights = true;
+};
+bool strip_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
+size_t strip_wimg_bytes(int32_t Fin, int32_t Fout, int32_t K);
+int launch_cheb_strip(const StripLaunch& s, hipStream_t stream);
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case DSPH_ACT_RELU: return v > 0.f ? v : 0.f;
