@@ -154,16 +154,33 @@ def measured_error(cols, vals, x, y, w_np, K, nside, seed=3, n_random=24):
     return float(np.abs(got - ref).max() / s_max), int(centres.size * x.shape[0])
 
 
-def fused_kernel_name(plan, K):
-    """Which kernels one fused forward launches: the structured-tile kernel on the class-R tiles, the BFS-tile kernel
-    on the rest (dsph_plan_tile_counts)."""
+def fused_kernel_name(plan, K, Fin, Fout, prec_code):
+    """Which kernels one fused forward launches: the strip kernel on the rectangles of plain structured tiles it takes for this
+    shape (dsph_plan_strip_tiles), the structured-tile kernel on the other structured tiles, the BFS-tile kernel on the rest
+    (dsph_plan_tile_counts)."""
     n_struct, n_bfs = plan.tile_counts(K)
+    n_strip = plan.strip_tiles(Fin, Fout, K, prec_code)
     parts = []
-    if n_struct:
-        parts.append(f"cheb_struct_kernel ({n_struct} tiles)")
+    if n_strip:
+        parts.append(f"cheb_strip5_kernel ({n_strip} tiles)")
+    if n_struct - n_strip:
+        parts.append(f"cheb_struct_kernel ({n_struct - n_strip} tiles)")
     if n_bfs:
         parts.append(f"cheb_fused_kernel ({n_bfs} tiles)")
     return " + ".join(parts)
+
+
+def timed_ms(run, steps, warm=3):
+    """Mean HIP-event time of `steps` forwards on the current stream, after `warm` untimed ones."""
+    for _ in range(warm):
+        run()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        run()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
 def main():
@@ -172,10 +189,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16x6"],
-                    help="contraction arithmetic: bf16x3 = 3-term split-bf16 MFMA with fp32 accumulate (2-3e-6 of max|y| at the "
-                         "headline shape, measured in the line); bf16x6 = fp32-equivalent 6-term split (the layers' default); "
-                         "fp32 = exact fp32 MFMA")
+    ap.add_argument("--precision", default=None, choices=["auto", "fp32", "bf16x3", "bf16x6"],
+                    help="contraction arithmetic; default: the layers' own default (gnn_layers.DEFAULT_PRECISION = auto: bf16x3 with 16 "
+                         "or more input channels, else bf16x6).  bf16x3 = 3-term split-bf16 MFMA with fp32 accumulate (error "
+                         "measured in the line); bf16x6 = fp32-equivalent 6-term split; fp32 = exact fp32 MFMA")
     ap.add_argument("--algo", default="auto", choices=["auto", "unfused", "fused"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = halo rows "
@@ -210,11 +227,12 @@ def main():
     from deepsphere import gnn_layers
 
     nside, K, Fin, Fout, N = CONFIGS[args.config]
-    if args.precision is None:
-        # the three-term split where its error is an average over many products (2-3e-6 at the headline shape, measured in
-        # the line); with fewer than 16 input channels (c1: Fin = 1, five products per output) it can reach 1e-5, so those
-        # configurations are timed with the fp32-equivalent six-term split
-        args.precision = "bf16x3" if Fin >= 16 else "bf16x6"
+    # what is timed is what a user of the layer gets: the layer's default arithmetic unless --precision says otherwise
+    layer_default = args.precision is None
+    if layer_default:
+        args.precision = gnn_layers.DEFAULT_PRECISION
+    resolved = gnn_layers.resolve_precision(args.precision, Fin)
+    prec_code = gnn_layers._PRECISIONS[resolved]
     t0 = time.time()
     cols, vals, lmax = build_laplacian_masked(nside, device) if args.config in MASKED else build_laplacian(nside, device)
     M, W_ell = cols.shape
@@ -231,14 +249,14 @@ def main():
             with torch.no_grad():  # inference forward: bias/activation fused in the kernel epilogue
                 return layer(x)
         fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-        kernel_name = fused_kernel_name(layer._get_plan(), K) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
+        kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
     else:
         from deepsphere import sharding
 
         # the ELL as a row producer: the rank reads its own rows and halo only, and learns its send lists from the
         # set-up gather of every rank's requests (sharding.ShardLayout)
         shard = sharding.ShardedChebyshev(lambda ids: (cols[ids], vals[ids]), None, K, Fout=Fout, rank=rank, world=world,
-                                          device=device, precision=args.precision, algo=args.algo, kernel=w_np, M=M)
+                                          device=device, precision=resolved, algo=args.algo, kernel=w_np, M=M)
         gen = torch.Generator(device=device).manual_seed(11 + rank)
         # this rank's rows live in the extended buffer the kernel reads (own rows, then halo rows): a producer
         # layer would write them there; no per-step copy
@@ -246,7 +264,7 @@ def main():
         x.normal_(generator=gen)
         run = lambda: shard(x)  # noqa: E731
         fused = shard.plan.fused_ok(Fin, Fout, K) and args.algo != "unfused"
-        kernel_name = (fused_kernel_name(shard.plan, K) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \
+        kernel_name = (fused_kernel_name(shard.plan, K, Fin, Fout, prec_code) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \
             " + rows_pack_kernel + " + \
             ("RCCL send/recv" if args.backend == "nccl" else "gloo send/recv (host-staged)") + " of the (K-1)-ring halo"
     setup_s = time.time() - t0
@@ -303,7 +321,7 @@ def main():
                 with torch.no_grad():
                     return layer(xr)
             fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-            kernel_name = fused_kernel_name(layer._get_plan(), K) if fused else kernel_name
+            kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code) if fused else kernel_name
     # Warm up exactly as the timed loop runs: the previous output stays referenced while the next forward allocates its
     # own, so BOTH output blocks are in the caching allocator before the clock starts (a first-ever hipMalloc of a second
     # 12.9 GB block inside the timed region costs one forward 350 ms on a box whose memory has not been touched yet).
@@ -355,7 +373,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath))
-                key = f"{args.config}:{args.precision}:{'fused' if fused else 'unfused'}:{world}"
+                key = f"{args.config}:{resolved}:{'fused' if fused else 'unfused'}:{world}"
                 traffic = rec.get(key, {}).get("hbm_bytes_per_forward")
             except Exception:
                 traffic = None
@@ -372,7 +390,8 @@ def main():
             "vs_baseline": None,
             "dtype": ({"fp32": "f32 (recurrence and contraction exact f32: v_mfma_f32_32x32x2_f32",
                        "bf16x6": "f32 (recurrence f32; contraction fp32-equivalent: 6-term exact split on the bf16 MFMA with f32 accumulate",
-                       "bf16x3": "f32 (recurrence f32; contraction 3-pass split-bf16 MFMA with f32 accumulate"}[args.precision]
+                       "bf16x3": "f32 (recurrence f32; contraction 3-pass split-bf16 MFMA with f32 accumulate"}[resolved]
+                      + (f"; precision '{resolved}' = the layer default for {Fin} input channels" if layer_default else f"; --precision {args.precision}")
                       + (f"; {err_note})" if err_note else ")")),
             "data": "synthetic",
             "config": {
@@ -394,38 +413,36 @@ def main():
                 "frac_of_measured_copy_6290": round(achieved / 6290.0, 4),
                 "median_forward_ms_hip_events": round(float(np.median(per_fwd_ms)), 4),
                 "traffic": traffic,
-                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of tools/measure_round2.sh; not re-measured in this run)" if traffic else None,
+                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of tools/measure_round3.sh; not re-measured in this run)" if traffic else None,
                 "algorithmic_bytes": b_alg,
                 "avg_forward_ms_hip_events": round(dev_ms, 4),
                 "min_max_forward_ms_hip_events": [round(float(np.min(per_fwd_ms)), 4), round(float(np.max(per_fwd_ms)), 4)],
             },
         }
         if world == 1:
-            # the same forward with the two fp32-accurate contractions, for the record: exact-fp32 MFMA (bitwise an fp32 fma
-            # chain) and the six-term bf16 split (fp32-equivalent, the layer's default); both against the fp32-MFMA roofline
+            # the same forward in the other contraction arithmetics, for the record (HIP events over `steps` forwards each).
+            # Each leg's roofline is the largest of its lower bounds: algorithmic bytes at 8 TB/s, and the dense flops at the
+            # peak of the pipe the arithmetic really runs on -- fp32 MFMA 157.3 TF/s; bf16 MFMA 2500 TF/s, counted three / six
+            # times for the three- / six-term split.
             f_d = 2.0 * N * M * K * Fin * Fout  # flops of the dense contraction
-            for key, prec_name, note in (
-                    ("fp32_exact", "fp32", "contraction on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain)"),
-                    ("fp32_split", "bf16x6", "the layer's default precision: fp32-equivalent six-term split on v_mfma_f32_32x32x16_bf16 "
-                                             "(operands split exactly into 8 + 8 + 8 mantissa bits, products down to 2^-16 kept)")):
-                if args.precision == prec_name:
+            t_hbm = b_alg / (HBM_PEAK_GBS * 1e9) * 1e3
+            legs = {"fp32": ("fp32_exact", "contraction on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain)", "mfma_f32", f_d / 157.3e12 * 1e3),
+                    "bf16x6": ("fp32_split", "fp32-equivalent six-term split on v_mfma_f32_32x32x16_bf16 (operands split exactly into "
+                                             "8 + 8 + 8 mantissa bits, products down to 2^-16 kept)", "mfma_bf16 x6", 6 * f_d / 2500e12 * 1e3),
+                    "bf16x3": ("bf16_split3", "three-term split on v_mfma_f32_32x32x16_bf16", "mfma_bf16 x3", 3 * f_d / 2500e12 * 1e3)}
+            out["roofline"]["bounds_ms"] = {"hbm": round(t_hbm, 3), legs[resolved][2]: round(legs[resolved][3], 3)}
+            for prec_name, (key, note, pipe, t_pipe) in legs.items():
+                if resolved == prec_name:
                     continue
                 layer.precision = prec_name
-                for _ in range(3):
-                    run()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(5):
-                    run()  # (output dropped at once: the loop reuses one block, no allocation inside the timing)
-                torch.cuda.synchronize()
-                msq = (time.perf_counter() - t1) / 5 * 1e3
+                msq = timed_ms(run, max(args.steps, 20))
                 yq = run()  # for the error measurement below
-                tfq = f_d / (msq * 1e-3) / 1e12
+                bound = max(t_hbm, t_pipe)
                 out[key] = {"ms_per_step": round(msq, 4), "value": round(N * M * Fout / msq / 1e3, 2), "note": note,
                             "measured_error": measured_error_of(yq),
-                            "roofline": {"bound": "mfma_f32", "achieved": round(tfq, 2), "peak": 157.3, "unit": "TFLOP/s",
-                                         "frac": round(tfq / 157.3, 4), "flops": f_d,
-                                         "hbm_frac": round(b_alg / (msq * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+                            "roofline": {"bound": "hbm" if t_hbm >= t_pipe else pipe, "bound_ms": round(bound, 3),
+                                         "frac": round(bound / msq, 4), "hbm_ms": round(t_hbm, 3), "pipe_ms": round(t_pipe, 3),
+                                         "flops": f_d, "hbm_frac": round(b_alg / (msq * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
                 del yq
             layer.precision = args.precision
         if world == 1:
@@ -434,14 +451,7 @@ def main():
             layer.use_bias = True
             layer.bias = torch.nn.Parameter(torch.randn(1, 1, Fout, device=device))
             layer.activation, layer._act_code = gnn_layers._resolve_activation("relu")
-            for _ in range(3):  # (also touches whichever cached output block the allocator hands out next: the first write
-                run()           #  to a block that has never been written costs tens of milliseconds)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                run()
-            torch.cuda.synchronize()
-            out["bias_relu"] = {"ms_per_step": round((time.perf_counter() - t1) / 5 * 1e3, 4)}
+            out["bias_relu"] = {"ms_per_step": round(timed_ms(run, max(args.steps, 20)), 4)}
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(K, Fin, Fout, device, args.cpu_budget)
         print(json.dumps(out), flush=True)

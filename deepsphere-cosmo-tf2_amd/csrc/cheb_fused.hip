@@ -132,6 +132,11 @@ void fused_plan_destroy(FusedPlan* fp) {
   delete fp;
 }
 
+bool fused_host_released(FusedPlan* fp) {
+  std::lock_guard<std::mutex> lock(fp->mu);
+  return fp->host_released;
+}
+
 // The tile tables depend on which rows are outputs (dsph_plan_set_levels): drop the cached ones.
 void fused_plan_invalidate(FusedPlan* fp) {
   if (!fp) return;
@@ -672,6 +677,19 @@ bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int6
   return true;
 }
 
+// one rule for "does the strip kernel take this forward" (launch_fused_common and dsph_plan_strip_tiles)
+static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K, int32_t precision) {
+  return ft.n_pairs > 0 && precision == DSPH_PREC_BF16X3 && strip_shape_ok(Fin, Fout, K) &&
+         plan->n_cols * (int64_t)std::max(Fin, Fout) * 4 < (1ll << 32);
+}
+
+int64_t fused_strip_tiles(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K, int32_t precision) {
+  if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX || Fin != pad4(Fin)) return 0;
+  const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
+  if (!ft.ok || Fout % 64 != 0) return 0;  // (wider layers: one launch per 64-column block, each through the strips)
+  return strips_apply(plan, ft, Fin, 64, K, precision) ? ft.n_strip_tiles : 0;
+}
+
 // two fragment layouts: the BFS-tile kernel's and, behind it, the structured-tile kernel's
 size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t) {
   const int32_t Fp = pad4(Fin);
@@ -754,10 +772,8 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
     const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
     defer_act = ft.ok && ft.n_r + ft.n_t > 0;
   }
-  if (defer_act && part != 0) {
-    set_error("cheb_fused: interior / boundary launches support the activations NONE and RELU only");
-    return DSPH_E_UNSUPPORTED;
-  }
+  // (two-part launches: both parts write the pre-activation, the pass runs once over all output rows behind the BOUNDARY
+  // part -- the pair is always INTERIOR first, BOUNDARY second, dsphere.h)
   // Fin not a multiple of four: a zero-padded copy of x behind the weight fragments in the workspace (with a two-part
   // launch both parts copy: the halo rows arrive between them)
   const int32_t Fin_w = Fin;
@@ -785,7 +801,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
                                        Fin_w);
     if (rc != DSPH_OK) return rc;
   }
-  if (defer_act) {
+  if (defer_act && part != 1) {
     const int64_t orows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
     return launch_struct_act(y, N * orows, Fout, Fout, act, stream);
   }
@@ -902,8 +918,8 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     sl.cheb = beta_rest != 0.f;
     sl.prep_weights = true;  // the first of the two launches packs the fragments
     // rectangles of interior class-R tiles: the strip kernel, when it has this shape; the class-R list shrinks to the rest
-    const bool strips = ft.n_pairs > 0 && precision == DSPH_PREC_BF16X3 && strip_shape_ok(Fin, Fout, K) && Fin_w == Fin &&
-                        (reinterpret_cast<uintptr_t>(y) & 15) == 0 && ld % 4 == 0 && plan->n_cols * (int64_t)ld * 4 < (1ll << 32);
+    const bool strips = strips_apply(plan, ft, Fin, Fout, K, precision) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                        ld % 4 == 0 && plan->n_cols * (int64_t)ld * 4 < (1ll << 32);
     if (strips && part != 2 && !dbg_only('b')) {
       StripLaunch st;
       st.x = x; st.w = w; st.bias = bias; st.y = y;

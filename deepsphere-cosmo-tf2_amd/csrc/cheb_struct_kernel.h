@@ -80,7 +80,8 @@ constexpr int ST_WSLICE_BYTES = 20480;          // weight fragments of one slice
 constexpr int ST_LDS_W = 3 * ST_PLANE_BYTES;    // 119,808
 constexpr int ST_LDS_BIAS = ST_LDS_W + 2 * ST_WSLICE_BYTES;  // 160,768
 constexpr int ST_LDS_ROWS = ST_LDS_BIAS + 256;               // byte offset, inside a map, of the x row of every plane cell
-constexpr int ST_LDS_TOTAL = ST_LDS_ROWS + ST_CELLS * 4;     // 163,520 of 163,840
+constexpr int ST_LDS_TOTAL = ST_LDS_ROWS + 640 * 4;          // 163,584 of 163,840 (640 entries: the last DMA piece index a
+                                                              // contraction wave forms, 39, reads row 639 -- unused, but inside the array)
 constexpr int ST_DMA_PIECES = ST_CELLS / 16;    // 39 wave-instructions of 1 KiB fill a plane
 constexpr int ST_WBLK3 = 3072;                  // DSPH_PREC_BF16X6: a weight block is 3 KiB (hi | mid | lo)
 constexpr int ST_TABV = 12;                     // floats per cell of a class-T tile's value table (9 used: 3 x 16 B)
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   }
   // LDS-DMA: wave c issues x pieces c, c+4, ...; lane l fills slot l & 3 of cell 16 piece + (l >> 2) of the plane
   constexpr int GX = StPieces<PREC>::GX, GW = StPieces<PREC>::GW;
-  constexpr int NPX = (ST_DMA_PIECES - GX + ST_CONTRACT_WAVES - 1) / ST_CONTRACT_WAVES;  // 6 (split bf16), 0 (fp32)
+  constexpr int NPX = (ST_DMA_PIECES - GX + ST_CONTRACT_WAVES - 1) / ST_CONTRACT_WAVES;  // pieces per contraction wave: 8 with GX = 8 (the last of wave 3 does not exist: its valid bit is clear)
   unsigned dinfo = 0;  // per piece s: bits 3s..3s+1 logical slot, bit 3s+2 valid
 #pragma unroll
   for (int s = 0; s < (NPX > 0 ? NPX : 1) && s < NPX; ++s) dinfo |= st_piece_info(GX + cw + ST_CONTRACT_WAVES * s, lane, D) << (3 * s);

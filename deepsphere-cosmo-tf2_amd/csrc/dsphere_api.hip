@@ -113,6 +113,10 @@ int dsph_plan_set_levels(dsph_plan* p, int32_t n_levels, const int64_t* rows_at_
     }
     prev = rows_at_level[i];
   }
+  if (p->fused && fused_host_released(p->fused)) {  // the tile tables cannot be rebuilt for the new output rows
+    set_error("set_levels: the plan's host copy of L~ was released (DSPH_PREPARE_RELEASE_HOST); set the levels before preparing");
+    return DSPH_E_UNSUPPORTED;
+  }
   p->levels.assign(rows_at_level, rows_at_level + n_levels);
   if (p->fused) {
     DeviceGuard guard(p->device);
@@ -148,6 +152,12 @@ int dsph_plan_tile_counts(const dsph_plan* p, int32_t K, int64_t* n_struct, int6
   if (!p || !n_struct || !n_bfs) { set_error("plan_tile_counts: NULL argument"); return DSPH_E_BADARG; }
   *n_struct = *n_bfs = 0;
   if (!fused_tile_counts(p, K, n_struct, n_bfs)) { set_error("plan_tile_counts: the fused kernels cannot run this plan with K = %d", K); return DSPH_E_UNSUPPORTED; }
+  return DSPH_OK;
+}
+
+int dsph_plan_strip_tiles(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t* n_tiles) {
+  if (!p || !n_tiles) { set_error("plan_strip_tiles: NULL argument"); return DSPH_E_BADARG; }
+  *n_tiles = fused_supported(p, Fin, Fout, K) ? fused_strip_tiles(p, Fin, Fout, K, precision) : 0;
   return DSPH_OK;
 }
 

@@ -73,9 +73,11 @@ int launch_rows_pack(const float* src, int64_t src_rows, const int32_t* idx, int
 FusedPlan* fused_plan_build(const dsph_plan* plan, const int32_t* h_cols, const float* h_vals);
 void fused_plan_destroy(FusedPlan* fp);
 void fused_plan_invalidate(FusedPlan* fp);
+bool fused_host_released(FusedPlan* fp);
 int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
+int64_t fused_strip_tiles(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K, int32_t precision);
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,

@@ -37,7 +37,7 @@ _ACT_BY_NAME = {
     "softmax": (lambda t: torch.softmax(t, dim=-1), None),
 }
 
-_PRECISIONS = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}
+_PRECISIONS = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6, "auto": None}
 _ALGOS = {"auto": _native.ALGO_AUTO, "unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}
 
 
@@ -58,14 +58,27 @@ def _resolve_activation(activation):
     raise ValueError(f"Could not find activation <{activation}> in tf.keras.activations...")
 
 
-# The contraction arithmetic a layer uses when the caller does not say: "bf16x6", the fp32-EQUIVALENT six-term split on the
-# bf16 matrix pipe (both operands split exactly into 8 + 8 + 8 mantissa bits, the six products down to 2^-16 kept, fp32
-# accumulation): 2-7e-7 of max|y| from the float64 oracle at every tested shape -- the figures of "fp32", the bitwise
-# fp32-fma-chain MFMA, which costs 1.2 x the time at the headline shape and stays available.  The 3-term split ("bf16x3",
-# 1.3 x faster again, what bench.py times) measures 2-6e-6 wherever the inner dimension K*Fin is large, but has no
-# worst-case guarantee at the 1e-5 of SURVEY 8c: a product can be off by 3 * 2^-18 = 1.1e-5, and with five terms per output
-# (Fin = 1, K = 5: BASELINE configs[0] on the whole map) 1.02e-5 was measured -- so it stays opt-in.
-DEFAULT_PRECISION = "bf16x6"
+# The contraction arithmetic a layer uses when the caller does not say: "auto" =
+#   * "bf16x3" for layers with 16 or more input channels: both operands of the dense product split hi + lo into bf16, the
+#     three products hi.hi + hi.lo + lo.hi on the bf16 matrix pipe, fp32 accumulation.  A product is off by at most
+#     3 * 2^-18 = 1.15e-5 of its size (so |error| <= 1.15e-5 * sum |x||w| in the worst case -- not a bound on max|y|);
+#     measured 2-6e-6 of max|y| against the float64 oracle on every test shape with 16 or more input channels, and held to
+#     2e-5 there (TOL_BF16X3 of the tests; SURVEY 8c allows the split-bf16 contraction 1e-4).  It is the arithmetic of the
+#     strip kernel (csrc/cheb_strip_kernel.h) and what bench.py times: product and benchmark are the same code path.
+#     (For scale: the reference's own matmul on the GPUs it targets is TF32 by default, 2^-11 per product.)
+#   * "bf16x6" for layers with fewer input channels (the first layer of a network: Fin = 1): the fp32-EQUIVALENT six-term
+#     split (both operands split exactly into 8 + 8 + 8 mantissa bits, the six products down to 2^-16 kept): 2-7e-7 of
+#     max|y|.  With five products per output nothing averages out -- the three-term split measured 1.02e-5 on BASELINE
+#     configs[0] -- and such layers cost next to nothing anyway.
+# "fp32" (the bitwise fp32-fma-chain MFMA), "bf16x6" and "bf16x3" can be asked for by name.
+DEFAULT_PRECISION = "auto"
+
+
+def resolve_precision(precision, Fin):
+    """The arithmetic a layer with ``Fin`` input channels runs for ``precision`` ("auto" | "fp32" | "bf16x3" | "bf16x6")."""
+    if precision == "auto":
+        return "bf16x3" if Fin >= 16 else "bf16x6"
+    return precision
 
 
 class _ChebConvFunction(torch.autograd.Function):
@@ -90,7 +103,7 @@ class _ChebConvFunction(torch.autograd.Function):
         plan = layer._get_plan()
         y, layer._workspace = _native.cheb_forward(
             plan, x, kernel.detach(), None, layer.K, act=_native.ACT_NONE,
-            precision=_PRECISIONS[layer.precision], algo=_ALGOS[layer.algo], workspace=layer._workspace,
+            precision=layer._prec_code(), algo=_ALGOS[layer.algo], workspace=layer._workspace,
             basis=layer._basis)
         ctx.layer = layer
         ctx.save_for_backward(x, kernel)
@@ -109,13 +122,13 @@ class _ChebConvFunction(torch.autograd.Function):
             plan_t = layer._get_plan(transposed=True)
             kernel_t = kernel.detach().reshape(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()
             dx, layer._workspace_t = _native.cheb_forward(
-                plan_t, dy, kernel_t, None, K, act=_native.ACT_NONE, precision=_PRECISIONS[layer.precision],
+                plan_t, dy, kernel_t, None, K, act=_native.ACT_NONE, precision=layer._prec_code(),
                 algo=_ALGOS[layer.algo], workspace=layer._workspace_t, basis=layer._basis)
         if ctx.needs_input_grad[1]:
             plan = layer._get_plan()
             dk, layer._workspace_w = _native.cheb_backward_weights(
                 plan, x, dy, K, basis=layer._basis, algo=_ALGOS[layer.algo], workspace=getattr(layer, "_workspace_w", None),
-                precision=_PRECISIONS[layer.precision])
+                precision=layer._prec_code())
         return dx, dk, None
 
 
@@ -159,10 +172,10 @@ class Chebyshev(torch.nn.Module):
             TensorFlow-GPU's sparse-matmul size limit, the HIP kernel has none
         :param kwargs: the reference forwards these to ``add_weight`` (regularizer, ...); stored in
             ``self.kwargs``.  Three keys are consumed here: ``device`` (torch device of the layer,
-            default: current CUDA device), ``precision`` ("bf16x6", the default: fp32-equivalent six-term bf16 split, 2-7e-7 of max|y|
-            from the float64 oracle | "fp32": exact-fp32 MFMA, bitwise an fp32 fma chain, same accuracy, 1.2 x the time |
-            "bf16x3": three-term split, 2-6e-6 at shapes with 16 or more input channels, 1.3 x faster; the recurrence is
-            fp32 in all three) and ``algo`` ("auto" | "unfused" | "fused").
+            default: current CUDA device), ``precision`` ("auto", the default: "bf16x3" -- the three-term bf16 split, 2-6e-6 of
+            max|y| from the float64 oracle -- for 16 or more input channels, else "bf16x6" | "bf16x6": fp32-equivalent six-term
+            split, 2-7e-7 | "fp32": exact-fp32 MFMA, bitwise an fp32 fma chain; the recurrence is fp32 in all of them; see
+            DEFAULT_PRECISION) and ``algo`` ("auto" | "unfused" | "fused").
         """
         super().__init__()
         self.L = L
@@ -264,6 +277,10 @@ class Chebyshev(torch.nn.Module):
                 self._plan_t = _native.LaplacianPlan(tc, tv, device=self._device.index)
         return self._plan_t
 
+    def _prec_code(self):
+        """C-ABI code of the contraction arithmetic of this (built) layer: ``precision="auto"`` resolved with its Fin."""
+        return _PRECISIONS[resolve_precision(self.precision, self._Fin)]
+
     # -- forward --------------------------------------------------------------------------------
     def forward(self, input_tensor, training=False):
         """
@@ -315,7 +332,7 @@ class Chebyshev(torch.nn.Module):
         act_code = self._act_code if (fuse_epilogue and self._act_code is not None) else _native.ACT_NONE
         y, self._workspace = _native.cheb_forward(
             plan, x, self.kernel.detach(), bias if fuse_epilogue else None, self.K, act=act_code,
-            precision=_PRECISIONS[self.precision], algo=_ALGOS[self.algo], workspace=self._workspace,
+            precision=self._prec_code(), algo=_ALGOS[self.algo], workspace=self._workspace,
             basis=self._basis,
         )
         if self.use_bn:  # BN -> bias -> activation, the reference's order (gnn_layers.py:152-159)

@@ -106,6 +106,18 @@ class HealpyGCNN(torch.nn.Sequential):
         return (indices[:, None] * per + np.arange(per, dtype=np.int64)[None, :]).reshape(-1)
 
     def forward(self, input_tensor, training=False):
+        """``training`` defaults to False like the reference's ``call`` (Keras passes True by itself inside ``fit``; torch has
+        no counterpart).  A network in ``model.train()`` mode that holds batch-norm layers and is called without the argument
+        would silently normalise with -- and never update -- the moving statistics: that combination warns once; write
+        ``model(x, training=True)`` in a training loop (``training=None``: follow ``self.training``)."""
+        if training is False and self.training and not getattr(self, "_warned_training", False):
+            if any(getattr(layer, "use_bn", False) for layer in self):
+                import warnings
+
+                warnings.warn("HealpyGCNN is in train() mode but forward() was called with the default training=False: its "
+                              "batch-norm layers use (and do not update) the moving statistics.  Pass training=True "
+                              "(or training=None to follow module.training).", stacklevel=2)
+                self._warned_training = True
         x = input_tensor
         for layer in self:
             if isinstance(layer, (gnn.Chebyshev, gnn.GCNN_ResidualLayer)):

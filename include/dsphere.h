@@ -100,7 +100,10 @@ int dsph_plan_set_levels(dsph_plan* plan, int32_t n_levels, const int64_t* rows_
  *          DSPH_PREPARE_RELEASE_HOST  afterwards drop the plan's host copy of the ELL arrays (kept by
  *                                     dsph_plan_create to build tables for further K); preparing another K
  *                                     later then fails with DSPH_E_UNSUPPORTED and forwards with that K take
- *                                     the unfused path under DSPH_ALGO_AUTO
+ *                                     the unfused path under DSPH_ALGO_AUTO; dsph_plan_set_levels then returns
+ *                                     DSPH_E_UNSUPPORTED (it would have to rebuild the tables), and the tables of
+ *                                     dsph_cheb_planes / dsph_cheb_backward_weights exist only if DSPH_PREPARE_BACKWARD
+ *                                     was passed in the same call
  * Returns DSPH_OK also when the fused kernels cannot run the plan (dsph_plan_fused_ok says which). */
 #define DSPH_PREPARE_BACKWARD 1
 #define DSPH_PREPARE_RELEASE_HOST 2
@@ -120,6 +123,15 @@ int dsph_plan_fused_ok(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t
  * rows of a sharded plan) and *n_bfs tiles handled through breadth-first ring tables (csrc/cheb_fused_kernel.h).
  * DSPH_E_UNSUPPORTED when neither kernel can run the plan (the unfused path then serves dsph_cheb_forward). */
 int dsph_plan_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
+
+/* How many of those structured tiles a forward of this shape hands to the strip kernel instead (csrc/cheb_strip_kernel.h:
+ * rectangles of at least 3 x 4 tiles whose regions are plain Z-order squares, streamed row by row in 32-column strips with
+ * the recurrence in registers -- Clenshaw's backward form, fed by the MFMA).  0 when the strip kernel does not take the shape
+ * (it implements K = 5, Fin = Fout = 64 per 64-column block, DSPH_PREC_BF16X3) or the plan holds no such rectangle; the
+ * other tiles are served as dsph_plan_tile_counts says.  Same summation per output whichever kernel writes it?  No: the two
+ * forms round differently (both within the tolerance of their precision), so outputs of tiles that change hands between
+ * two plans of the same graph agree to rounding, not bit for bit. */
+int dsph_plan_strip_tiles(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t* n_tiles);
 
 /* Bytes of scratch dsph_cheb_forward needs for this call shape (0 is possible). */
 size_t dsph_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout,
@@ -152,7 +164,10 @@ int dsph_poly_forward(const dsph_plan* plan, const float* x, const float* w, con
  * DSPH_PART_INTERIOR = the 256-row tiles whose whole (K-1)-hop region lies inside the plan's output rows, i.e. on
  * a sharded plan the tiles that read no halo row of another rank; DSPH_PART_BOUNDARY = the others.  Launching
  * INTERIOR while the halo exchange is in flight and BOUNDARY after it hides the exchange behind the interior
- * (deepsphere/sharding.py).  INTERIOR + BOUNDARY write exactly the rows DSPH_PART_ALL writes, with the same bits. */
+ * (deepsphere/sharding.py).  INTERIOR + BOUNDARY write exactly the rows DSPH_PART_ALL writes, with the same bits.
+ * The two calls are a pair, INTERIOR first: with an activation other than NONE / RELU the kernels write the pre-activation
+ * in both parts and the BOUNDARY call finishes with one elementwise pass over all output rows (so y is final only after
+ * the BOUNDARY call, and calling BOUNDARY without its INTERIOR partner applies the activation to rows it did not write). */
 #define DSPH_PART_ALL 0
 #define DSPH_PART_INTERIOR 1
 #define DSPH_PART_BOUNDARY 2
