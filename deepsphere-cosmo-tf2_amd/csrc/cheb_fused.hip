@@ -25,6 +25,7 @@
 // (order, slice) pairs in MFMA operand order.
 // Registers: each lane owns one (or two) region rows for the whole tile: their ELL values and
 // pre-swizzled LDS addresses stay in VGPRs across all slices and all maps of the batch.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -274,63 +275,86 @@ static bool embed_tile(const dsph_plan* plan, const int32_t* cols, const float* 
   return true;
 }
 
-// Strip kernel: which class-R tiles it takes, and in what pieces.  The interior class-R tiles are covered greedily by
-// rectangles (in the virtual Morton plane of the tile indices: tile t sits at (compress(t), compress(t >> 1))); a
-// rectangle of at least 3 x 4 tiles is cut into 32-column strips with 24 output columns each, two strips per
-// workgroup item, and into row segments sized so that the items fill the CUs evenly.  Tiles of smaller rectangles
-// stay with the tile kernels (`rest`).
+// Strip kernel: which class-R tiles it takes, and in what pieces.  The interior class-R tiles are covered by rectangles (in
+// the virtual Morton plane of the tile indices: tile t sits at (compress(t), compress(t >> 1))) of 3 to 5 tile columns and at
+// least 4 tile rows; a rectangle is cut into 32-column strips with 24 output columns each, two strips per workgroup item,
+// and into row segments sized so that the items fill the CUs evenly.  The other tiles stay with the tile kernels (`rest`).
 static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_cu, std::vector<StripPair>& pairs,
                          std::vector<int32_t>& rest, int64_t* n_taken) {
   pairs.clear();
   rest.clear();
   *n_taken = 0;
   struct Rect { int tx, ty, wt, ht; };
-  std::vector<Rect> rects;
-  std::vector<uint64_t> keys(r_interior.size());
+  // columns of the tile plane and their vertical runs of class-R tiles
+  std::vector<uint64_t> keys(r_interior.size());  // (tx, ty)
   for (size_t i = 0; i < r_interior.size(); ++i) {
     const unsigned t = (unsigned)r_interior[i];
-    keys[i] = ((uint64_t)st_compress(t >> 1) << 32) | st_compress(t);
+    keys[i] = ((uint64_t)st_compress(t) << 32) | st_compress(t >> 1);
   }
   std::sort(keys.begin(), keys.end());
-  std::vector<char> used(keys.size(), 0);
-  auto find = [&](unsigned tx, unsigned ty) -> long {
-    const uint64_t k = ((uint64_t)ty << 32) | tx;
-    auto it = std::lower_bound(keys.begin(), keys.end(), k);
-    return (it != keys.end() && *it == k) ? (long)(it - keys.begin()) : -1;
-  };
-  for (size_t i = 0; i < keys.size(); ++i) {
-    if (used[i]) continue;
-    const unsigned tx = (unsigned)(keys[i] & 0xffffffffu), ty = (unsigned)(keys[i] >> 32);
-    int wt = 1;
-    for (;; ++wt) {
-      const long j = find(tx + wt, ty);
-      if (j < 0 || used[j]) break;
-    }
-    int ht = 1;
-    for (;; ++ht) {
-      bool all = true;
-      for (int u = 0; u < wt && all; ++u) {
-        const long j = find(tx + u, ty + ht);
-        all = j >= 0 && !used[j];
-      }
-      if (!all) break;
-    }
-    for (int v = 0; v < ht; ++v)
-      for (int u = 0; u < wt; ++u) used[find(tx + u, ty + v)] = 1;
-    rects.push_back({(int)tx, (int)ty, wt, ht});
+  struct Run { int tx, y0, y1; bool used; };
+  std::vector<Run> runs;
+  for (size_t i = 0; i < keys.size();) {
+    const int tx = (int)(keys[i] >> 32), y0 = (int)(keys[i] & 0xffffffffu);
+    size_t j = i + 1;
+    while (j < keys.size() && (int)(keys[j] >> 32) == tx && (int)(keys[j] & 0xffffffffu) == y0 + (int)(j - i)) ++j;
+    runs.push_back({tx, y0, y0 + (int)(j - i), false});
+    i = j;
   }
-  // rectangles worth streaming: at least one full strip pair wide, and tall enough to pay for the 2 D + 1 rows of run-in
+  // Groups of 3 (at the end of a stretch: 4 or 5) adjacent columns whose runs share at least 4 rows: one rectangle each, of the
+  // shared rows.  (Three tile columns = 48 pixels = one pair of strips; tall rather than wide, the strips run along y.  On a
+  // full base pixel every column has the same run and nothing is left over; on a mask the rows a group does not share, and
+  // stretches of fewer than 3 columns, stay with the tile kernels.)
+  auto overlap = [](int a0, int a1, int b0, int b1, int* o0, int* o1) { *o0 = std::max(a0, b0); *o1 = std::min(a1, b1); return *o1 - *o0; };
+  const char* mr = getenv("DSPH_STRIP_MINROWS");  // (tuning: least height of a rectangle, in tiles)
+  const int min_rows = mr ? std::max(4, atoi(mr)) : 4;
   std::vector<Rect> take;
-  for (const Rect& r : rects) {
-    if (r.wt >= 3 && r.ht >= 4) {
-      take.push_back(r);
-      *n_taken += (int64_t)r.wt * r.ht;
-    } else {
-      for (int v = 0; v < r.ht; ++v)
-        for (int u = 0; u < r.wt; ++u) rest.push_back((int32_t)st_morton((unsigned)(r.tx + u), (unsigned)(r.ty + v)));
+  for (size_t i = 0; i < runs.size(); ++i) {
+    if (runs[i].used) continue;
+    // how many adjacent columns continue this run with at least 4 shared rows (at most 6 looked at)
+    std::vector<size_t> chain{i};
+    int y0 = runs[i].y0, y1 = runs[i].y1;
+    while (chain.size() < 6) {
+      const int want = runs[chain.back()].tx + 1;
+      size_t best = runs.size();
+      int by0 = 0, by1 = 0;
+      for (size_t j = chain.back() + 1; j < runs.size() && runs[j].tx <= want; ++j) {
+        int o0, o1;
+        if (runs[j].tx == want && !runs[j].used && overlap(y0, y1, runs[j].y0, runs[j].y1, &o0, &o1) >= min_rows &&
+            (best == runs.size() || o1 - o0 > by1 - by0)) { best = j; by0 = o0; by1 = o1; }
+      }
+      if (best == runs.size()) break;
+      if (chain.size() < 5) { y0 = by0; y1 = by1; }  // (the sixth only says "the stretch goes on")
+      chain.push_back(best);
+    }
+    const int avail = (int)chain.size();
+    if (avail < 3 || y1 - y0 < min_rows) continue;  // stays with the tile kernels
+    const int w = avail >= 6 ? 3 : std::min(avail, 5);
+    // the shared rows of the w columns actually taken
+    y0 = runs[chain[0]].y0; y1 = runs[chain[0]].y1;
+    for (int c = 1; c < w; ++c) { int o0, o1; overlap(y0, y1, runs[chain[c]].y0, runs[chain[c]].y1, &o0, &o1); y0 = o0; y1 = o1; }
+    if (y1 - y0 < min_rows) continue;
+    take.push_back({runs[chain[0]].tx, y0, w, y1 - y0});
+    *n_taken += (int64_t)w * (y1 - y0);
+    for (int c = 0; c < w; ++c) {
+      Run& r = runs[chain[c]];
+      // what the rectangle leaves of the run: above / below stay as (used) leftovers for the tile kernels
+      for (int y = r.y0; y < r.y1; ++y)
+        if (y < y0 || y >= y1) rest.push_back((int32_t)st_morton((unsigned)r.tx, (unsigned)y));
+      r.used = true;
     }
   }
+  for (const Run& r : runs)
+    if (!r.used)
+      for (int y = r.y0; y < r.y1; ++y) rest.push_back((int32_t)st_morton((unsigned)r.tx, (unsigned)y));
   std::sort(rest.begin(), rest.end());
+  if (getenv("DSPH_STRIP_DEBUG")) {
+    long a3 = 0, a45 = 0;
+    int hmin = 1 << 30, hmax = 0;
+    for (const Rect& r : take) { (r.wt == 3 ? a3 : a45) += (long)r.wt * r.ht; hmin = std::min(hmin, r.ht); hmax = std::max(hmax, r.ht); }
+    fprintf(stderr, "build_strips: %zu rectangles (3 wide: %ld tiles, 4-5 wide: %ld tiles, heights %d..%d), %zu tiles left over\n",
+            take.size(), a3, a45, take.empty() ? 0 : hmin, hmax, rest.size());
+  }
   if (take.empty()) return;
   // segment height: the one that minimises (items per CU, rounded up) x (rows per item + run-in)
   const int cand[] = {4096, 2048, 1024, 512, 384, 256, 192, 128, 96, 64};
@@ -346,6 +370,20 @@ static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_
     }
     const long cost = ((items + num_cu - 1) / num_cu) * (hmax + 2 * D + 1);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_h = h; }
+  }
+  // Worth it?  A strip step (48 output pixels of one row, one map) takes a workgroup ~3.0 us, a 256-pixel tile of one map takes
+  // the tile kernels ~18.7 us of a CU (both measured at the headline shape): in units of 0.1 us per map,
+  //   strips: (items per CU, rounded up) x (rows per item + run-in) x 30      tile kernels: tiles x 187 / CUs.
+  // Ragged masks (many short rectangles: run-in rows, a last strip of 8 or 16 columns, items of unequal height) lose that
+  // comparison and keep their tiles on the tile kernels.
+  if (getenv("DSPH_STRIP_FORCE") == nullptr && best_cost * 30 >= (long)(*n_taken) * 187 / num_cu) {
+    if (getenv("DSPH_STRIP_DEBUG")) fprintf(stderr, "build_strips: not taken (strip cost %ld >= tile cost %ld)\n", best_cost * 30, (long)(*n_taken) * 187 / num_cu);
+    for (const Rect& r : take)
+      for (int v = 0; v < r.ht; ++v)
+        for (int u = 0; u < r.wt; ++u) rest.push_back((int32_t)st_morton((unsigned)(r.tx + u), (unsigned)(r.ty + v)));
+    std::sort(rest.begin(), rest.end());
+    *n_taken = 0;
+    return;
   }
   for (const Rect& r : take) {
     const int X0 = 16 * r.tx, X1 = 16 * (r.tx + r.wt), Y0 = 16 * r.ty, Y1 = 16 * (r.ty + r.ht);

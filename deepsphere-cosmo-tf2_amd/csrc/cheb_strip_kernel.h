@@ -708,12 +708,17 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
   };
   // the MFMA chain of one level beside `NQ` quarters of stencil work: MFMA m is followed by the quarters that fall to
   // it; the fragments of inner block ib + 2 are requested once those of ib have been consumed (set: [lo | hi], ib & 1)
+#if SP_ABL & 512  // (timing only: the B fragments are not read from LDS)
+#define SP_FRLOAD(P) (wr[0][0][0])
+#else
+#define SP_FRLOAD(P) (*reinterpret_cast<const sp_bf16x8*>(P))
+#endif
 #define SP_CHAIN(ACC, FIRST_STMT, WLEV, FADDR, NQ, ...)                                                                \
   {                                                                                                                    \
     sp_bf16x8 fr[2][2];                                                                                                \
     _Pragma("unroll") for (int ib = 0; ib < 2; ++ib) {                                                                 \
-      fr[ib][0] = *reinterpret_cast<const sp_bf16x8*>(smem + (FADDR) + ib * 2 * SP_FRAG + SP_FRAG);                    \
-      fr[ib][1] = *reinterpret_cast<const sp_bf16x8*>(smem + (FADDR) + ib * 2 * SP_FRAG);                              \
+      fr[ib][0] = SP_FRLOAD(smem + (FADDR) + ib * 2 * SP_FRAG + SP_FRAG);                                              \
+      fr[ib][1] = SP_FRLOAD(smem + (FADDR) + ib * 2 * SP_FRAG);                                                        \
     }                                                                                                                  \
     _Pragma("unroll") for (int ib = 0; ib < NIB; ++ib) {                                                               \
       _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                  \
@@ -725,8 +730,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
         _Pragma("unroll") for (int qq = (m * (NQ)) / 12; qq < ((m + 1) * (NQ)) / 12; ++qq) { __VA_ARGS__; }            \
       }                                                                                                                \
       if (ib + 2 < NIB) {                                                                                              \
-        fr[ib & 1][0] = *reinterpret_cast<const sp_bf16x8*>(smem + (FADDR) + (ib + 2) * 2 * SP_FRAG + SP_FRAG);        \
-        fr[ib & 1][1] = *reinterpret_cast<const sp_bf16x8*>(smem + (FADDR) + (ib + 2) * 2 * SP_FRAG);                  \
+        fr[ib & 1][0] = SP_FRLOAD(smem + (FADDR) + (ib + 2) * 2 * SP_FRAG + SP_FRAG);                                  \
+        fr[ib & 1][1] = SP_FRLOAD(smem + (FADDR) + (ib + 2) * 2 * SP_FRAG);                                            \
       }                                                                                                                \
     }                                                                                                                  \
   }
@@ -1029,6 +1034,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
     }
   }
 #undef SP_CHAIN
+#undef SP_FRLOAD
 }
 
 }  // namespace dsph

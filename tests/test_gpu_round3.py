@@ -36,6 +36,24 @@ def _csr(cols, vals):
     return sparse.csr_matrix((vals.reshape(-1).astype(np.float64), cols.reshape(-1), np.arange(0, W * M + 1, W)), shape=(M, M))
 
 
+class _force_strips:
+    """Small maps do not pay for the strip kernel (fewer strip pairs than CUs: cheb_fused.hip weighs that when the tile tables
+    are built) -- DSPH_STRIP_FORCE, read at that moment, hands it every rectangle anyway, which is what these tests are about."""
+
+    def __enter__(self):
+        os.environ["DSPH_STRIP_FORCE"] = "1"
+
+    def __exit__(self, *exc):
+        del os.environ["DSPH_STRIP_FORCE"]
+
+
+def _strip_plan(cols, vals, K, Fin):
+    with _force_strips():
+        plan = _native.LaplacianPlan(cols, vals, device=0)
+        plan.prepare(K, Fin)
+    return plan
+
+
 def _plan_without_strips(cols, vals, K, Fin):
     """The same plan with the strip kernel switched off (DSPH_NO_STRIP is read when the tile tables are built)."""
     os.environ["DSPH_NO_STRIP"] = "1"
@@ -59,8 +77,7 @@ def test_strip_kernel_whole_map(nside, N, basis, act, use_bias):
     K, Fin, Fout = 5, 64, 64
     cols, vals = _grid_ell(nside)
     M = cols.shape[0]
-    plan = _native.LaplacianPlan(cols, vals, device=0)
-    plan.prepare(K, Fin)
+    plan = _strip_plan(cols, vals, K, Fin)
     n_struct, n_bfs = plan.tile_counts(K)
     n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3)
     nt = nside // 16
@@ -91,6 +108,14 @@ def test_strip_kernel_whole_map(nside, N, basis, act, use_bias):
     assert float((y - y0).abs().max()) / float(np.abs(ref).max()) < 2 * TOL
 
 
+def test_small_maps_keep_their_tiles_on_the_tile_kernels():
+    """The cost comparison of cheb_fused.hip: at nside 128 there are 24 strip pairs for 256 CUs -- the tile kernels keep the map."""
+    cols, vals = _grid_ell(128)
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    plan.prepare(5, 64)
+    assert plan.strip_tiles(64, 64, 5, _native.PREC_BF16X3) == 0
+
+
 def test_strip_kernel_through_the_layer_default():
     """The layer's default arithmetic ("auto") is the three-term split at 64 input channels: the layer API reaches the strip
     kernel with no keyword, and a 1-channel first layer resolves to the six-term split."""
@@ -104,7 +129,7 @@ def test_strip_kernel_through_the_layer_default():
     W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
     layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=Fout, device="cuda:0", activation="relu",
                                                    initializer=lambda t: t.copy_(torch.from_numpy(W)))
-    with torch.no_grad():
+    with _force_strips(), torch.no_grad():
         y = layer(_dev(x))
     assert layer._prec_code() == _native.PREC_BF16X3
     assert layer._get_plan().strip_tiles(Fin, Fout, K, layer._prec_code()) > 0
@@ -120,8 +145,7 @@ def test_strip_kernel_partial_sky():
     nside, K, Fin, Fout, N = 256, 5, 64, 64, 2
     cols, vals, _ = bench.build_laplacian_masked(nside, torch.device("cuda", 0))
     M = cols.shape[0]
-    plan = _native.LaplacianPlan(cols, vals, device=0)
-    plan.prepare(K, Fin)
+    plan = _strip_plan(cols, vals, K, Fin)
     n_struct, n_bfs = plan.tile_counts(K)
     n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3)
     print(f"cap at nside {nside}: {M} pixels, {n_strip} strip tiles of {n_struct} structured, {n_bfs} BFS")
@@ -141,8 +165,7 @@ def test_strip_kernel_wider_layer():
     nside, K, Fin, Fout, N = 128, 5, 64, 128, 1
     cols, vals = _grid_ell(nside)
     M = cols.shape[0]
-    plan = _native.LaplacianPlan(cols, vals, device=0)
-    plan.prepare(K, Fin)
+    plan = _strip_plan(cols, vals, K, Fin)
     assert plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3) > 0
     rng = np.random.default_rng(9)
     x = rng.standard_normal((N, M, Fin)).astype(np.float32)
