@@ -13,7 +13,10 @@ SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST
 i=0
 for P in "${SETS[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/tools/run_forward.py $cfg $prec fused 2 > $out/p$i.log 2>&1
+  # PMC_ONLY="3 4": just those passes (FETCH_SIZE and WRITE_SIZE)
+  if [ -n "$PMC_ONLY" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then continue; fi
+  echo "pass $i: $P"
+  timeout 400 rocprofv3 --pmc $P --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/tools/run_forward.py $cfg $prec fused 2 > $out/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
@@ -27,7 +30,7 @@ for i in range(1, 7):
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             n[(k, r["Counter_Name"])] += 1
     for k, d in acc.items():
-        if "cheb" not in k: continue
+        if "dsph" not in k and "elementwise" not in k: continue
         for c, v in sorted(d.items()):
             res.setdefault(k, {})[c] = v / max(1, n[(k, c)])
 for k, d in res.items():
