@@ -184,12 +184,14 @@ class ShardLayout:
         return out, row_ids, row_cols, row_vals
 
 
-def _pack(src, idx):
-    """buf[n, i, :] = src[n, idx[i], :].  HIP gather kernel on the GPU; plain indexing on CPU tensors
-    (reached only by the gloo tests: it moves bytes, it computes nothing)."""
+def _pack(src, idx, out=None):
+    """buf[n, i, :] = src[n, idx[i], :] (into ``out`` when given).  HIP gather kernel on the GPU; plain indexing on CPU
+    tensors (reached only by the gloo tests: it moves bytes, it computes nothing)."""
     if src.is_cuda:
-        return _native.rows_pack(src, idx)
-    return src[:, idx.long()].contiguous()
+        return _native.rows_pack(src, idx, out=out)
+    if out is None:
+        return src[:, idx.long()].contiguous()
+    return torch.index_select(src, 1, idx.long(), out=out)
 
 
 def _unpack(dst, idx, buf):
@@ -311,6 +313,8 @@ class ShardedChebyshev:
                                               device=self.device.index, levels=lay.levels)
         self._x_ext = None
         self._dy_ext = None
+        self._xbufs = {}                # packed send / receive rows per extended buffer, see _exchange_buffers
+        self.exchange_allocations = 0   # how often those were (re)allocated: 1 per buffer and (N, F) in steady state
         self._workspace = None
         self._workspace_w = None
         self._compute_wgrad = _compute_wgrad
@@ -353,6 +357,7 @@ class ShardedChebyshev:
         N, own, F = x_local.shape
         if own != lay.n_own:
             raise ValueError(f"this rank owns {lay.n_own} rows, got {own}")
+        buf_name = buf
         cur = getattr(self, buf)  # "_x_ext" for the input, "_dy_ext" for the upstream gradient of the backward pass
         in_place = (cur is not None and tuple(cur.shape) == (N, lay.n_cols, F)
                     and x_local.data_ptr() == cur.data_ptr() and x_local.stride() == cur.stride())
@@ -368,28 +373,45 @@ class ShardedChebyshev:
         # ranks sharing one GPU, debugging) the packed rows are staged through host memory instead;
         # only the transport differs, the pack / unpack kernels and the forward are the same.
         via_host = x_local.is_cuda and dist.get_backend(self.group) == "gloo"
-        ops, recv_bufs, keep = [], {}, []
+        xb = self._exchange_buffers(buf_name, N, F, x_local.device, via_host)
+        ops = []
         for p, idx in self._send_idx.items():
-            buf = _pack(x_ext, idx)
+            _pack(x_ext, idx, out=xb["send"][p])
             if via_host:
-                buf = buf.cpu()
-            keep.append(buf)
-            ops.append(dist.P2POp(dist.isend, buf, self._peer(p), group=self.group))
-        for p, idx in self._recv_idx.items():
-            buf = torch.empty((N, idx.numel(), F), dtype=torch.float32,
-                              device="cpu" if via_host else x_local.device)
-            recv_bufs[p] = buf
-            ops.append(dist.P2POp(dist.irecv, buf, self._peer(p), group=self.group))
+                xb["send_host"][p].copy_(xb["send"][p])
+            ops.append(dist.P2POp(dist.isend, xb["send_host" if via_host else "send"][p], self._peer(p), group=self.group))
+        for p in self._recv_idx:
+            ops.append(dist.P2POp(dist.irecv, xb["recv_host" if via_host else "recv"][p], self._peer(p), group=self.group))
         reqs = dist.batch_isend_irecv(ops)
 
         def finish():
             for req in reqs:
                 req.wait()
-            for p, buf in recv_bufs.items():
-                _unpack(x_ext, self._recv_idx[p], buf.to(x_local.device) if via_host else buf)
-            keep.clear()
+            for p, idx in self._recv_idx.items():
+                if via_host:
+                    xb["recv"][p].copy_(xb["recv_host"][p])
+                _unpack(x_ext, idx, xb["recv"][p])
 
         return x_ext, finish
+
+    def _exchange_buffers(self, name, N, F, device, via_host):
+        """The packed send and receive rows of one extended buffer (``_x_ext`` | ``_dy_ext``), allocated once per
+        (N, F) and kept: a step of the exchange allocates nothing.  Under a host-staged (gloo) group of HIP ranks every
+        buffer has a pinned host twin."""
+        key = (name, int(N), int(F), str(device), bool(via_host))
+        xb = self._xbufs.get(name)
+        if xb is not None and xb["key"] == key:
+            return xb
+        mk = lambda idx, dev, pin=False: torch.empty((N, idx.numel(), F), dtype=torch.float32, device=dev, pin_memory=pin)
+        xb = {"key": key,
+              "send": {p: mk(i, device) for p, i in self._send_idx.items()},
+              "recv": {p: mk(i, device) for p, i in self._recv_idx.items()}}
+        if via_host:
+            xb["send_host"] = {p: mk(i, "cpu", True) for p, i in self._send_idx.items()}
+            xb["recv_host"] = {p: mk(i, "cpu", True) for p, i in self._recv_idx.items()}
+        self._xbufs[name] = xb
+        self.exchange_allocations += 1
+        return xb
 
     def _peer(self, p):
         import torch.distributed as dist

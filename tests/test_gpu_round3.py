@@ -206,3 +206,84 @@ def test_set_levels_after_release_host_is_an_error():
     with pytest.raises((RuntimeError, ValueError)):
         plan.set_levels([cols.shape[0]] * 4)
     assert plan.fused_ok(16, 32, 5)  # still prepared for the K it was prepared for
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the real exchange_start -> INTERIOR -> finish -> BOUNDARY sequence, two processes on the one GPU
+# under a gloo group (host-staged transport; the pack / unpack kernels, both launches and the overlap are the real ones)
+
+def _two_rank_worker(rank, world, port, act_name, out):
+    import torch.distributed as dist
+
+    from deepsphere import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        nside, K, Fin, Fout, N = 64, 5, 16, 32, 2
+        cols, vals = _grid_ell(nside)
+        M = cols.shape[0]
+        rng = np.random.default_rng(5)
+        x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+        W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+        b = rng.standard_normal(Fout).astype(np.float32)
+        act = {"none": _native.ACT_NONE, "relu": _native.ACT_RELU, "elu": _native.ACT_ELU}[act_name]
+        sh = sharding.ShardedChebyshev(cols, vals, K, rank=rank, world=world, device="cuda:0", precision="bf16x3",
+                                       algo="fused", kernel=W, bias=b, act=act)
+        a, e = sh.layout.own
+        xl = _dev(x[:, a:e].copy())
+        ys = [sh(xl).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        full, _ = _native.cheb_forward(_native.LaplacianPlan(cols, vals, device=0), _dev(x), _dev(W), _dev(b), K, act=act,
+                                       precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+        halo_ok = bool(torch.equal(sh._x_ext.cpu(), torch.from_numpy(x[:, sh.layout.local_ids])))
+        res = {
+            "rank": rank,
+            "fused": bool(sh.fused),
+            "equal": bool(all(torch.equal(y, full[:, a:e]) for y in ys)),
+            "halo_ok": halo_ok,
+            "allocations": int(sh.exchange_allocations),
+            "halo_rows": int(sh.layout.n_cols - sh.layout.n_own),
+        }
+        gathered = [None] * world
+        dist.all_gather_object(gathered, res)
+        if rank == 0:
+            out.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("act", ["none", "elu"])
+def test_two_ranks_on_one_gpu_real_exchange(act):
+    """Two processes share cuda:0; each owns half of an nside-64 map.  Every step runs pack -> isend / irecv -> interior
+    tiles -> wait -> unpack -> boundary tiles; the stitched result equals the unsharded forward bit for bit (also with
+    ELU: ADVICE r2, the two-part launch with a deferred activation), and three steps allocate the packed buffers once."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, act, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = out.get(timeout=420)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()  # exactly the processes started above
+    assert all(p.exitcode == 0 for p in procs)
+    assert len(res) == 2
+    for r in res:
+        print(r)
+        assert r["fused"] and r["halo_rows"] > 0
+        assert r["halo_ok"], "the halo rows must be the owners' rows"
+        assert r["equal"], "a shard must reproduce the unsharded rows bit for bit"
+        assert r["allocations"] == 1, "the exchange allocates its packed buffers once per (N, F)"

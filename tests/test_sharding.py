@@ -109,6 +109,12 @@ def _worker(rank, world, port, K, partial, out):
         err = float(np.abs(y_local.numpy() - ref).max() / np.abs(ref).max())
         # the halo rows really came over the wire: compare the extended input with the global one
         halo_ok = bool(np.array_equal(sh._x_ext.numpy(), x[:, sh.layout.local_ids]))
+        # the packed send / receive rows are allocated once per (N, F): two more steps, still one allocation
+        for _ in range(2):
+            y_again = sh(torch.from_numpy(x[:, a:b].copy()))
+            halo_ok = halo_ok and bool(np.array_equal(y_again.numpy(), y_local.numpy()))
+        if sh._send_idx or sh._recv_idx:
+            halo_ok = halo_ok and sh.exchange_allocations == 1
         res = torch.tensor([err, 1.0 if halo_ok else 0.0], dtype=torch.float64)
         gathered = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(gathered, res)
