@@ -882,6 +882,9 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
     const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
     // (Tried: s_setprio 2 here -- the L waves are the younger ones of their SIMDs and lose the issue arbitration to their H
     // partner: their slots shrink from 1.8 k + 1.4 k to 1.2 k + 1.2 k cycles, H's grow by as much, the step stays the same.)
+#if SP_ABL & 4096
+    asm volatile("s_setprio 2");
+#endif
     int taken = 0;  // top-of-step reads done so far by this wave
     for (int p = p_begin + slot0; p < p_end; p += nslots) {
       const StripPair pr = a.pairs[p];
