@@ -3,6 +3,8 @@
 // first start to the last end over the waves of SIMD 0, per instruction group, for 1 and 2 waves per SIMD.
 //   MODE 0: 16 independent v_fmac_f32        MODE 1: 8 v_pk_fma_f32 (the same 16 multiply-adds)
 //   MODE 2: 1 MFMA 32x32x16 bf16 + 12 v_fmac MODE 3: 1 MFMA alone      MODE 4: 1 MFMA + 24 v_fmac
+//   MODE 5: 16 v_fmac_f32_dpp wave_shr:1      MODE 6: the strip kernel's quarter (4 plain + 8 dpp) + 2 more plain (14)
+//   MODE 7: the quarter with its centre terms packed (2 v_pk_fma + 8 dpp)
 // hipcc --offload-arch=gfx950 -O3 -o simd_share simd_share.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -44,6 +46,27 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* stamps,
       } else if (MODE == 2) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(s[i]), "v"(u));
+      } else if (MODE == 5) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(s[i]), "v"(u));
+      } else if (MODE == 6 || MODE == 7) {
+#pragma unroll
+        for (int i = 0; i < 4; i += 4) {
+          if (MODE == 6) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i + e]) : "v"(s[i + e]), "v"(u));
+          } else {
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(pa[0]) : "v"(ps[0]), "v"(pu));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(pa[1]) : "v"(ps[1]), "v"(pu));
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[4 + e]) : "v"(s[4 + e]), "v"(u));
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[8 + e]) : "v"(s[8 + e]), "v"(u));
+        }
       } else if (MODE == 4) {
 #pragma unroll
         for (int i = 0; i < 24; ++i) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(s[i]), "v"(u));
@@ -69,9 +92,10 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* stamps,
 int main() {
   float* out; unsigned long long* st;
   hipMalloc(&out, 512 * 256 * 4); hipMalloc(&st, 16 * 8);
-  const char* names[5] = {"16 v_fmac_f32", "8 v_pk_fma_f32 (16 multiply-adds)", "1 MFMA + 12 v_fmac", "1 MFMA alone", "1 MFMA + 24 v_fmac"};
+  const char* names[8] = {"16 v_fmac_f32", "8 v_pk_fma_f32 (16 multiply-adds)", "1 MFMA + 12 v_fmac", "1 MFMA alone", "1 MFMA + 24 v_fmac",
+                          "16 v_fmac_f32_dpp", "quarter: 4 plain + 8 dpp", "quarter: 2 pk + 8 dpp"};
   const int groups = 256;
-  for (int mode = 0; mode < 5; ++mode)
+  for (int mode = 0; mode < 8; ++mode)
     for (int threads : {256, 512}) {
       for (int rep = 0; rep < 2; ++rep) {
         if (mode == 0) k<0><<<256, threads>>>(out, st, groups);
@@ -79,6 +103,9 @@ int main() {
         if (mode == 2) k<2><<<256, threads>>>(out, st, groups);
         if (mode == 3) k<3><<<256, threads>>>(out, st, groups);
         if (mode == 4) k<4><<<256, threads>>>(out, st, groups);
+        if (mode == 5) k<5><<<256, threads>>>(out, st, groups);
+        if (mode == 6) k<6><<<256, threads>>>(out, st, groups);
+        if (mode == 7) k<7><<<256, threads>>>(out, st, groups);
         hipDeviceSynchronize();
       }
       unsigned long long h[16]; hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
