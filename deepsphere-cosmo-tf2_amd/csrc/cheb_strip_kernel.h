@@ -456,6 +456,18 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip_kernel(StripArgs a) 
 #ifndef SP_FD
 #define SP_FD "v_fmac_f32_dpp "
 #endif
+// cache-policy bits of the x loads and the y stores (tuning: -DDSPH_SP_LDF=1..4, -DDSPH_SP_STNT)
+#if DSPH_SP_LDF == 1
+#define SP_LDF " nt"
+#elif DSPH_SP_LDF == 2
+#define SP_LDF " sc0 sc1"
+#elif DSPH_SP_LDF == 3
+#define SP_LDF " sc1"
+#elif DSPH_SP_LDF == 4
+#define SP_LDF " sc0 sc1 nt"
+#else
+#define SP_LDF ""
+#endif
 
 // one MFMA: acc += wa * bb
 __device__ __forceinline__ void sp_m(sp_f32x16& acc, const sp_bf16x8& wa, const sp_bf16x8& bb) {
@@ -648,8 +660,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
     if (SP_ABL & 8) { xv[0] = sp_f32x4{0.f, 0.f, 0.f, 0.f}; xv[1] = xv[2] = xv[3] = xv[0]; return; }
     const char* src = xmap + (size_t)((sXc | sY) * xrowb + (unsigned)(lane >> 4) * 16u);
     asm volatile(
-        "global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
-        "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+        "global_load_dwordx4 %0, %4, off" SP_LDF "\n\tglobal_load_dwordx4 %1, %4, off offset:64" SP_LDF "\n\t"
+        "global_load_dwordx4 %2, %4, off offset:128" SP_LDF "\n\tglobal_load_dwordx4 %3, %4, off offset:192" SP_LDF
         : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[2]), "=&v"(xv[3])
         : "v"(src)
         : "memory");
@@ -983,8 +995,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
           for (int qq = 0; qq < 4; ++qq) sp_q<false, false>(Y, R[1][L2], qq, SP_HI(c0));
 #endif
           SP_STAMP(4);
-          SP_STAMP(5);
           xw_wait(xv);  // (here, in front of this step's y stores: the wait is for everything in flight)
+          SP_STAMP(5);
           // y of row ytop - K leaves through LDS so that the stores are coalesced (lane = pixel stores touch 32 rows per
           // instruction and hold the wave ~400 cycles each): into the 16 runs of 256 bytes that THIS wave will overwrite with
           // the fragments of row ytop+1 a few instructions further down -- pixels 16 ob .. 16 ob + 15 of every fragment of the
@@ -1015,7 +1027,11 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
                 sp_f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = fmaxf(yo[e] + bv[e], floor_v);
+#ifdef DSPH_SP_STNT
+                __builtin_nontemporal_store(o, reinterpret_cast<sp_f32x4*>(ymap + (size_t)rid * yrowb + (unsigned)(32 * ob + 4 * (lane & 7)) * 4u));
+#else
                 *reinterpret_cast<sp_f32x4*>(ymap + (size_t)rid * yrowb + (unsigned)(32 * ob + 4 * (lane & 7)) * 4u) = o;
+#endif
               }
             }
           }
