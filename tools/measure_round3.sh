@@ -16,5 +16,7 @@ tools/pmc3.sh r3_c3 c3 bf16x3 > $O/pmc_c3_bf16x3.txt 2>&1
 PMC_ONLY="3 4" tools/pmc3.sh r3_c3x6 c3 bf16x6 > $O/pmc_c3_bf16x6.txt 2>&1
 PMC_ONLY="3 4" tools/pmc3.sh r3_c5 c5 bf16x3 > $O/pmc_c5_bf16x3.txt 2>&1
 PMC_ONLY="3 4" tools/pmc3.sh r3_c4 c4 bf16x3 > $O/pmc_c4_bf16x3.txt 2>&1
-for t in c3 c3x6 c5 c4; do cp gpurun_out/pmc_r3_$t/summary.json $O/pmc_$t.json; rm -rf gpurun_out/pmc_r3_$t/p[0-9]*; done
+PMC_ONLY="3 4" tools/pmc3.sh r3_c2 c2 bf16x3 > $O/pmc_c2_bf16x3.txt 2>&1
+PMC_ONLY="3 4" tools/pmc3.sh r3_c1 c1 bf16x6 > $O/pmc_c1_bf16x6.txt 2>&1
+for t in c3 c3x6 c5 c4 c2 c1; do cp gpurun_out/pmc_r3_$t/summary.json $O/pmc_$t.json; rm -rf gpurun_out/pmc_r3_$t/p[0-9]*; done
 ls -la $O

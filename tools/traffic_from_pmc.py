@@ -36,6 +36,9 @@ for tag, (key, note) in TAGS.items():
         name = k.split("(")[0].strip()
         fetch[name] = v.get("FETCH_SIZE")
         write[name] = v.get("WRITE_SIZE")
+    if not fetch or any(fetch[k] is None or write[k] is None for k in fetch):
+        print("incomplete passes for", tag, "- entry left as it is", file=sys.stderr)
+        continue
     total = int(sum(2 * fetch[k] + write[k] for k in fetch) * 1024)
     rec[key] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "hbm_bytes_per_forward": total, "kernel": note,
                 "source": "tools/pmc3.sh passes 3 and 4 (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 tools/run_forward.py), mean per dispatch"}
