@@ -13,16 +13,19 @@
 //   * the strip is streamed along y (one pixel row per step, every level lagging one row behind the level above):
 //     the y-neighbours of a pixel are the previous / next rows held in the same lane's registers, the x-neighbours
 //     are the adjacent lanes, fetched by DPP wave shifts folded into the multiply-adds (v_fmac_f32_dpp);
-//   * y is stored straight from the registers; x is read once per strip row (1.33 x in all: 24 of a strip's 32
-//     columns are output, four on either side are halo that is recomputed), weights never move: they live in the
-//     waves' registers for the whole launch (that is what the two roles are for, below);
+//   * x is read once per strip row (1.33 x in all: 24 of a strip's 32 columns are output, four on either side are
+//     halo that is recomputed) by coalesced loads and goes into LDS once, as bf16 hi / lo MFMA fragments; y goes
+//     from the accumulators through a free ring slot so that its stores are coalesced too; weights never move:
+//     they live in the waves' registers for the whole launch (that is what the two roles are for, below);
 //   * no halo in y at all inside a segment: a strip walks hundreds of rows.
 // Roles.  A strip of 32 pixel columns is served by four waves: (role H | L) x (output-channel half ob).  H
 // evaluates the upper levels K-1 .. S of the recurrence, L the lower ones S-1 .. 0 (S = K / 2) one step later;
 // what crosses from H to L per step is one row of b_S and the dying row of b_{S+1}, 8 KiB through LDS.  Splitting
 // the levels -- not the pixels -- between waves is what lets every wave keep the weights of ITS levels in
 // registers (96 of them for three levels of a 64 x 32 block, hi and lo) and still fit two waves per SIMD; the
-// LDS then holds only the ring of the last K+2 rows of x (as bf16 hi / lo MFMA fragments, 8 KiB per row).
+// LDS then holds only the ring of the last K+2 rows of x (as bf16 hi / lo MFMA fragments, 8 KiB per row), the
+// hand-over rows and a ring of the last K+1 rows of L~ (nine values per pixel).
+// What bounds it, and everything that was tried on it: DESIGN.md section 4.0, profiles/r3_strip_ablations.txt.
 // A workgroup is two strips = eight waves, wave w and w + 4 share a SIMD: one H and one L, whose MFMA / VALU mix
 // is complementary.
 //
