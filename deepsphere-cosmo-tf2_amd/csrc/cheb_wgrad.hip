@@ -12,12 +12,16 @@
 // writes its partial K x Fin x Fout slab; a second kernel adds the slabs in a fixed order, so the
 // result is bitwise reproducible (float atomics would not be).
 // Roofline: K planes + dy read once -> HBM-bound for small Fin*Fout; fp32-MFMA-bound from 64 x 64 up.
+#include <algorithm>
+
 #include "dsphere_common.h"
 
 namespace dsph {
 
 constexpr int WG_KC = 8;        // most orders per pass (accumulator tiles per wave)
-constexpr int WG_ROWS = 4096;   // pixel rows per work item
+constexpr int WG_ROWS = 4096;   // least pixel rows per work item
+constexpr int WG_ITEMS = 768;   // most work items (= partial slabs) per call: 3 per CU of an MI355X, 60 MB of slabs at K 5, 64 -> 64.
+                                // A constant, not the device's CU count: the partition, and with it the rounding, is the same everywhere.
 constexpr int WG_KMAX = 64;
 
 struct WgradPlanes {
@@ -30,7 +34,7 @@ template <int KC>
 __global__ __launch_bounds__(256, 2) void cheb_wgrad_kernel(WgradPlanes planes, int64_t plane_rows,
                                                          const float* __restrict__ dy, float* __restrict__ slabs,
                                                          int64_t rows, int N, int Fin, int Fout, int K, int k0,
-                                                         int kc, int nfb, int nob, int chunks_per_map) {
+                                                         int kc, int nfb, int nob, int chunks_per_map, int rows_per_item) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int combo = blockIdx.y * 4 + wave;  // (fb, ob) block of this wave
   const bool active = combo < nfb * nob;
@@ -40,8 +44,8 @@ __global__ __launch_bounds__(256, 2) void cheb_wgrad_kernel(WgradPlanes planes, 
   const bool f_ok = active && fcol < Fin, o_ok = active && ocol < Fout;
   const int work = blockIdx.x;  // (map n, chunk) pairs
   const int n = work / chunks_per_map, chunk = work % chunks_per_map;
-  const int64_t m0 = (int64_t)chunk * WG_ROWS;
-  const int64_t m1 = m0 + WG_ROWS < rows ? m0 + WG_ROWS : rows;
+  const int64_t m0 = (int64_t)chunk * rows_per_item;
+  const int64_t m1 = m0 + rows_per_item < rows ? m0 + rows_per_item : rows;
 
   f32x16 acc[KC];
 #pragma unroll
@@ -103,9 +107,18 @@ __global__ __launch_bounds__(256) void cheb_wgrad_reduce_kernel(const float* __r
   dw[((int64_t)f * K + k) * Fout + o] = s;
 }
 
-static int wgrad_work_items(int64_t N, int64_t rows) {
-  return (int)(N * ((rows + WG_ROWS - 1) / WG_ROWS));
+// Rows per work item: 4096, or as many more as keep the number of items (N x chunks per map) at WG_ITEMS; a multiple of 16
+// (the kernel's trip).  At the headline shape: 4 maps x 192 chunks of 65,536 rows = 768 slabs of 80 KiB (12,288 of them before).
+static int64_t wgrad_rows_per_item(int64_t N, int64_t rows) {
+  const int64_t chunks_max = std::max<int64_t>(1, WG_ITEMS / std::max<int64_t>(N, 1));
+  int64_t per = std::max<int64_t>(WG_ROWS, (rows + chunks_max - 1) / chunks_max);
+  return (per + 15) / 16 * 16;
 }
+static int wgrad_chunks(int64_t N, int64_t rows) {
+  const int64_t per = wgrad_rows_per_item(N, rows);
+  return (int)((rows + per - 1) / per);
+}
+static int wgrad_work_items(int64_t N, int64_t rows) { return (int)(N * wgrad_chunks(N, rows)); }
 
 size_t wgrad_workspace_bytes(int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K) {
   return (size_t)wgrad_work_items(N, rows) * K * Fin * Fout * sizeof(float);
@@ -125,7 +138,8 @@ int launch_cheb_wgrad(const float* const* planes, int64_t plane_rows, const floa
   }
   WgradPlanes pp;
   for (int k = 0; k < WG_KMAX; ++k) pp.p[k] = k < K ? planes[k] : nullptr;
-  const int chunks = (int)((rows + WG_ROWS - 1) / WG_ROWS);
+  const int chunks = wgrad_chunks(N, rows);
+  const int rows_per_item = (int)wgrad_rows_per_item(N, rows);
   const int nwork = wgrad_work_items(N, rows);
   const int nfb = (Fin + 31) / 32, nob = (Fout + 31) / 32;
   dim3 grid((unsigned)nwork, (unsigned)((nfb * nob + 3) / 4));
@@ -134,7 +148,7 @@ int launch_cheb_wgrad(const float* const* planes, int64_t plane_rows, const floa
 #define DSPH_WGRAD(KC)                                                                                   \
   hipLaunchKernelGGL(cheb_wgrad_kernel<KC>, grid, dim3(256), 0, stream, pp, plane_rows, dy,              \
                      static_cast<float*>(workspace), rows, (int)N, (int)Fin, (int)Fout, (int)K, k0, kc, nfb, nob, \
-                     chunks)
+                     chunks, rows_per_item)
     if (kc <= 2) DSPH_WGRAD(2);
     else if (kc <= 4) DSPH_WGRAD(4);
     else if (kc <= 5) DSPH_WGRAD(5);
