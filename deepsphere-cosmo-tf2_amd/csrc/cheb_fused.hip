@@ -87,6 +87,14 @@ struct FusedPlan {
   unsigned char* d_rowflag = nullptr;
   bool rows_tried = false;
   bool host_released = false;  // DSPH_PREPARE_RELEASE_HOST: no tables for further depths
+  // The BFS-tile launch of a forward writes tiles of y that the structured launches do not touch: it runs on this side stream,
+  // forked from and joined back into the caller's stream by the two events (a few dozen face-corner tiles would otherwise
+  // hold the whole device for the latency of one tile: 14 of the 44 us of BASELINE configs[0], 57 of 544 us of configs[1]).
+  // Created with the plan -- a forward allocates nothing; fork_mu keeps two host threads that share a plan from interleaving
+  // their record / wait pairs.  Capturable: the side stream joins the capture through the fork event and leaves it at the join.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  std::mutex fork_mu;
 };
 
 static int template_width(int w) {
@@ -121,6 +129,17 @@ FusedPlan* fused_plan_build(const dsph_plan* plan, const int32_t* h_cols, const 
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0)
     fp->num_cu = prop.multiProcessorCount;
+  if (getenv("DSPH_NO_FORK") == nullptr) {
+    DeviceGuard guard(plan->device);
+    if (!guard.ok || hipStreamCreateWithFlags(&fp->side, hipStreamNonBlocking) != hipSuccess) fp->side = nullptr;
+    if (fp->side && (hipEventCreateWithFlags(&fp->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&fp->ev_join, hipEventDisableTiming) != hipSuccess)) {
+      if (fp->ev_fork) (void)hipEventDestroy(fp->ev_fork);
+      (void)hipStreamDestroy(fp->side);
+      fp->side = nullptr;
+      fp->ev_fork = fp->ev_join = nullptr;
+    }
+  }
   return fp;
 }
 
@@ -130,6 +149,12 @@ void fused_plan_destroy(FusedPlan* fp) {
   if (fp->d_gvals8) (void)hipFree(fp->d_gvals8);
   if (fp->d_gdiag) (void)hipFree(fp->d_gdiag);
   if (fp->d_rowflag) (void)hipFree(fp->d_rowflag);
+  if (fp->side) {
+    (void)hipStreamSynchronize(fp->side);
+    (void)hipEventDestroy(fp->ev_fork);
+    (void)hipEventDestroy(fp->ev_join);
+    (void)hipStreamDestroy(fp->side);
+  }
   delete fp;
 }
 
@@ -795,7 +820,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream,
                                const float* dy = nullptr, float* dw = nullptr, int32_t ld = 0, int32_t part = 0,
-                               int32_t Fin_w = 0);
+                               int32_t Fin_w = 0, int32_t only = 0);  // only: 0 every launch, 1 the structured ones, 2 the BFS-tile one
 
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
@@ -832,12 +857,37 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
     x = xp;
     Fin = Fp;
   }
+  // structured launches and the BFS-tile launch write disjoint tiles: when a forward has both, the latter goes to the plan's
+  // side stream (FusedPlan::side), forked behind whatever the caller's stream holds so far and joined before this call returns
+  FusedPlan* fp = plan->fused;
+  bool fork = false;
+  if (fp && fp->side && K >= 2 && K - 1 <= FUSED_DMAX) {
+    const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
+    const int ng = !ft.ok ? 0 : (part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior));
+    // (worth its two event operations only when the structured launches run for a while: two tile-maps per CU and more --
+    // BASELINE configs[0], 168 tile-maps, is 13 us faster without it, configs[1] 29 us faster with it)
+    fork = ft.ok && ft.n_r + ft.n_t > 0 && ng > 0 && N * (int64_t)(ft.n_r + ft.n_t) >= 2 * (int64_t)fp->num_cu;
+  }
   for (int32_t cb = 0; cb < Fout; cb += 64) {
-    const int rc = launch_fused_common(plan, x, w + cb, bias ? bias + cb : nullptr, y + cb, nullptr, N, Fin,
-                                       std::min<int32_t>(64, Fout - cb), K, defer_act ? DSPH_ACT_NONE : act, precision,
-                                       alpha_rest, beta_rest, workspace, workspace_bytes, stream, nullptr, nullptr, Fout, part,
-                                       Fin_w);
-    if (rc != DSPH_OK) return rc;
+    auto run = [&](hipStream_t st, int32_t only) {
+      return launch_fused_common(plan, x, w + cb, bias ? bias + cb : nullptr, y + cb, nullptr, N, Fin,
+                                 std::min<int32_t>(64, Fout - cb), K, defer_act ? DSPH_ACT_NONE : act, precision, alpha_rest,
+                                 beta_rest, workspace, workspace_bytes, st, nullptr, nullptr, Fout, part, Fin_w, only);
+    };
+    if (!fork) {
+      const int rc = run(stream, 0);
+      if (rc != DSPH_OK) return rc;
+      continue;
+    }
+    std::lock_guard<std::mutex> lock(fp->fork_mu);
+    DSPH_HIP(hipEventRecord(fp->ev_fork, stream));
+    DSPH_HIP(hipStreamWaitEvent(fp->side, fp->ev_fork, 0));
+    const int rc_b = run(fp->side, 2);
+    DSPH_HIP(hipEventRecord(fp->ev_join, fp->side));
+    const int rc_s = run(stream, 1);
+    DSPH_HIP(hipStreamWaitEvent(stream, fp->ev_join, 0));  // (also on an error: the side stream never outlives the call)
+    if (rc_b != DSPH_OK) return rc_b;
+    if (rc_s != DSPH_OK) return rc_s;
   }
   if (defer_act && part != 1) {
     const int64_t orows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
@@ -919,7 +969,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream, const float* dy,
-                               float* dw, int32_t ld, int32_t part, int32_t Fin_w) {
+                               float* dw, int32_t ld, int32_t part, int32_t Fin_w, int32_t only) {
   if (ld <= 0) ld = Fout;
   if (Fin_w <= 0) Fin_w = Fin;  // channels of w; smaller than Fin when x is a zero-padded copy  // row stride of w, bias-less y / dy / dw: the layer's Fout when this is one column block
   const bool wgrad_mode = dy != nullptr;  // y then carries the slab workspace
@@ -942,7 +992,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   }
   const int C = (Fin + FUSED_CH - 1) / FUSED_CH, NB = (Fout + 31) / 32;
   // ---- class-R and class-T tiles: the structured-tile kernel (forward only), without and with per-tile tables ----------
-  if (!planes_mode && ft.n_r + ft.n_t > 0) {
+  if (!planes_mode && ft.n_r + ft.n_t > 0 && only != 2) {
     StructLaunch sl;
     sl.x = x; sl.w = w; sl.bias = bias; sl.y = y;
     sl.wfrag = static_cast<unsigned char*>(workspace) + wb;
@@ -997,6 +1047,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     const int ng = part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior);
     if (ng == 0 || dbg_only('s')) return DSPH_OK;
   }
+  if (only == 1) return DSPH_OK;
   // the BFS-tile kernel has two contraction arithmetics; the six-term split of the structured kernel is fp32-equivalent
   if (precision == DSPH_PREC_BF16X6) precision = DSPH_PREC_FP32;
   if (!planes_mode) {

@@ -146,7 +146,8 @@ size_t dsph_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32
  *   y     device (N, out_rows, Fout) fp32
  * Batch normalisation (gnn_layers.py:152-153) sits between the contraction and the bias in the
  * reference; a layer with use_bn=True calls this with bias=NULL, act=NONE and finishes on the host.
- * Asynchronous on `hip_stream` (a hipStream_t; NULL = the default stream). */
+ * Asynchronous on `hip_stream` (a hipStream_t; NULL = the default stream).  (Part of a large fused forward may run on a
+ * stream the plan owns, forked from and joined back into `hip_stream` inside the call: invisible to the caller, capturable.) */
 int dsph_cheb_forward(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, int32_t algo, void* workspace, size_t workspace_bytes,

@@ -287,3 +287,35 @@ def test_two_ranks_on_one_gpu_real_exchange(act):
         assert r["halo_ok"], "the halo rows must be the owners' rows"
         assert r["equal"], "a shard must reproduce the unsharded rows bit for bit"
         assert r["allocations"] == 1, "the exchange allocates its packed buffers once per (N, F)"
+
+
+def test_side_stream_launch_changes_no_bit():
+    """Round 3: with enough work the BFS-tile launch of a forward runs on the plan's side stream, forked from and joined into the
+    caller's stream.  Same kernels, same tiles: the result equals the single-stream one (DSPH_NO_FORK, read at plan creation) bit
+    for bit, on the default stream and on a stream of the caller's, also when the output buffer is reused at once."""
+    cols, vals = _grid_ell(64)
+    M, N, Fin, Fout, K = cols.shape[0], 6, 16, 32, 5
+    rng = np.random.default_rng(21)
+    x = _dev(rng.standard_normal((N, M, Fin)).astype(np.float32))
+    W = _dev((rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32))
+    b = _dev(rng.standard_normal(Fout).astype(np.float32))
+    os.environ["DSPH_NO_FORK"] = "1"
+    try:
+        plan0 = _native.LaplacianPlan(cols, vals, device=0)
+    finally:
+        del os.environ["DSPH_NO_FORK"]
+    plan1 = _native.LaplacianPlan(cols, vals, device=0)
+    ns, nb = plan1.tile_counts(K)
+    assert ns > 0 and nb > 0 and N * ns >= 512  # both kinds of tiles, and past the fork's work threshold
+    kw = dict(act=_native.ACT_ELU, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    y0, _ = _native.cheb_forward(plan0, x, W, b, K, **kw)
+    y1, ws = _native.cheb_forward(plan1, x, W, b, K, **kw)
+    assert torch.equal(y0, y1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):  # back to back into the same buffers: every call's join orders the next call's launches
+            y2, ws = _native.cheb_forward(plan1, x, W, b, K, workspace=ws, out=y1, **kw)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y2)
