@@ -180,8 +180,8 @@ def test_strip_kernel_wider_layer():
 def test_interior_plus_boundary_with_every_activation(act):
     """a two-part launch (what a multi-rank ShardedChebyshev issues) with an activation the structured kernels do not
     fuse used to fail; now both parts write the pre-activation and the BOUNDARY call finishes y.  INTERIOR + BOUNDARY must
-    equal the single launch."""
-    nside, K, Fin, Fout, N = 64, 5, 16, 32, 2
+    equal the single launch.  (Four maps: enough tile-maps for the BFS-tile launch of every call to take the plan's side stream.)"""
+    nside, K, Fin, Fout, N = 64, 5, 16, 32, 4
     cols, vals = _grid_ell(nside)
     M = cols.shape[0]
     plan = _native.LaplacianPlan(cols, vals, device=0)
