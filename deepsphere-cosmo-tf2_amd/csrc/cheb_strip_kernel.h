@@ -741,16 +741,24 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
     unsigned char* p = smem + sbase + (unsigned)slot * ROWB + xw_off;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-      bf16x4 hi, lo;
+      // per pair of values: one packed convert for the two hi halves, a shift and a mask to get them back as floats, two
+      // subtractions, one packed convert for the lo halves (six instructions; element by element hipcc makes eight of it)
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      u32x2 hi, lo;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const __bf16 hh = (__bf16)xv[k][j];
-        hi[j] = hh;
-        lo[j] = (__bf16)(xv[k][j] - (float)hh);
+      for (int j = 0; j < 2; ++j) {
+        const float a0 = xv[k][2 * j], a1 = xv[k][2 * j + 1];
+        const bf16x2 h = __builtin_convertvector(f32x2{a0, a1}, bf16x2);
+        const unsigned hu = __builtin_bit_cast(unsigned, h);
+        const float h0 = __builtin_bit_cast(float, hu << 16), h1 = __builtin_bit_cast(float, hu & 0xffff0000u);
+        const bf16x2 l = __builtin_convertvector(f32x2{a0 - h0, a1 - h1}, bf16x2);
+        hi[j] = hu;
+        lo[j] = __builtin_bit_cast(unsigned, l);
       }
-      *reinterpret_cast<bf16x4*>(p + 2 * SP_FRAG * k) = hi;
-      *reinterpret_cast<bf16x4*>(p + 2 * SP_FRAG * k + SP_FRAG) = lo;
+      *reinterpret_cast<u32x2*>(p + 2 * SP_FRAG * k) = hi;
+      *reinterpret_cast<u32x2*>(p + 2 * SP_FRAG * k + SP_FRAG) = lo;
     }
   };
   // The rows of L~ go through a ring in LDS next to the x ring (slot of row ytop: cs_top), fetched once per strip by the wave
@@ -1021,17 +1029,16 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
           // the rows H left at the end of the previous step: b2[new] -> R[0][L2] (the set that died then), b3 -> R[1][L2]
           if (!(SP_ABL & 8192)) {  // (at the first step of a map these are the last rows of the previous map: finite, and never reach an output)
             const unsigned char* hp = smem + hand;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-              const sp_f32x4 r0 = *reinterpret_cast<const sp_f32x4*>(hp + f * SP_FRAG);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) R[0][L2][4 * f + e] = r0[e];
-              if (CHEB) {
-                const sp_f32x4 r1 = *reinterpret_cast<const sp_f32x4*>(hp + (4 + f) * SP_FRAG);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) R[1][L2][4 * f + e] = r1[e];
-              }
-            }
+            // (rows put together by concatenation: element by element hipcc loads into scratch registers and copies)
+            typedef float sp_f32x8 __attribute__((ext_vector_type(8)));
+            auto row16 = [&](const unsigned char* q) __attribute__((always_inline)) -> sp_f32x16 {
+              const sp_f32x4 a0 = *reinterpret_cast<const sp_f32x4*>(q), a1 = *reinterpret_cast<const sp_f32x4*>(q + SP_FRAG),
+                             a2 = *reinterpret_cast<const sp_f32x4*>(q + 2 * SP_FRAG), a3 = *reinterpret_cast<const sp_f32x4*>(q + 3 * SP_FRAG);
+              const sp_f32x8 lo8 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), hi8 = __builtin_shufflevector(a2, a3, 0, 1, 2, 3, 4, 5, 6, 7);
+              return __builtin_shufflevector(lo8, hi8, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            };
+            R[0][L2] = row16(hp);
+            if (CHEB) R[1][L2] = row16(hp + 4 * SP_FRAG);
           }
           ++taken;
           flag_set(taken);  // (LDS operations of a wave complete in order: the reads above are done first)
