@@ -803,6 +803,14 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
 #else
 #define SP_FRLOAD(P) (*reinterpret_cast<const sp_bf16x8*>(P))
 #endif
+// order of the three terms of an inner block: (weights hi | lo = 0 | 1, x lo | hi = 0 | 1)
+#ifdef DSPH_SP_ORDER2  // W_lo.x_hi, W_hi.x_hi, W_hi.x_lo: one operand stays where it is between consecutive MFMAs
+#define SP_ORD_A(j) ((j) == 0 ? 1 : 0)
+#define SP_ORD_B(j) ((j) == 2 ? 0 : 1)
+#else                  // W_hi.x_lo, W_lo.x_hi, W_hi.x_hi: the small terms first
+#define SP_ORD_A(j) ((j) == 1 ? 1 : 0)
+#define SP_ORD_B(j) ((j) == 0 ? 0 : 1)
+#endif
 #define SP_CHAIN(ACC, FIRST_STMT, WLEV, FADDR, NQ, ...)                                                                \
   {                                                                                                                    \
     sp_bf16x8 fr[2][2];                                                                                                \
@@ -813,8 +821,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
     _Pragma("unroll") for (int ib = 0; ib < NIB; ++ib) {                                                               \
       _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                  \
         const int m = 3 * ib + j;                                                                                      \
-        const sp_bf16x8& wa_ = wr[WLEV][ib][j == 1 ? 1 : 0];                                                           \
-        const sp_bf16x8& bb_ = fr[ib & 1][j == 0 ? 0 : 1];                                                             \
+        const sp_bf16x8& wa_ = wr[WLEV][ib][SP_ORD_A(j)];                                                              \
+        const sp_bf16x8& bb_ = fr[ib & 1][SP_ORD_B(j)];                                                                \
         if (m == 0) { FIRST_STMT; }                                                                                    \
         else sp_m(ACC, wa_, bb_);                                                                                      \
         _Pragma("unroll") for (int qq = (m * (NQ)) / 12; qq < ((m + 1) * (NQ)) / 12; ++qq) { __VA_ARGS__; }            \
