@@ -154,12 +154,12 @@ def measured_error(cols, vals, x, y, w_np, K, nside, seed=3, n_random=24):
     return float(np.abs(got - ref).max() / s_max), int(centres.size * x.shape[0])
 
 
-def fused_kernel_name(plan, K, Fin, Fout, prec_code):
+def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1):
     """Which kernels one fused forward launches: the strip kernel on the rectangles of plain structured tiles it takes for this
     shape (dsph_plan_strip_tiles), the structured-tile kernel on the other structured tiles, the BFS-tile kernel on the rest
     (dsph_plan_tile_counts)."""
     n_struct, n_bfs = plan.tile_counts(K)
-    n_strip = plan.strip_tiles(Fin, Fout, K, prec_code)
+    n_strip = plan.strip_tiles(Fin, Fout, K, prec_code, N=N)
     parts = []
     if n_strip:
         parts.append(f"cheb_strip5_kernel ({n_strip} tiles)")
@@ -249,7 +249,7 @@ def main():
             with torch.no_grad():  # inference forward: bias/activation fused in the kernel epilogue
                 return layer(x)
         fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-        kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
+        kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
     else:
         from deepsphere import sharding
 
@@ -264,7 +264,7 @@ def main():
         x.normal_(generator=gen)
         run = lambda: shard(x)  # noqa: E731
         fused = shard.plan.fused_ok(Fin, Fout, K) and args.algo != "unfused"
-        kernel_name = (fused_kernel_name(shard.plan, K, Fin, Fout, prec_code) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \
+        kernel_name = (fused_kernel_name(shard.plan, K, Fin, Fout, prec_code, N) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \
             " + rows_pack_kernel + " + \
             ("RCCL send/recv" if args.backend == "nccl" else "gloo send/recv (host-staged)") + " of the (K-1)-ring halo"
     setup_s = time.time() - t0
@@ -321,7 +321,7 @@ def main():
                 with torch.no_grad():
                     return layer(xr)
             fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-            kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code) if fused else kernel_name
+            kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N) if fused else kernel_name
     # Warm up exactly as the timed loop runs: the previous output stays referenced while the next forward allocates its
     # own, so BOTH output blocks are in the caching allocator before the clock starts (a first-ever hipMalloc of a second
     # 12.9 GB block inside the timed region costs one forward 350 ms on a box whose memory has not been touched yet).

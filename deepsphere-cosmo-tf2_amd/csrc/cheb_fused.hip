@@ -71,6 +71,9 @@ struct FusedTiles {
   StripPair* d_pairs = nullptr;
   int n_pairs = 0;
   int64_t n_strip_tiles = 0;
+  std::vector<int32_t> strip_steps;        // per pair, in list order: rows + run-in = strip steps of one map
+  std::map<int64_t, int64_t> strip_span;   // batch N -> steps of the busiest workgroup (strip_makespan; under FusedPlan::mu)
+  bool strip_forced = false;               // DSPH_STRIP_FORCE at build time: the cost gate is off
   int32_t* d_rrest = nullptr;
   int n_rrest = 0, n_rrest_interior = 0;
 };
@@ -300,12 +303,32 @@ static bool embed_tile(const dsph_plan* plan, const int32_t* cols, const float* 
   return true;
 }
 
+// Steps of the busiest workgroup when the strip kernel deals `steps.size()` pairs x N maps the way cheb_strip5_kernel does:
+// items q = pair * N + map, a contiguous eighth of them per XCD, dealt to the XCD's workgroups in turn.
+static int strip_grid(int num_cu, int64_t n_items) { return (int)std::max<int64_t>(8, std::min<int64_t>(num_cu, (n_items + 7) / 8 * 8)); }
+static int64_t strip_makespan(const std::vector<int32_t>& steps, int64_t N, int num_cu) {
+  const int64_t Q = (int64_t)steps.size() * N;
+  const int G = strip_grid(num_cu, Q);
+  int64_t worst = 0;
+  std::vector<int64_t> load;
+  for (int xcd = 0; xcd < 8; ++xcd) {
+    const int nslots = (G + 7 - xcd) / 8;
+    const int64_t q0 = Q * xcd / 8, q1 = Q * (xcd + 1) / 8;
+    if (nslots <= 0 || q1 <= q0) continue;
+    load.assign((size_t)nslots, 0);
+    for (int64_t q = q0; q < q1; ++q) load[(size_t)((q - q0) % nslots)] += steps[(size_t)(q / N)];
+    for (int64_t v : load) worst = std::max(worst, v);
+  }
+  return worst;
+}
+
 // Strip kernel: which class-R tiles it takes, and in what pieces.  The interior class-R tiles are covered by rectangles (in
 // the virtual Morton plane of the tile indices: tile t sits at (compress(t), compress(t >> 1))) of 3 to 5 tile columns and at
 // least 4 tile rows; a rectangle is cut into 32-column strips with 24 output columns each, two strips per workgroup item,
 // and into row segments sized so that the items fill the CUs evenly.  The other tiles stay with the tile kernels (`rest`).
 static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_cu, std::vector<StripPair>& pairs,
-                         std::vector<int32_t>& rest, int64_t* n_taken) {
+                         std::vector<int32_t>& rest, int64_t* n_taken, std::vector<int32_t>& steps) {
+  steps.clear();
   pairs.clear();
   rest.clear();
   *n_taken = 0;
@@ -381,65 +404,81 @@ static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_
             take.size(), a3, a45, take.empty() ? 0 : hmin, hmax, rest.size());
   }
   if (take.empty()) return;
-  // segment height: the one that minimises (items per CU, rounded up) x (rows per item + run-in)
-  const int cand[] = {4096, 2048, 1024, 512, 384, 256, 192, 128, 96, 64};
-  long best_cost = -1;
-  int best_h = 256;
-  for (int h : cand) {
-    long items = 0, hmax = 0;
+  // Segment height: every segment pays 2 D + 1 run-in rows, every workgroup should get the same number of steps.  Candidates
+  // from the whole rectangle down to 256 rows (measured on the partial sky of BASELINE configs[4], batch 16, strips forced:
+  // 23.0 ms with 64-row segments, 21.6 with 128, 21.3 with 256 and 512, 21.6 unsegmented; the tile kernels: 21.8); the one whose busiest workgroup has the fewest steps
+  // for ONE map wins -- a batch only evens things out further, items being (pair, map).
+  auto cut = [&](int h, std::vector<StripPair>& out) {
+    out.clear();
     for (const Rect& r : take) {
-      const int np = ((16 * r.wt + SP_USE - 1) / SP_USE + 1) / 2, H = 16 * r.ht;
-      const int nseg = (H + h - 1) / h;
-      items += (long)np * nseg;
-      hmax = std::max<long>(hmax, (H + nseg - 1) / nseg);
-    }
-    const long cost = ((items + num_cu - 1) / num_cu) * (hmax + 2 * D + 1);
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_h = h; }
-  }
-  // Worth it?  A strip step (48 output pixels of one row, one map) takes a workgroup ~3.0 us, a 256-pixel tile of one map takes
-  // the tile kernels ~18.7 us of a CU (both measured at the headline shape): in units of 0.1 us per map,
-  //   strips: (items per CU, rounded up) x (rows per item + run-in) x 30      tile kernels: tiles x 187 / CUs.
-  // Ragged masks (many short rectangles: run-in rows, a last strip of 8 or 16 columns, items of unequal height) lose that
-  // comparison and keep their tiles on the tile kernels.
-  if (getenv("DSPH_STRIP_FORCE") == nullptr && best_cost * 30 >= (long)(*n_taken) * 187 / num_cu) {
-    if (getenv("DSPH_STRIP_DEBUG")) fprintf(stderr, "build_strips: not taken (strip cost %ld >= tile cost %ld)\n", best_cost * 30, (long)(*n_taken) * 187 / num_cu);
-    for (const Rect& r : take)
-      for (int v = 0; v < r.ht; ++v)
-        for (int u = 0; u < r.wt; ++u) rest.push_back((int32_t)st_morton((unsigned)(r.tx + u), (unsigned)(r.ty + v)));
-    std::sort(rest.begin(), rest.end());
-    *n_taken = 0;
-    return;
-  }
-  for (const Rect& r : take) {
-    const int X0 = 16 * r.tx, X1 = 16 * (r.tx + r.wt), Y0 = 16 * r.ty, Y1 = 16 * (r.ty + r.ht);
-    const int ns = (X1 - X0 + SP_USE - 1) / SP_USE;
-    const int H = Y1 - Y0, nseg = (H + best_h - 1) / best_h;
-    for (int sg = 0; sg < nseg; ++sg) {
-      const int ya = Y0 + (int)((int64_t)H * sg / nseg), yb = Y0 + (int)((int64_t)H * (sg + 1) / nseg);
-      for (int s0 = 0; s0 < ns; s0 += 2) {
-        StripPair p;
-        for (int e = 0; e < 2; ++e) {
-          const int s = s0 + e;
-          if (s < ns) {
-            p.x0[e] = X0 + SP_USE * s;
-            p.w[e] = std::min(SP_USE, X1 - p.x0[e]);
-          } else {
-            p.x0[e] = p.x0[0];
-            p.w[e] = 0;
+      const int X0 = 16 * r.tx, X1 = 16 * (r.tx + r.wt), Y0 = 16 * r.ty, Y1 = 16 * (r.ty + r.ht);
+      const int ns = (X1 - X0 + SP_USE - 1) / SP_USE;
+      const int H = Y1 - Y0, nseg = (H + h - 1) / h;
+      for (int sg = 0; sg < nseg; ++sg) {
+        const int ya = Y0 + (int)((int64_t)H * sg / nseg), yb = Y0 + (int)((int64_t)H * (sg + 1) / nseg);
+        for (int s0 = 0; s0 < ns; s0 += 2) {
+          StripPair p;
+          for (int e = 0; e < 2; ++e) {
+            const int s = s0 + e;
+            if (s < ns) {
+              p.x0[e] = X0 + SP_USE * s;
+              p.w[e] = std::min(SP_USE, X1 - p.x0[e]);
+            } else {
+              p.x0[e] = p.x0[0];
+              p.w[e] = 0;
+            }
           }
+          p.y0 = ya;
+          p.y1 = yb;
+          p.xlo = X0 - D;
+          p.xhi = X1 - 1 + D;
+          for (int e = 0; e < 2; ++e)  // lane 0 of the strip: D columns left of the first output column, but never past the halo
+            p.xs[e] = std::min(p.x0[e] - D, p.xhi + 1 - SP_PX);
+          p.ylo = Y0 - D;
+          p.yhi = Y1 - 1 + D;
+          out.push_back(p);
         }
-        p.y0 = ya;
-        p.y1 = yb;
-        p.xlo = X0 - D;
-        p.xhi = X1 - 1 + D;
-        for (int e = 0; e < 2; ++e)  // lane 0 of the strip: D columns left of the first output column, but never past the halo
-          p.xs[e] = std::min(p.x0[e] - D, p.xhi + 1 - SP_PX);
-        p.ylo = Y0 - D;
-        p.yhi = Y1 - 1 + D;
-        pairs.push_back(p);
       }
     }
+    // Items of unequal height (ragged masks): tallest first, then dealt over the eight XCD ranges of the kernel (a range is a
+    // contiguous eighth of the list), so that every XCD -- and, the kernel dealing a range to its workgroups in turn, every
+    // workgroup -- gets its share of tall and short ones.  Equal heights (a full sphere): the order of the cut stays,
+    // neighbours in x next to each other.
+    bool ragged = false;
+    for (const StripPair& p : out) ragged = ragged || (p.y1 - p.y0 != out[0].y1 - out[0].y0);
+    if (ragged) {
+      std::stable_sort(out.begin(), out.end(), [](const StripPair& a, const StripPair& b) { return a.y1 - a.y0 > b.y1 - b.y0; });
+      std::vector<StripPair> dealt;
+      dealt.reserve(out.size());
+      for (size_t x = 0; x < 8; ++x)
+        for (size_t i2 = x; i2 < out.size(); i2 += 8) dealt.push_back(out[i2]);
+      out.swap(dealt);
+    }
+  };
+  auto steps_of = [&](const std::vector<StripPair>& v, std::vector<int32_t>& st) {
+    st.resize(v.size());
+    for (size_t i2 = 0; i2 < v.size(); ++i2) st[i2] = (v[i2].y1 - v[i2].y0) + 2 * D + 1;
+  };
+  const int cand[] = {4096, 2048, 1024, 512, 384, 256};
+  int64_t best_span = -1;
+  int best_h = 256;
+  {
+    std::vector<StripPair> trial;
+    std::vector<int32_t> st;
+    for (int h : cand) {
+      cut(h, trial);
+      steps_of(trial, st);
+      const int64_t span = strip_makespan(st, 1, num_cu);
+      if (best_span < 0 || span < best_span) { best_span = span; best_h = h; }
+    }
   }
+  if (const char* sg = getenv("DSPH_STRIP_SEG")) best_h = std::max(16, atoi(sg));  // (tuning: the segment height, in rows)
+  cut(best_h, pairs);
+  steps_of(pairs, steps);
+  if (getenv("DSPH_STRIP_DEBUG"))
+    fprintf(stderr, "build_strips: segments of %d rows, %zu pairs, busiest workgroup %ld / %ld / %ld steps for 1 / 4 / 16 maps; tile cost "
+            "per map in the same unit %ld\n", best_h, pairs.size(), (long)strip_makespan(steps, 1, num_cu), (long)strip_makespan(steps, 4, num_cu),
+            (long)strip_makespan(steps, 16, num_cu), (long)(*n_taken * 187 / (30 * num_cu)));
 }
 
 // Breadth-first rings of every tile; uploads the tables.  Returns a reference to the cached entry.
@@ -627,8 +666,11 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   std::vector<StripPair> pairs;
   std::vector<int32_t> rrest;
   ft.n_strip_tiles = 0;
+  ft.strip_steps.clear();
+  ft.strip_span.clear();
+  ft.strip_forced = getenv("DSPH_STRIP_FORCE") != nullptr;
   if (!full && D <= SP_DMAX && getenv("DSPH_NO_STRIP") == nullptr)
-    build_strips(r_interior, D, fp->num_cu, pairs, rrest, &ft.n_strip_tiles);
+    build_strips(r_interior, D, fp->num_cu, pairs, rrest, &ft.n_strip_tiles, ft.strip_steps);
   else
     rrest = r_interior;
   ft.n_pairs = (int)pairs.size();
@@ -740,17 +782,35 @@ bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int6
   return true;
 }
 
-// one rule for "does the strip kernel take this forward" (launch_fused_common and dsph_plan_strip_tiles)
-static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K, int32_t precision) {
-  return ft.n_pairs > 0 && precision == DSPH_PREC_BF16X3 && strip_shape_ok(Fin, Fout, K) &&
-         plan->n_cols * (int64_t)std::max(Fin, Fout) * 4 < (1ll << 32);
+// One rule for "does the strip kernel take this forward" (launch_fused_common and dsph_plan_strip_tiles): the shape is the
+// kernel's, and the strips are worth it for this batch.  A strip step (48 output pixels of one row, one map) takes a workgroup
+// ~3.0 us, a 256-pixel tile of one map takes the tile kernels ~18.7 us of a CU (both measured at the headline shape): in units
+// of 0.1 us,   strips: (steps of the busiest workgroup, strip_makespan) x 30      tile kernels: tiles x N x 187 / CUs,
+// with 3 % in favour of the tile kernels.  Small maps (fewer items than CUs) and ragged masks at small batches lose that
+// comparison and keep their tiles on the tile kernels; DSPH_STRIP_FORCE (read when the tables are built) switches it off.
+static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t N) {
+  if (!(ft.n_pairs > 0 && precision == DSPH_PREC_BF16X3 && strip_shape_ok(Fin, Fout, K) &&
+        plan->n_cols * (int64_t)std::max(Fin, Fout) * 4 < (1ll << 32)))
+    return false;
+  if (ft.strip_forced) return true;
+  if (N < 1 || (int64_t)ft.strip_steps.size() * N > (1ll << 24)) return false;
+  FusedPlan* fp = plan->fused;
+  int64_t span;
+  {
+    std::lock_guard<std::mutex> lock(fp->mu);
+    auto& cache = const_cast<FusedTiles&>(ft).strip_span;
+    auto it = cache.find(N);
+    if (it == cache.end()) it = cache.emplace(N, strip_makespan(ft.strip_steps, N, fp->num_cu)).first;
+    span = it->second;
+  }
+  return span * 30 * 103 < ft.n_strip_tiles * N * 187 / fp->num_cu * 100;
 }
 
-int64_t fused_strip_tiles(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K, int32_t precision) {
+int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision) {
   if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX || Fin != pad4(Fin)) return 0;
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
   if (!ft.ok || Fout % 64 != 0) return 0;  // (wider layers: one launch per 64-column block, each through the strips)
-  return strips_apply(plan, ft, Fin, 64, K, precision) ? ft.n_strip_tiles : 0;
+  return strips_apply(plan, ft, Fin, 64, K, precision, N) ? ft.n_strip_tiles : 0;
 }
 
 // two fragment layouts: the BFS-tile kernel's and, behind it, the structured-tile kernel's
@@ -1006,7 +1066,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     sl.cheb = beta_rest != 0.f;
     sl.prep_weights = true;  // the first of the two launches packs the fragments
     // rectangles of interior class-R tiles: the strip kernel, when it has this shape; the class-R list shrinks to the rest
-    const bool strips = strips_apply(plan, ft, Fin, Fout, K, precision) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+    const bool strips = strips_apply(plan, ft, Fin, Fout, K, precision, N) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                         ld % 4 == 0 && plan->n_cols * (int64_t)ld * 4 < (1ll << 32);
     if (strips && part != 2 && !dbg_only('b')) {
       StripLaunch st;

@@ -66,7 +66,8 @@ int launch_cheb_strip(const StripLaunch& s, hipStream_t stream) {
   a.Fout = s.Fout;
   a.ld = s.ld;
   a.act = s.act;
-  const int grid = std::max(8, std::min(s.num_cu, (s.npairs + 7) / 8 * 8));
+  // (one workgroup per CU, fewer when there are fewer (pair, map) items; cheb_fused.hip's strip_makespan mirrors this)
+  const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(s.num_cu, ((int64_t)s.npairs * s.N + 7) / 8 * 8));
   void (*kern)(StripArgs) = nullptr;
   // K = 5: the hand-ordered instantiation; DSPH_STRIP_GENERIC=1 (diagnosis) and the other K: the generic kernel
   static const bool generic = getenv("DSPH_STRIP_GENERIC") != nullptr;

@@ -700,7 +700,11 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
 
   const int G = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
   const int nslots = (G + 7 - xcd) / 8;
-  const int p_begin = (int)((int64_t)a.npairs * xcd / 8), p_end = (int)((int64_t)a.npairs * (xcd + 1) / 8);
+  // work items are (strip pair, map): a contiguous range of them per XCD (neighbouring pairs and the maps of a pair share an
+  // L2), dealt to the XCD's workgroups in turn -- with the pairs sorted by height (cheb_fused.hip) every workgroup gets its
+  // share of tall and short ones
+  const int64_t n_items = (int64_t)a.npairs * a.N;
+  const int p_begin = (int)(n_items * xcd / 8), p_end = (int)(n_items * (xcd + 1) / 8);
   const unsigned xrowb = (unsigned)a.Fin * 4u, yrowb = (unsigned)a.ld * 4u;
 
   // ---- pieces shared by the two roles -------------------------------------------------------------------------------
@@ -852,7 +856,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
     }
     int handed = 0;  // hand-overs written so far by this wave; its L partner counts its top-of-step reads in the flag: the write
                      // at the end of step j (hand-over number j) may go ahead once L's read of step j has happened (flag >= j + 1)
-    for (int p = p_begin + slot0; p < p_end; p += nslots) {
+    for (int q = p_begin + slot0; q < p_end; q += nslots) {
+      const int p = q / a.N, nq = q - p * a.N;
       const StripPair pr = a.pairs[p];
       const int xs = strip ? pr.xs[1] : pr.xs[0];
       const unsigned sX = st_spread((unsigned)(xs + px));  // this lane's pixel column (the rows of L~)
@@ -860,7 +865,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
       auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
         return st_spread((unsigned)min(max(yrow, pr.ylo), pr.yhi)) << 1;
       };
-      for (int n = 0; n < a.N; ++n) {
+      for (int n = nq; n <= nq; ++n) {
         sp_f32x16 R[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -984,7 +989,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
     asm volatile("s_setprio 2");
 #endif
     int taken = 0;  // top-of-step reads done so far by this wave
-    for (int p = p_begin + slot0; p < p_end; p += nslots) {
+    for (int q = p_begin + slot0; q < p_end; q += nslots) {
+      const int p = q / a.N, nq = q - p * a.N;
       const StripPair pr = a.pairs[p];
       const int xs = strip ? pr.xs[1] : pr.xs[0], x0 = strip ? pr.x0[1] : pr.x0[0], wuse = strip ? pr.w[1] : pr.w[0];
       const unsigned sXc = st_spread((unsigned)(xs + 16 * ob + (lane & 15)));  // the pixel row its x chunks belong to
@@ -994,7 +1000,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void cheb_strip5_kernel(StripArgs a)
       auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
         return st_spread((unsigned)min(max(yrow, pr.ylo), pr.yhi)) << 1;
       };
-      for (int n = 0; n < a.N; ++n) {
+      for (int n = nq; n <= nq; ++n) {
         const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)n * a.x_rows * xrowb;
         char* __restrict__ ymap = reinterpret_cast<char*>(a.y) + (size_t)n * a.y_rows * yrowb;
         sp_f32x16 R[2][3], Y;

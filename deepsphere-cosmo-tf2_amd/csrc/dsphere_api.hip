@@ -155,9 +155,9 @@ int dsph_plan_tile_counts(const dsph_plan* p, int32_t K, int64_t* n_struct, int6
   return DSPH_OK;
 }
 
-int dsph_plan_strip_tiles(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t* n_tiles) {
+int dsph_plan_strip_tiles(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t* n_tiles) {
   if (!p || !n_tiles) { set_error("plan_strip_tiles: NULL argument"); return DSPH_E_BADARG; }
-  *n_tiles = fused_supported(p, Fin, Fout, K) ? fused_strip_tiles(p, Fin, Fout, K, precision) : 0;
+  *n_tiles = fused_supported(p, Fin, Fout, K) ? fused_strip_tiles(p, N, Fin, Fout, K, precision) : 0;
   return DSPH_OK;
 }
 

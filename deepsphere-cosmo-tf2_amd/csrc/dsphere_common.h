@@ -77,7 +77,7 @@ bool fused_host_released(FusedPlan* fp);
 int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
-int64_t fused_strip_tiles(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K, int32_t precision);
+int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision);
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,

@@ -39,7 +39,7 @@ SIGNATURES = {
     "dsph_plan_fused_ok": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
     "dsph_plan_prepare": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
     "dsph_plan_tile_counts": (ctypes.c_int, [_c_vp, _c_i32, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
-    "dsph_plan_strip_tiles": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32, _c_i32, ctypes.POINTER(_c_i64)]),
+    "dsph_plan_strip_tiles": (ctypes.c_int, [_c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, ctypes.POINTER(_c_i64)]),
     "dsph_workspace_bytes": (ctypes.c_size_t, [_c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32]),
     "dsph_cheb_forward": (
         ctypes.c_int,
@@ -186,10 +186,12 @@ class LaplacianPlan:
         check(lib().dsph_plan_tile_counts(self.handle, int(K), ctypes.byref(a), ctypes.byref(b)), "dsph_plan_tile_counts")
         return int(a.value), int(b.value)
 
-    def strip_tiles(self, Fin, Fout, K, precision=PREC_BF16X3):
-        """How many of the structured tiles a fused forward of this shape hands to the strip kernel (``dsph_plan_strip_tiles``)."""
+    def strip_tiles(self, Fin, Fout, K, precision=PREC_BF16X3, N=1):
+        """How many of the structured tiles a fused forward of this shape, on a batch of N maps, hands to the strip kernel
+        (``dsph_plan_strip_tiles``)."""
         n = _c_i64(0)
-        check(lib().dsph_plan_strip_tiles(self.handle, int(Fin), int(Fout), int(K), int(precision), ctypes.byref(n)), "dsph_plan_strip_tiles")
+        check(lib().dsph_plan_strip_tiles(self.handle, int(N), int(Fin), int(Fout), int(K), int(precision), ctypes.byref(n)),
+              "dsph_plan_strip_tiles")
         return int(n.value)
 
     def workspace_bytes(self, N, Fin, Fout, K, precision=PREC_FP32, algo=ALGO_AUTO):

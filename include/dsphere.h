@@ -127,11 +127,14 @@ int dsph_plan_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, i
 /* How many of those structured tiles a forward of this shape hands to the strip kernel instead (csrc/cheb_strip_kernel.h:
  * rectangles of at least 3 x 4 tiles whose regions are plain Z-order squares, streamed row by row in 32-column strips with
  * the recurrence in registers -- Clenshaw's backward form, fed by the MFMA).  0 when the strip kernel does not take the shape
- * (it implements K = 5, Fin = Fout = 64 per 64-column block, DSPH_PREC_BF16X3) or the plan holds no such rectangle; the
- * other tiles are served as dsph_plan_tile_counts says.  Same summation per output whichever kernel writes it?  No: the two
+ * (it implements K = 5, Fin = Fout = 64 per 64-column block, DSPH_PREC_BF16X3), the plan holds no such rectangle, or the
+ * strips would not pay for a batch of N maps (its work items are (pair of strips, map): small or ragged plans need a batch
+ * to fill the device; the rule is in csrc/cheb_fused.hip, strips_apply); the other tiles are served as dsph_plan_tile_counts
+ * says.  Same summation per output whichever kernel writes it?  No: the two
  * forms round differently (both within the tolerance of their precision), so outputs of tiles that change hands between
  * two plans of the same graph agree to rounding, not bit for bit. */
-int dsph_plan_strip_tiles(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t* n_tiles);
+int dsph_plan_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision,
+                          int64_t* n_tiles);
 
 /* Bytes of scratch dsph_cheb_forward needs for this call shape (0 is possible). */
 size_t dsph_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout,

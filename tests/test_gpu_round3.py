@@ -109,11 +109,23 @@ def test_strip_kernel_whole_map(nside, N, basis, act, use_bias):
 
 
 def test_small_maps_keep_their_tiles_on_the_tile_kernels():
-    """The cost comparison of cheb_fused.hip: at nside 128 there are 24 strip pairs for 256 CUs -- the tile kernels keep the map."""
+    """The cost comparison of cheb_fused.hip (strips_apply), made per call with the batch: the strip kernel's work items are
+    (pair of strips, map).  At nside 128 there are 24 pairs for 256 CUs: a single map stays on the tile kernels, a batch of 64
+    fills the device and goes to the strips -- and is still right."""
     cols, vals = _grid_ell(128)
     plan = _native.LaplacianPlan(cols, vals, device=0)
     plan.prepare(5, 64)
     assert plan.strip_tiles(64, 64, 5, _native.PREC_BF16X3) == 0
+    assert plan.strip_tiles(64, 64, 5, _native.PREC_BF16X3, N=2) == 0
+    assert plan.strip_tiles(64, 64, 5, _native.PREC_BF16X3, N=64) > 0
+    M, N, Fin, Fout, K = cols.shape[0], 64, 64, 64, 5
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), None, K, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    sel = [0, 17, 63]  # three maps of the batch against the oracle
+    ref = orc.chebyshev_forward(_csr(cols, vals), x[sel], W, K)
+    assert rel_err(y[sel].cpu().numpy(), ref) < TOL
 
 
 def test_strip_kernel_through_the_layer_default():
