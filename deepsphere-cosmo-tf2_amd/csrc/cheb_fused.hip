@@ -940,14 +940,17 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
       continue;
     }
     std::lock_guard<std::mutex> lock(fp->fork_mu);
-    DSPH_HIP(hipEventRecord(fp->ev_fork, stream));
-    DSPH_HIP(hipStreamWaitEvent(fp->side, fp->ev_fork, 0));
+    DSPH_HIP(hipEventRecord(fp->ev_fork, stream));             // (nothing is on the side stream yet: a failure here or in the
+    DSPH_HIP(hipStreamWaitEvent(fp->side, fp->ev_fork, 0));    //  next line leaves nothing to join)
     const int rc_b = run(fp->side, 2);
-    DSPH_HIP(hipEventRecord(fp->ev_join, fp->side));
+    const hipError_t e_rec = hipEventRecord(fp->ev_join, fp->side);
     const int rc_s = run(stream, 1);
-    DSPH_HIP(hipStreamWaitEvent(stream, fp->ev_join, 0));  // (also on an error: the side stream never outlives the call)
+    // the join happens whatever went wrong in between: the side stream never outlives the call
+    const hipError_t e_join = e_rec == hipSuccess ? hipStreamWaitEvent(stream, fp->ev_join, 0) : hipStreamSynchronize(fp->side);
     if (rc_b != DSPH_OK) return rc_b;
     if (rc_s != DSPH_OK) return rc_s;
+    if (e_rec != hipSuccess) return hip_fail(e_rec, "hipEventRecord(join)");
+    if (e_join != hipSuccess) return hip_fail(e_join, "join of the side stream");
   }
   if (defer_act && part != 1) {
     const int64_t orows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
