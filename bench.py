@@ -40,6 +40,9 @@ CONFIGS = {
     # configs[4] on ONE GPU (BASELINE quotes it on 8): partial sky, a spherical cap of 1/3 of the sphere padded to
     # nside-8 superpixels like utils.extend_indices, ragged tiles and border rows
     "c5": (1024, 5, 64, 64, 16),
+    # beyond BASELINE.json (side lines, never the headline): the order of the reference's tutorial layers
+    # (examples/quick_start.ipynb:118-127, HealpyChebyshev(K=10, ...)) at configs[1]'s map and channel counts
+    "k10": (256, 10, 16, 32, 8),
 }
 MASKED = {"c5"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
@@ -154,10 +157,21 @@ def measured_error(cols, vals, x, y, w_np, K, nside, seed=3, n_random=24):
     return float(np.abs(got - ref).max() / s_max), int(centres.size * x.shape[0])
 
 
-def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1):
+def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1, split="auto"):
     """Which kernels one fused forward launches: the strip kernel on the rectangles of plain structured tiles it takes for this
     shape (dsph_plan_strip_tiles), the structured-tile kernel on the other structured tiles, the BFS-tile kernel on the rest
     (dsph_plan_tile_counts)."""
+    if K > 5 and (split == "always" or (split == "auto" and K > 9)):
+        terms, k = [], K
+        while k > 5:
+            k -= 4
+            terms.append(5)
+        terms.append(k)
+        cz = (Fin + Fout + 3) // 4 * 4
+        return (f"{len(terms)} passes of {' / '.join(str(t) for t in reversed(terms))} terms (T_(4+j) = 2 T_4 T_j - T_|4-j|) through [x | u] of "
+                f"{cz} channels; last pass: " + fused_kernel_name(plan, 5, cz, Fout, prec_code, N))
+    if K > 9:
+        return f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
     n_struct, n_bfs = plan.tile_counts(K)
     n_strip = plan.strip_tiles(Fin, Fout, K, prec_code, N=N)
     parts = []
@@ -194,6 +208,10 @@ def main():
                          "or more input channels, else bf16x6).  bf16x3 = 3-term split-bf16 MFMA with fp32 accumulate (error "
                          "measured in the line); bf16x6 = fp32-equivalent 6-term split; fp32 = exact fp32 MFMA")
     ap.add_argument("--algo", default="auto", choices=["auto", "unfused", "fused"])
+    ap.add_argument("--split", default="auto", choices=["auto", "always", "never"],
+                    help="K > 5: the product-identity chain of K <= 5 passes (csrc/cheb_split.hip) -- plan option DSPH_OPT_SPLIT")
+    ap.add_argument("--strips", default="auto", choices=["auto", "always", "never"], help="plan option DSPH_OPT_STRIPS")
+    ap.add_argument("--quick", action="store_true", help="the headline leg only: no side legs in the other arithmetics, no CPU baseline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = halo rows "
                          "staged through the host, ranks dealt round-robin over the visible GPUs (debugging on a 1-GPU box)")
@@ -224,8 +242,10 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
-    from deepsphere import gnn_layers
+    from deepsphere import _native, gnn_layers
 
+    plan_options = {_native.OPT_SPLIT: {"auto": 0, "always": 1, "never": 2}[args.split],
+                    _native.OPT_STRIPS: {"auto": 0, "always": 1, "never": 2}[args.strips]}
     nside, K, Fin, Fout, N = CONFIGS[args.config]
     # what is timed is what a user of the layer gets: the layer's default arithmetic unless --precision says otherwise
     layer_default = args.precision is None
@@ -241,22 +261,23 @@ def main():
     if world == 1:
         layer = gnn_layers.Chebyshev.from_prepared_ell(
             cols, vals, K, lmax=lmax, Fout=Fout, device=device, precision=args.precision, algo=args.algo,
-            initializer=lambda t: t.copy_(torch.from_numpy(w_np)),
+            initializer=lambda t: t.copy_(torch.from_numpy(w_np)), plan_options=plan_options,
         )
         gen = torch.Generator(device=device).manual_seed(11)
         x = torch.randn((N, M, Fin), device=device, generator=gen)
         def run():
             with torch.no_grad():  # inference forward: bias/activation fused in the kernel epilogue
                 return layer(x)
-        fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-        kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
+        fused = (layer._get_plan().fused_ok(Fin, Fout, K) or (K > 9 and args.split != "never")) and args.algo != "unfused"
+        kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N, args.split) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
     else:
         from deepsphere import sharding
 
         # the ELL as a row producer: the rank reads its own rows and halo only, and learns its send lists from the
         # set-up gather of every rank's requests (sharding.ShardLayout)
         shard = sharding.ShardedChebyshev(lambda ids: (cols[ids], vals[ids]), None, K, Fout=Fout, rank=rank, world=world,
-                                          device=device, precision=resolved, algo=args.algo, kernel=w_np, M=M)
+                                          device=device, precision=resolved, algo=args.algo, kernel=w_np, M=M,
+                                          plan_options=plan_options)
         gen = torch.Generator(device=device).manual_seed(11 + rank)
         # this rank's rows live in the extended buffer the kernel reads (own rows, then halo rows): a producer
         # layer would write them there; no per-step copy
@@ -264,7 +285,7 @@ def main():
         x.normal_(generator=gen)
         run = lambda: shard(x)  # noqa: E731
         fused = shard.plan.fused_ok(Fin, Fout, K) and args.algo != "unfused"
-        kernel_name = (fused_kernel_name(shard.plan, K, Fin, Fout, prec_code, N) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \
+        kernel_name = (fused_kernel_name(shard.plan, K, Fin, Fout, prec_code, N, "never") if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel") + \
             " + rows_pack_kernel + " + \
             ("RCCL send/recv" if args.backend == "nccl" else "gloo send/recv (host-staged)") + " of the (K-1)-ring halo"
     setup_s = time.time() - t0
@@ -314,14 +335,14 @@ def main():
             replicas_note = f"replicas only: the sharded forward failed ({err or 'on another rank'})"
             layer = gnn_layers.Chebyshev.from_prepared_ell(
                 cols, vals, K, lmax=lmax, Fout=Fout, device=device, precision=args.precision, algo=args.algo,
-                initializer=lambda t: t.copy_(torch.from_numpy(w_np)))
+                initializer=lambda t: t.copy_(torch.from_numpy(w_np)), plan_options=plan_options)
             xr = torch.randn((N, M, Fin), device=device, generator=torch.Generator(device=device).manual_seed(11 + rank))
 
             def run():  # noqa: F811
                 with torch.no_grad():
                     return layer(xr)
             fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-            kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N) if fused else kernel_name
+            kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N, args.split) if fused else kernel_name
     # Warm up exactly as the timed loop runs: the previous output stays referenced while the next forward allocates its
     # own, so BOTH output blocks are in the caching allocator before the clock starts (a first-ever hipMalloc of a second
     # 12.9 GB block inside the timed region costs one forward 350 ms on a box whose memory has not been touched yet).
@@ -419,7 +440,7 @@ def main():
                 "min_max_forward_ms_hip_events": [round(float(np.min(per_fwd_ms)), 4), round(float(np.max(per_fwd_ms)), 4)],
             },
         }
-        if world == 1:
+        if world == 1 and not args.quick:
             # the same forward in the other contraction arithmetics, for the record (HIP events over `steps` forwards each).
             # Each leg's roofline is the largest of its lower bounds: algorithmic bytes at 8 TB/s, and the dense flops at the
             # peak of the pipe the arithmetic really runs on -- fp32 MFMA 157.3 TF/s; bf16 MFMA 2500 TF/s, counted three / six
@@ -445,14 +466,14 @@ def main():
                                          "flops": f_d, "hbm_frac": round(b_alg / (msq * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
                 del yq
             layer.precision = args.precision
-        if world == 1:
+        if world == 1 and not args.quick:
             # one run with bias + ReLU fused into the kernel epilogue
             layer.precision = args.precision
             layer.use_bias = True
             layer.bias = torch.nn.Parameter(torch.randn(1, 1, Fout, device=device))
             layer.activation, layer._act_code = gnn_layers._resolve_activation("relu")
             out["bias_relu"] = {"ms_per_step": round(timed_ms(run, max(args.steps, 20)), 4)}
-        if world == 1 and args.cpu_budget > 0:
+        if world == 1 and args.cpu_budget > 0 and not args.quick:
             out["cpu_baseline"] = cpu_baseline(K, Fin, Fout, device, args.cpu_budget)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -27,6 +27,7 @@
 // pre-swizzled LDS addresses stay in VGPRs across all slices and all maps of the batch.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <map>
@@ -72,8 +73,13 @@ struct FusedTiles {
   int n_pairs = 0;
   int64_t n_strip_tiles = 0;
   std::vector<int32_t> strip_steps;        // per pair, in list order: rows + run-in = strip steps of one map
-  std::map<int64_t, int64_t> strip_span;   // batch N -> steps of the busiest workgroup (strip_makespan; under FusedPlan::mu)
-  bool strip_forced = false;               // DSPH_STRIP_FORCE at build time: the cost gate is off
+  std::vector<StripPair> h_pairs;          // host copy of d_pairs (dsph_plan_strip_pairs: what the seam tests read)
+  mutable std::map<int64_t, int64_t> strip_span;  // batch N -> steps of the busiest workgroup (strip_makespan; under FusedPlan::mu)
+  bool strip_forced = false;               // DSPH_OPT_STRIPS = 1 when the tables were built: the cost gate is off
+  // every tile of the plan, the interior ones first (d_all[0 .. n_all_interior)): what a two-part launch with a deferred
+  // activation finishes per part (launch_struct_act_tiles)
+  int32_t* d_all = nullptr;
+  int n_all = 0, n_all_interior = 0;
   int32_t* d_rrest = nullptr;
   int n_rrest = 0, n_rrest_interior = 0;
 };
@@ -93,10 +99,11 @@ struct FusedPlan {
   // The BFS-tile launch of a forward writes tiles of y that the structured launches do not touch: it runs on this side stream,
   // forked from and joined back into the caller's stream by the two events (a few dozen face-corner tiles would otherwise
   // hold the whole device for the latency of one tile: 14 of the 44 us of BASELINE configs[0], 57 of 544 us of configs[1]).
-  // Created with the plan -- a forward allocates nothing; fork_mu keeps two host threads that share a plan from interleaving
-  // their record / wait pairs.  Capturable: the side stream joins the capture through the fork event and leaves it at the join.
+  // Created by dsph_plan_prepare on plans whose tables call for a fork (side_stream_ready) -- a prepared forward allocates
+  // nothing; fork_mu keeps two host threads that share a plan from interleaving their record / wait pairs.  Capturable: the side stream joins the capture through the fork event and leaves it at the join.
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_failed = false;
   std::mutex fork_mu;
 };
 
@@ -120,6 +127,7 @@ static void free_tiles(FusedTiles& ft) {
   if (ft.d_tabvals) (void)hipFree(ft.d_tabvals);
   if (ft.d_pairs) (void)hipFree(ft.d_pairs);
   if (ft.d_rrest) (void)hipFree(ft.d_rrest);
+  if (ft.d_all) (void)hipFree(ft.d_all);
   ft = FusedTiles();
 }
 
@@ -132,18 +140,34 @@ FusedPlan* fused_plan_build(const dsph_plan* plan, const int32_t* h_cols, const 
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0)
     fp->num_cu = prop.multiProcessorCount;
-  if (getenv("DSPH_NO_FORK") == nullptr) {
-    DeviceGuard guard(plan->device);
-    if (!guard.ok || hipStreamCreateWithFlags(&fp->side, hipStreamNonBlocking) != hipSuccess) fp->side = nullptr;
-    if (fp->side && (hipEventCreateWithFlags(&fp->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&fp->ev_join, hipEventDisableTiming) != hipSuccess)) {
-      if (fp->ev_fork) (void)hipEventDestroy(fp->ev_fork);
-      (void)hipStreamDestroy(fp->side);
-      fp->side = nullptr;
-      fp->ev_fork = fp->ev_join = nullptr;
-    }
-  }
   return fp;
+}
+
+// The side stream and its two events exist only on plans that fork (a network holds dozens of plans, most of which
+// never do): created by dsph_plan_prepare when the prepared tables call for it, or by the first forward that wants to fork --
+// unless that forward is being captured into a graph, in which case it runs on the one stream.  Under fork_mu.
+static bool side_stream_ready(const dsph_plan* plan, FusedPlan* fp, hipStream_t caller, bool may_create) {
+  if (fp->side) return true;
+  if (fp->side_failed || !may_create) return false;
+  if (caller != nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  }
+  DeviceGuard guard(plan->device);
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (!guard.ok || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { fp->side_failed = true; return false; }
+  if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    (void)hipStreamDestroy(st);
+    fp->side_failed = true;
+    return false;
+  }
+  fp->ev_fork = e0;
+  fp->ev_join = e1;
+  fp->side = st;
+  return true;
 }
 
 void fused_plan_destroy(FusedPlan* fp) {
@@ -326,8 +350,8 @@ static int64_t strip_makespan(const std::vector<int32_t>& steps, int64_t N, int 
 // the virtual Morton plane of the tile indices: tile t sits at (compress(t), compress(t >> 1))) of 3 to 5 tile columns and at
 // least 4 tile rows; a rectangle is cut into 32-column strips with 24 output columns each, two strips per workgroup item,
 // and into row segments sized so that the items fill the CUs evenly.  The other tiles stay with the tile kernels (`rest`).
-static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_cu, std::vector<StripPair>& pairs,
-                         std::vector<int32_t>& rest, int64_t* n_taken, std::vector<int32_t>& steps) {
+static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_cu, const PlanOptions& opt,
+                         std::vector<StripPair>& pairs, std::vector<int32_t>& rest, int64_t* n_taken, std::vector<int32_t>& steps) {
   steps.clear();
   pairs.clear();
   rest.clear();
@@ -354,8 +378,7 @@ static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_
   // full base pixel every column has the same run and nothing is left over; on a mask the rows a group does not share, and
   // stretches of fewer than 3 columns, stay with the tile kernels.)
   auto overlap = [](int a0, int a1, int b0, int b1, int* o0, int* o1) { *o0 = std::max(a0, b0); *o1 = std::min(a1, b1); return *o1 - *o0; };
-  const char* mr = getenv("DSPH_STRIP_MINROWS");  // (tuning: least height of a rectangle, in tiles)
-  const int min_rows = mr ? std::max(4, atoi(mr)) : 4;
+  const int min_rows = std::max(4, opt.strip_min_rows);  // (tuning, DSPH_OPT_STRIP_MINROWS: least height of a rectangle, in tiles)
   std::vector<Rect> take;
   for (size_t i = 0; i < runs.size(); ++i) {
     if (runs[i].used) continue;
@@ -396,6 +419,7 @@ static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_
     if (!r.used)
       for (int y = r.y0; y < r.y1; ++y) rest.push_back((int32_t)st_morton((unsigned)r.tx, (unsigned)y));
   std::sort(rest.begin(), rest.end());
+#ifdef DSPH_ABLATE  // (diagnostic build only: the shipped library reads no environment variable)
   if (getenv("DSPH_STRIP_DEBUG")) {
     long a3 = 0, a45 = 0;
     int hmin = 1 << 30, hmax = 0;
@@ -403,6 +427,7 @@ static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_
     fprintf(stderr, "build_strips: %zu rectangles (3 wide: %ld tiles, 4-5 wide: %ld tiles, heights %d..%d), %zu tiles left over\n",
             take.size(), a3, a45, take.empty() ? 0 : hmin, hmax, rest.size());
   }
+#endif
   if (take.empty()) return;
   // Segment height: every segment pays 2 D + 1 run-in rows, every workgroup should get the same number of steps.  Candidates
   // from the whole rectangle down to 256 rows (measured on the partial sky of BASELINE configs[4], batch 16, strips forced:
@@ -472,13 +497,15 @@ static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_
       if (best_span < 0 || span < best_span) { best_span = span; best_h = h; }
     }
   }
-  if (const char* sg = getenv("DSPH_STRIP_SEG")) best_h = std::max(16, atoi(sg));  // (tuning: the segment height, in rows)
+  if (opt.strip_seg > 0) best_h = std::max(16, opt.strip_seg);  // (tuning, DSPH_OPT_STRIP_SEG: the segment height, in rows)
   cut(best_h, pairs);
   steps_of(pairs, steps);
+#ifdef DSPH_ABLATE
   if (getenv("DSPH_STRIP_DEBUG"))
     fprintf(stderr, "build_strips: segments of %d rows, %zu pairs, busiest workgroup %ld / %ld / %ld steps for 1 / 4 / 16 maps; tile cost "
             "per map in the same unit %ld\n", best_h, pairs.size(), (long)strip_makespan(steps, 1, num_cu), (long)strip_makespan(steps, 4, num_cu),
             (long)strip_makespan(steps, 16, num_cu), (long)(*n_taken * 187 / (30 * num_cu)));
+#endif
 }
 
 // Breadth-first rings of every tile; uploads the tables.  Returns a reference to the cached entry.
@@ -515,7 +542,7 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   region.reserve((size_t)ntiles * 600);
   std::vector<int32_t> ring, next, interior, boundary, r_interior, r_boundary;
   std::vector<unsigned char> cls((size_t)ntiles, 0);
-  if (!full && D <= ST_DMAX && getenv("DSPH_NO_STRUCT") == nullptr) {
+  if (!full && D <= ST_DMAX && plan->opt.use_struct) {
     if (!fp->rows_tried) {
       fp->rows_tried = true;
       if (struct_build_rows(plan, &fp->d_gvals8, &fp->d_gdiag, &fp->d_rowflag) != DSPH_OK) {
@@ -530,8 +557,7 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
       std::fill(cls.begin(), cls.end(), 0);
   }
   // class-T candidates: whatever the classification left over, when the structured kernel is in play at all
-  const bool try_tables = !full && D <= ST_DMAX && getenv("DSPH_NO_STRUCT") == nullptr && getenv("DSPH_NO_TABLES") == nullptr &&
-                          fp->d_rowflag != nullptr;
+  const bool try_tables = !full && D <= ST_DMAX && plan->opt.use_struct && plan->opt.use_tables && fp->d_rowflag != nullptr;
   std::vector<int32_t> t_interior, t_boundary, trow_i, trow_b, e_row(ST_CELLS), h_key, h_slot;
   std::vector<float> tval_i, tval_b, e_val((size_t)ST_CELLS * ST_TABV);
   int rmax = 0, emax = 0;
@@ -659,6 +685,16 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
   };
   if (lcols.empty()) { lcols.push_back(0); lvals.push_back(0.f); }
+  std::vector<int32_t> all_tiles;  // every tile, whatever its class: interior ones first
+  all_tiles.insert(all_tiles.end(), r_interior.begin(), r_interior.end());
+  all_tiles.insert(all_tiles.end(), t_interior.begin(), t_interior.end());
+  all_tiles.insert(all_tiles.end(), interior.begin(), interior.end());
+  ft.n_all_interior = (int)all_tiles.size();
+  all_tiles.insert(all_tiles.end(), r_boundary.begin(), r_boundary.end());
+  all_tiles.insert(all_tiles.end(), t_boundary.begin(), t_boundary.end());
+  all_tiles.insert(all_tiles.end(), boundary.begin(), boundary.end());
+  ft.n_all = (int)all_tiles.size();
+  if (all_tiles.empty()) all_tiles.push_back(0);
   ft.n_interior = (int)interior.size();
   interior.insert(interior.end(), boundary.begin(), boundary.end());
   ft.n_part = (int)interior.size();
@@ -668,12 +704,13 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   ft.n_strip_tiles = 0;
   ft.strip_steps.clear();
   ft.strip_span.clear();
-  ft.strip_forced = getenv("DSPH_STRIP_FORCE") != nullptr;
-  if (!full && D <= SP_DMAX && getenv("DSPH_NO_STRIP") == nullptr)
-    build_strips(r_interior, D, fp->num_cu, pairs, rrest, &ft.n_strip_tiles, ft.strip_steps);
+  ft.strip_forced = plan->opt.strips == 1;
+  if (!full && D <= SP_DMAX && plan->opt.strips != 2)
+    build_strips(r_interior, D, fp->num_cu, plan->opt, pairs, rrest, &ft.n_strip_tiles, ft.strip_steps);
   else
     rrest = r_interior;
   ft.n_pairs = (int)pairs.size();
+  ft.h_pairs = pairs;
   ft.n_rrest_interior = (int)rrest.size();
   rrest.insert(rrest.end(), r_boundary.begin(), r_boundary.end());
   ft.n_rrest = (int)rrest.size();
@@ -701,6 +738,7 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
               up((void**)&ft.d_part, interior.data(), interior.size() * 4) &&
               up((void**)&ft.d_rlist, r_interior.data(), r_interior.size() * 4) &&
               up((void**)&ft.d_rrest, rrest.data(), rrest.size() * 4) &&
+              up((void**)&ft.d_all, all_tiles.data(), all_tiles.size() * 4) &&
               up((void**)&ft.d_pairs, pairs.data(), pairs.size() * sizeof(StripPair));
   if (!good) {
     FusedTiles keep = ft;
@@ -754,13 +792,19 @@ static bool supported_impl(const dsph_plan* plan, int32_t Fin, int32_t Fout, int
 // (fused_pad_kernel; the kernels load x in 16-byte pieces).  The first layer of every reference model has Fin = 1.
 static inline int32_t pad4(int32_t Fin) { return (Fin + 3) & ~3; }
 
+int fused_dmax() { return FUSED_DMAX; }
+
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
   return Fin >= 1 && supported_impl(plan, pad4(Fin), Fout, K, false);
 }
 
 int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags) {
   if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return DSPH_OK;  // nothing to build: the unfused path serves it
-  (void)get_tiles(plan, K - 1, want_full(plan, pad4(std::max(Fin, 1)), false));
+  const FusedTiles& ftp = get_tiles(plan, K - 1, want_full(plan, pad4(std::max(Fin, 1)), false));
+  if (ftp.ok && plan->opt.fork && ftp.n_r + ftp.n_t > 0 && ftp.n_part > 0) {  // a forward of this K may fork: the side stream exists before it
+    std::lock_guard<std::mutex> lock(plan->fused->fork_mu);
+    (void)side_stream_ready(plan, plan->fused, nullptr, true);
+  }
   if (flags & DSPH_PREPARE_BACKWARD) (void)get_tiles(plan, K - 1, true);
   if (flags & DSPH_PREPARE_RELEASE_HOST) {
     FusedPlan* fp = plan->fused;
@@ -787,10 +831,14 @@ bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int6
 // ~3.0 us, a 256-pixel tile of one map takes the tile kernels ~18.7 us of a CU (both measured at the headline shape): in units
 // of 0.1 us,   strips: (steps of the busiest workgroup, strip_makespan) x 30      tile kernels: tiles x N x 187 / CUs,
 // with 3 % in favour of the tile kernels.  Small maps (fewer items than CUs) and ragged masks at small batches lose that
-// comparison and keep their tiles on the tile kernels; DSPH_STRIP_FORCE (read when the tables are built) switches it off.
-static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t N) {
-  if (!(ft.n_pairs > 0 && precision == DSPH_PREC_BF16X3 && strip_shape_ok(Fin, Fout, K) &&
-        plan->n_cols * (int64_t)std::max(Fin, Fout) * 4 < (1ll << 32)))
+// comparison and keep their tiles on the tile kernels.  The rule depends on the batch and on the device's CU count, so the
+// same map can be summed in two different orders at two batch sizes (both within the tolerance of the precision); a caller
+// that needs batch- or shard-invariant bits fixes the choice per plan: dsph_plan_set_option(DSPH_OPT_STRIPS, 1 always | 2 never).
+//   Fout: the columns of THIS launch (one 64-column block of the layer); ld: the layer's row stride of y.
+static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t N,
+                         int32_t ld) {
+  if (!(ft.n_pairs > 0 && precision == DSPH_PREC_BF16X3 && strip_shape_ok(Fin, Fout, K) && ld % 4 == 0 &&
+        plan->n_cols * (int64_t)std::max(Fin, ld) * 4 < (1ll << 32)))
     return false;
   if (ft.strip_forced) return true;
   if (N < 1 || (int64_t)ft.strip_steps.size() * N > (1ll << 24)) return false;
@@ -798,19 +846,32 @@ static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fi
   int64_t span;
   {
     std::lock_guard<std::mutex> lock(fp->mu);
-    auto& cache = const_cast<FusedTiles&>(ft).strip_span;
-    auto it = cache.find(N);
-    if (it == cache.end()) it = cache.emplace(N, strip_makespan(ft.strip_steps, N, fp->num_cu)).first;
+    auto it = ft.strip_span.find(N);
+    if (it == ft.strip_span.end()) it = ft.strip_span.emplace(N, strip_makespan(ft.strip_steps, N, fp->num_cu)).first;
     span = it->second;
   }
   return span * 30 * 103 < ft.n_strip_tiles * N * 187 / fp->num_cu * 100;
 }
 
+// tiles a forward of this shape hands to the strip kernel: the same predicate the launch uses, for the layer's first 64-column
+// block (a layer with Fout = 96 runs its first block through the strips and reports them; one with Fout < 64 has none)
 int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision) {
-  if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX || Fin != pad4(Fin)) return 0;
+  if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX || Fin != pad4(Fin) || Fout < 64) return 0;
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
-  if (!ft.ok || Fout % 64 != 0) return 0;  // (wider layers: one launch per 64-column block, each through the strips)
-  return strips_apply(plan, ft, Fin, 64, K, precision, N) ? ft.n_strip_tiles : 0;
+  if (!ft.ok) return 0;
+  return strips_apply(plan, ft, Fin, 64, K, precision, N, Fout) ? ft.n_strip_tiles : 0;
+}
+
+// the strip pairs of the K-term tables, 12 int32 each: x0[2], w[2], xs[2], y0, y1, xlo, xhi, ylo, yhi (StripPair); returns how
+// many there are (also when cap is smaller), -1 when the plan has no fused tables for this K
+int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_t cap) {
+  if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return -1;
+  const FusedTiles& ft = get_tiles(plan, K - 1, false);
+  if (!ft.ok) return -1;
+  static_assert(sizeof(StripPair) == 12 * sizeof(int32_t), "StripPair is twelve int32");
+  const int64_t n = (int64_t)ft.h_pairs.size();
+  for (int64_t i = 0; i < n && i < cap; ++i) memcpy(out + 12 * i, &ft.h_pairs[(size_t)i], sizeof(StripPair));
+  return n;
 }
 
 // two fragment layouts: the BFS-tile kernel's and, behind it, the structured-tile kernel's
@@ -895,8 +956,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
     const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
     defer_act = ft.ok && ft.n_r + ft.n_t > 0;
   }
-  // (two-part launches: both parts write the pre-activation, the pass runs once over all output rows behind the BOUNDARY
-  // part -- the pair is always INTERIOR first, BOUNDARY second, dsphere.h)
+  // (two-part launches: each part writes the pre-activation of its tiles and then finishes exactly those tiles' rows)
   // Fin not a multiple of four: a zero-padded copy of x behind the weight fragments in the workspace (with a two-part
   // launch both parts copy: the halo rows arrive between them)
   const int32_t Fin_w = Fin;
@@ -921,7 +981,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
   // side stream (FusedPlan::side), forked behind whatever the caller's stream holds so far and joined before this call returns
   FusedPlan* fp = plan->fused;
   bool fork = false;
-  if (fp && fp->side && K >= 2 && K - 1 <= FUSED_DMAX) {
+  if (fp && plan->opt.fork && K >= 2 && K - 1 <= FUSED_DMAX) {
     const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
     const int ng = !ft.ok ? 0 : (part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior));
     // (worth its two event operations only when the structured launches run for a while: two tile-maps per CU and more --
@@ -934,27 +994,41 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
                                  std::min<int32_t>(64, Fout - cb), K, defer_act ? DSPH_ACT_NONE : act, precision, alpha_rest,
                                  beta_rest, workspace, workspace_bytes, st, nullptr, nullptr, Fout, part, Fin_w, only);
     };
-    if (!fork) {
-      const int rc = run(stream, 0);
-      if (rc != DSPH_OK) return rc;
-      continue;
+    if (fork) {
+      std::unique_lock<std::mutex> lock(fp->fork_mu);
+      if (side_stream_ready(plan, fp, stream, true)) {
+        DSPH_HIP(hipEventRecord(fp->ev_fork, stream));             // (nothing is on the side stream yet: a failure here or in the
+        DSPH_HIP(hipStreamWaitEvent(fp->side, fp->ev_fork, 0));    //  next line leaves nothing to join)
+        const int rc_b = run(fp->side, 2);
+        const hipError_t e_rec = hipEventRecord(fp->ev_join, fp->side);
+        const int rc_s = run(stream, 1);
+        // the join happens whatever went wrong in between: the side stream never outlives the call.  (Without the join
+        // event the only way to join is to wait for the side stream on the host -- not while the caller is capturing, where
+        // a synchronisation would invalidate the capture: the error goes back instead, the capture is lost either way.)
+        hipError_t e_join = hipSuccess;
+        if (e_rec == hipSuccess) e_join = hipStreamWaitEvent(stream, fp->ev_join, 0);
+        else {
+          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+          if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) e_join = hipStreamSynchronize(fp->side);
+        }
+        if (rc_b != DSPH_OK) return rc_b;
+        if (rc_s != DSPH_OK) return rc_s;
+        if (e_rec != hipSuccess) return hip_fail(e_rec, "hipEventRecord(join)");
+        if (e_join != hipSuccess) return hip_fail(e_join, "join of the side stream");
+        continue;
+      }
     }
-    std::lock_guard<std::mutex> lock(fp->fork_mu);
-    DSPH_HIP(hipEventRecord(fp->ev_fork, stream));             // (nothing is on the side stream yet: a failure here or in the
-    DSPH_HIP(hipStreamWaitEvent(fp->side, fp->ev_fork, 0));    //  next line leaves nothing to join)
-    const int rc_b = run(fp->side, 2);
-    const hipError_t e_rec = hipEventRecord(fp->ev_join, fp->side);
-    const int rc_s = run(stream, 1);
-    // the join happens whatever went wrong in between: the side stream never outlives the call
-    const hipError_t e_join = e_rec == hipSuccess ? hipStreamWaitEvent(stream, fp->ev_join, 0) : hipStreamSynchronize(fp->side);
-    if (rc_b != DSPH_OK) return rc_b;
-    if (rc_s != DSPH_OK) return rc_s;
-    if (e_rec != hipSuccess) return hip_fail(e_rec, "hipEventRecord(join)");
-    if (e_join != hipSuccess) return hip_fail(e_join, "join of the side stream");
+    const int rc = run(stream, 0);
+    if (rc != DSPH_OK) return rc;
   }
-  if (defer_act && part != 1) {
+  if (defer_act) {
     const int64_t orows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
-    return launch_struct_act(y, N * orows, Fout, Fout, act, stream);
+    if (part == 0) return launch_struct_act(y, N * orows, Fout, Fout, act, stream);
+    // a part finishes the rows of its own tiles only: INTERIOR and BOUNDARY can be issued in any order, repeated, or alone
+    const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
+    const int32_t* tl = part == 1 ? ft.d_all : ft.d_all + ft.n_all_interior;
+    const int nt = part == 1 ? ft.n_all_interior : ft.n_all - ft.n_all_interior;
+    return launch_struct_act_tiles(y, tl, nt, N, orows, Fout, Fout, act, stream);
   }
   return DSPH_OK;
 }
@@ -1069,8 +1143,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     sl.cheb = beta_rest != 0.f;
     sl.prep_weights = true;  // the first of the two launches packs the fragments
     // rectangles of interior class-R tiles: the strip kernel, when it has this shape; the class-R list shrinks to the rest
-    const bool strips = strips_apply(plan, ft, Fin, Fout, K, precision, N) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
-                        ld % 4 == 0 && plan->n_cols * (int64_t)ld * 4 < (1ll << 32);
+    const bool strips = strips_apply(plan, ft, Fin, Fout, K, precision, N, ld) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     if (strips && part != 2 && !dbg_only('b')) {
       StripLaunch st;
       st.x = x; st.w = w; st.bias = bias; st.y = y;
@@ -1082,6 +1155,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       st.npairs = ft.n_pairs; st.Fin = Fin; st.Fout = Fout; st.K = K; st.act = act; st.precision = precision; st.ld = ld;
       st.num_cu = plan->fused->num_cu;
       st.cheb = sl.cheb;
+      st.generic = plan->opt.strip_generic;
       const int rc = launch_cheb_strip(st, stream);
       if (rc != DSPH_OK) return rc;
     }

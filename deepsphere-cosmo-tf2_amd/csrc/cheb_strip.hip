@@ -69,8 +69,8 @@ int launch_cheb_strip(const StripLaunch& s, hipStream_t stream) {
   // (one workgroup per CU, fewer when there are fewer (pair, map) items; cheb_fused.hip's strip_makespan mirrors this)
   const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(s.num_cu, ((int64_t)s.npairs * s.N + 7) / 8 * 8));
   void (*kern)(StripArgs) = nullptr;
-  // K = 5: the hand-ordered instantiation; DSPH_STRIP_GENERIC=1 (diagnosis) and the other K: the generic kernel
-  static const bool generic = getenv("DSPH_STRIP_GENERIC") != nullptr;
+  // K = 5: the hand-ordered instantiation; DSPH_OPT_STRIP_GENERIC (diagnosis) and the other K: the generic kernel
+  const bool generic = s.generic;
 #define DSPH_SP_PICK(KK) (s.cheb ? cheb_strip_kernel<KK, 4, true> : cheb_strip_kernel<KK, 4, false>)
   switch (s.K) {
     case 2: kern = DSPH_SP_PICK(2); break;

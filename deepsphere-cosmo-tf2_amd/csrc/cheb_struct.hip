@@ -156,6 +156,32 @@ int launch_struct_act(float* y, int64_t rows, int32_t cols, int32_t ld, int32_t 
   return DSPH_OK;
 }
 
+// The same pass over the rows of a list of 256-row tiles, for every map: what one part of a two-part launch finishes (each part
+// finalises only the rows it wrote, so repeating a part or running it alone never touches the other part's rows).
+__global__ __launch_bounds__(256) void struct_act_tiles_kernel(float* __restrict__ y, const int32_t* __restrict__ tiles, int64_t y_rows,
+                                                               int cols, int ld, int act) {
+  const int64_t r0 = (int64_t)tiles[blockIdx.x] * 256;
+  const int64_t nr = y_rows - r0 < 256 ? y_rows - r0 : 256;
+  float* base = y + ((int64_t)blockIdx.y * y_rows + r0) * ld;
+  for (int64_t e = threadIdx.x; e < nr * cols; e += 256) {
+    const int64_t r = e / cols;
+    const int c = (int)(e - r * cols);
+    base[r * ld + c] = apply_act(base[r * ld + c], act);
+  }
+}
+
+int launch_struct_act_tiles(float* y, const int32_t* d_tiles, int ntiles, int64_t N, int64_t y_rows, int32_t cols, int32_t ld,
+                            int32_t act, hipStream_t stream) {
+  if (ntiles <= 0 || N <= 0) return DSPH_OK;
+  for (int64_t n0 = 0; n0 < N; n0 += 65535) {
+    const unsigned nn = (unsigned)(N - n0 < 65535 ? N - n0 : 65535);
+    hipLaunchKernelGGL(struct_act_tiles_kernel, dim3((unsigned)ntiles, nn), dim3(256), 0, stream, y + n0 * y_rows * ld, d_tiles, y_rows,
+                       (int)cols, (int)ld, (int)act);
+    DSPH_HIP(hipGetLastError());
+  }
+  return DSPH_OK;
+}
+
 // Skip connection of a residual block in one pass (dsph_residual_epilogue): four floats per thread where the pointers allow.
 template <bool BEFORE>
 __global__ __launch_bounds__(256) void residual_epilogue_kernel(float* __restrict__ y, const float* __restrict__ skip, int64_t n,

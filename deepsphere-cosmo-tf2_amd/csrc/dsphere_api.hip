@@ -125,6 +125,54 @@ int dsph_plan_set_levels(dsph_plan* p, int32_t n_levels, const int64_t* rows_at_
   return DSPH_OK;
 }
 
+int dsph_plan_set_option(dsph_plan* p, int32_t option, int64_t value) {
+  if (!p) { set_error("plan_set_option: plan is NULL"); return DSPH_E_BADARG; }
+  PlanOptions o = p->opt;
+  bool tables = true;  // the option changes what the tile tables hold
+  switch (option) {
+    case DSPH_OPT_STRIPS:
+      if (value < 0 || value > 2) { set_error("plan_set_option: DSPH_OPT_STRIPS takes 0 (cost rule), 1 (always), 2 (never)"); return DSPH_E_BADARG; }
+      o.strips = (int)value;
+      break;
+    case DSPH_OPT_STRUCT: o.use_struct = value != 0; break;
+    case DSPH_OPT_TABLES: o.use_tables = value != 0; break;
+    case DSPH_OPT_FORK: o.fork = value != 0; tables = false; break;
+    case DSPH_OPT_STRIP_SEG:
+      if (value < 0 || value > (1 << 20)) { set_error("plan_set_option: DSPH_OPT_STRIP_SEG takes rows, 0 = automatic"); return DSPH_E_BADARG; }
+      o.strip_seg = (int)value;
+      break;
+    case DSPH_OPT_STRIP_MINROWS:
+      if (value < 4 || value > (1 << 20)) { set_error("plan_set_option: DSPH_OPT_STRIP_MINROWS takes tiles, at least 4"); return DSPH_E_BADARG; }
+      o.strip_min_rows = (int)value;
+      break;
+    case DSPH_OPT_STRIP_GENERIC: o.strip_generic = value != 0; tables = false; break;
+    case DSPH_OPT_SPLIT:
+      if (value < 0 || value > 2) { set_error("plan_set_option: DSPH_OPT_SPLIT takes 0 (automatic), 1 (always), 2 (never)"); return DSPH_E_BADARG; }
+      o.split_order = (int)value;
+      tables = false;
+      break;
+    default: set_error("plan_set_option: unknown option %d", (int)option); return DSPH_E_BADARG;
+  }
+  if (tables && p->fused) {
+    if (fused_host_released(p->fused)) {
+      set_error("plan_set_option: the plan's host copy of L~ was released (DSPH_PREPARE_RELEASE_HOST); set options before preparing");
+      return DSPH_E_UNSUPPORTED;
+    }
+    DeviceGuard guard(p->device);
+    fused_plan_invalidate(p->fused);  // like dsph_plan_set_levels: the tables are rebuilt on the next prepare / forward
+  }
+  p->opt = o;
+  return DSPH_OK;
+}
+
+int dsph_plan_strip_pairs(const dsph_plan* p, int32_t K, int32_t* out, int64_t capacity, int64_t* n_pairs) {
+  if (!p || !n_pairs || capacity < 0 || (capacity > 0 && !out)) { set_error("plan_strip_pairs: bad arguments"); return DSPH_E_BADARG; }
+  const int64_t n = fused_strip_pairs(p, K, out, capacity);
+  if (n < 0) { *n_pairs = 0; set_error("plan_strip_pairs: the plan has no fused tables for K = %d", (int)K); return DSPH_E_UNSUPPORTED; }
+  *n_pairs = n;
+  return DSPH_OK;
+}
+
 int dsph_plan_prepare(dsph_plan* p, int32_t K, int32_t Fin, int32_t flags) {
   if (!p || K <= 0 || Fin <= 0 || (flags & ~(DSPH_PREPARE_BACKWARD | DSPH_PREPARE_RELEASE_HOST))) {
     set_error("plan_prepare: bad arguments (plan %p, K %d, Fin %d, flags %d)", (void*)p, K, Fin, flags);
@@ -132,6 +180,12 @@ int dsph_plan_prepare(dsph_plan* p, int32_t K, int32_t Fin, int32_t flags) {
   }
   DeviceGuard guard(p->device);
   if (!guard.ok) { set_error("plan_prepare: cannot select device %d", p->device); return DSPH_E_HIP; }
+  // a layer with more than five terms may run as a chain of passes (cheb_split.hip): then it is their tables that are
+  // built, not the breadth-first tables of depth K - 1.  (The output width is not an argument here; the tables depend on it
+  // only through the 4 GiB-per-map limit of the structured kernel, judged with Fout = Fin.)
+  if (K > 5 && p->n_cols == p->n_rows && p->levels.empty() &&
+      (p->opt.split_order == 1 || (p->opt.split_order == 0 && K - 1 > fused_dmax())))
+    return split_prepare(p, K, Fin, Fin, flags);
   return fused_prepare(p, K, Fin, flags);
 }
 
@@ -161,6 +215,15 @@ int dsph_plan_strip_tiles(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fo
   return DSPH_OK;
 }
 
+// K > 5 by the product identity (cheb_split.hip) instead of the breadth-first-table kernel (K <= 9) or the unfused kernels:
+// DSPH_OPT_SPLIT = always whenever the plan allows it; by default beyond the fused kernels' own reach (K >= 10, where the
+// alternative is the unfused path's K planes through HBM) and for 6 <= K <= 9 where the measured rule says so (use_split).
+static bool use_split(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo, int32_t part) {
+  if (K <= 5 || algo == DSPH_ALGO_UNFUSED || part != DSPH_PART_ALL || p->opt.split_order == 2) return false;
+  if (p->opt.split_order == 0 && K - 1 <= fused_dmax() && fused_supported(p, Fin, Fout, K)) return false;
+  return split_applicable(p, Fin, Fout, K);
+}
+
 static int resolve_algo(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo) {
   if (algo == DSPH_ALGO_UNFUSED) return DSPH_ALGO_UNFUSED;
   if (fused_supported(p, Fin, Fout, K)) return DSPH_ALGO_FUSED;
@@ -170,6 +233,7 @@ static int resolve_algo(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K
 size_t dsph_workspace_bytes(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                             int32_t precision, int32_t algo) {
   if (!p || N <= 0 || Fin <= 0 || K <= 0) return 0;
+  if (use_split(p, Fin, Fout, K, algo, DSPH_PART_ALL)) return split_workspace_bytes(p, N, Fin, Fout, K, precision);
   const int a = resolve_algo(p, Fin, Fout, K, algo);
   if (a == DSPH_ALGO_FUSED) return fused_workspace_bytes(p, N, Fin, Fout, K, precision);
   // unfused: planes 1..K-1, each (N, n_cols, Fin) fp32, 256-byte aligned
@@ -249,6 +313,11 @@ int dsph_poly_forward_part(const dsph_plan* p, const float* x, const float* w, c
     return DSPH_E_BADARG;
   }
   if (N == 0) return DSPH_OK;
+  if (use_split(p, Fin, Fout, K, algo, part)) {
+    DeviceGuard guard(p->device);
+    return launch_split_forward(p, x, w, bias, y, N, Fin, Fout, K, basis, act, precision, workspace, workspace_bytes,
+                                (hipStream_t)hip_stream);
+  }
   const int a = resolve_algo(p, Fin, Fout, K, algo);
   if (a < 0) { set_error("cheb_forward: fused kernel cannot run this plan/shape (Fin=%d Fout=%d K=%d)", Fin, Fout, K); return DSPH_E_UNSUPPORTED; }
   const size_t need = dsph_workspace_bytes(p, N, Fin, Fout, K, precision, a);

@@ -35,6 +35,19 @@ struct DeviceGuard {
 
 struct FusedPlan;  // tile decomposition for the single-launch kernel (cheb_fused.hip)
 
+// Per-plan choices of dsph_plan_set_option (include/dsphere.h: DSPH_OPT_*).  They belong to the plan, not to the process:
+// the library reads no environment variable on the product path.
+struct PlanOptions {
+  int strips = 0;            // DSPH_OPT_STRIPS: 0 cost rule per call, 1 always (when the shape is the kernel's), 2 never
+  bool use_struct = true;    // DSPH_OPT_STRUCT: structured-tile kernel for the tiles that verify as a 2-D stencil
+  bool use_tables = true;    // DSPH_OPT_TABLES: class-T tiles (per-tile tables) on the structured kernel
+  bool fork = true;          // DSPH_OPT_FORK: BFS-tile launch on the plan's side stream beside the structured ones
+  int strip_seg = 0;         // DSPH_OPT_STRIP_SEG: rows per strip segment (0: chosen by the makespan rule)
+  int strip_min_rows = 4;    // DSPH_OPT_STRIP_MINROWS: least height of a strip rectangle, in tiles
+  bool strip_generic = false;  // DSPH_OPT_STRIP_GENERIC: compiler-scheduled strip kernel instead of the hand-ordered one
+  int split_order = 0;       // DSPH_OPT_SPLIT: K > 5 by the product identity (0 auto, 1 always when possible, 2 never)
+};
+
 }  // namespace dsph
 
 // The opaque plan of the C ABI: the rescaled Laplacian in padded ELL form, resident in HBM.
@@ -46,6 +59,7 @@ struct dsph_plan {
   int32_t* d_cols = nullptr;  // [n_rows][W] row-major (wave-uniform row reads)
   float* d_vals = nullptr;    // [n_rows][W]
   std::vector<int64_t> levels;  // optional shrinking schedule, see dsph_plan_set_levels
+  dsph::PlanOptions opt;
   dsph::FusedPlan* fused = nullptr;
 };
 
@@ -78,6 +92,7 @@ int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
 int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision);
+int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_t cap);
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,
@@ -92,6 +107,15 @@ int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* 
                             void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                              int32_t precision);
+
+// K > 5 as a chain of passes with K <= 5 on the fused kernels (cheb_split.hip)
+int fused_dmax();
+bool split_applicable(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
+size_t split_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision);
+int split_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t Fout, int32_t flags);
+int launch_split_forward(const dsph_plan* plan, const float* x, const float* w, const float* bias, float* y, int64_t N, int32_t Fin,
+                         int32_t Fout, int32_t K, int32_t basis, int32_t act, int32_t precision, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream);
 
 // structured-tile kernel (cheb_struct.hip)
 struct StructLaunch {
@@ -114,6 +138,8 @@ bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
 size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K);
 int launch_cheb_struct(const StructLaunch& s, hipStream_t stream);
 int launch_struct_act(float* y, int64_t rows, int32_t cols, int32_t ld, int32_t act, hipStream_t stream);
+int launch_struct_act_tiles(float* y, const int32_t* d_tiles, int ntiles, int64_t N, int64_t y_rows, int32_t cols, int32_t ld,
+                            int32_t act, hipStream_t stream);
 int launch_residual_epilogue(float* y, const float* skip, int64_t n, float alpha, int32_t act, bool before, hipStream_t stream);
 
 // strip kernel (cheb_strip.hip): rectangles of class-R tiles, streamed in 32-column strips
@@ -127,6 +153,7 @@ struct StripLaunch {
   int32_t npairs, Fin, Fout, K, act, precision, ld, num_cu;
   bool cheb;
   bool prep_weights = true;
+  bool generic = false;      // DSPH_OPT_STRIP_GENERIC: the compiler-scheduled template also at K = 5
 };
 bool strip_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
 size_t strip_wimg_bytes(int32_t Fin, int32_t Fout, int32_t K);

@@ -20,6 +20,10 @@ ALGO_AUTO, ALGO_UNFUSED, ALGO_FUSED = 0, 1, 2
 PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
 PREPARE_BACKWARD, PREPARE_RELEASE_HOST = 1, 2
 BASIS_CHEBYSHEV, BASIS_MONOMIAL = 0, 1
+# dsph_plan_set_option (include/dsphere.h: DSPH_OPT_*)
+OPT_STRIPS, OPT_STRUCT, OPT_TABLES, OPT_FORK, OPT_STRIP_SEG, OPT_STRIP_MINROWS, OPT_STRIP_GENERIC, OPT_SPLIT = 1, 2, 3, 4, 5, 6, 7, 8
+STRIPS_AUTO, STRIPS_ALWAYS, STRIPS_NEVER = 0, 1, 2
+SPLIT_AUTO, SPLIT_ALWAYS, SPLIT_NEVER = 0, 1, 2
 
 _c_i64 = ctypes.c_int64
 _c_i32 = ctypes.c_int32
@@ -32,6 +36,8 @@ SIGNATURES = {
     "dsph_plan_create": (ctypes.c_int, [ctypes.POINTER(_c_vp), _c_i64, _c_i64, _c_i32, _c_vp, _c_vp, ctypes.c_int]),
     "dsph_plan_destroy": (None, [_c_vp]),
     "dsph_plan_set_levels": (ctypes.c_int, [_c_vp, _c_i32, _c_vp]),
+    "dsph_plan_set_option": (ctypes.c_int, [_c_vp, _c_i32, _c_i64]),
+    "dsph_plan_strip_pairs": (ctypes.c_int, [_c_vp, _c_i32, _c_vp, _c_i64, ctypes.POINTER(_c_i64)]),
     "dsph_plan_rows": (_c_i64, [_c_vp]),
     "dsph_plan_cols": (_c_i64, [_c_vp]),
     "dsph_plan_ell_width": (_c_i32, [_c_vp]),
@@ -137,7 +143,7 @@ def require_gpu():
 class LaplacianPlan:
     """Owner of one ``dsph_plan``: the rescaled Laplacian, padded ELL, resident on one GPU."""
 
-    def __init__(self, ell_cols, ell_vals, n_cols=None, device=0, levels=None):
+    def __init__(self, ell_cols, ell_vals, n_cols=None, device=0, levels=None, options=None):
         cols = np.ascontiguousarray(ell_cols, dtype=np.int32)
         vals = np.ascontiguousarray(ell_vals, dtype=np.float32)
         if cols.ndim != 2 or cols.shape != vals.shape:
@@ -155,6 +161,12 @@ class LaplacianPlan:
         self.levels = None
         if levels is not None:
             self.set_levels(levels)
+        for opt, value in (options or {}).items():
+            self.set_option(opt, value)
+
+    def set_option(self, option, value):
+        """``dsph_plan_set_option``: a per-plan choice (OPT_*), to be made before the tables of a K are built."""
+        check(lib().dsph_plan_set_option(self.handle, int(option), int(value)), "dsph_plan_set_option")
 
     def set_levels(self, levels):
         lv = np.ascontiguousarray(levels, dtype=np.int64)
@@ -193,6 +205,17 @@ class LaplacianPlan:
         check(lib().dsph_plan_strip_tiles(self.handle, int(N), int(Fin), int(Fout), int(K), int(precision), ctypes.byref(n)),
               "dsph_plan_strip_tiles")
         return int(n.value)
+
+    def strip_pairs(self, K):
+        """The strip kernel's work list for K terms (``dsph_plan_strip_pairs``): an int32 array [n_pairs, 12] of
+        x0[2], w[2], xs[2], y0, y1, xlo, xhi, ylo, yhi in the virtual Z-order plane of the row index."""
+        n = _c_i64(0)
+        check(lib().dsph_plan_strip_pairs(self.handle, int(K), _c_vp(), 0, ctypes.byref(n)), "dsph_plan_strip_pairs")
+        out = np.zeros((int(n.value), 12), dtype=np.int32)
+        if n.value:
+            check(lib().dsph_plan_strip_pairs(self.handle, int(K), out.ctypes.data, int(n.value), ctypes.byref(n)),
+                  "dsph_plan_strip_pairs")
+        return out
 
     def workspace_bytes(self, N, Fin, Fout, K, precision=PREC_FP32, algo=ALGO_AUTO):
         return int(lib().dsph_workspace_bytes(self.handle, int(N), int(Fin), int(Fout), int(K), int(precision),

@@ -75,10 +75,22 @@ DEFAULT_PRECISION = "auto"
 
 
 def resolve_precision(precision, Fin):
-    """The arithmetic a layer with ``Fin`` input channels runs for ``precision`` ("auto" | "fp32" | "bf16x3" | "bf16x6")."""
+    """The arithmetic a contraction over ``Fin`` input channels runs for ``precision`` ("auto" | "fp32" | "bf16x3" |
+    "bf16x6").  "auto" is resolved PER CONTRACTION: the forward with the layer's Fin, the input gradient -- the forward of
+    the transposed layer on dy -- with the layer's Fout (a 64 -> 1 layer runs its dx through the six-term split)."""
     if precision == "auto":
         return "bf16x3" if Fin >= 16 else "bf16x6"
     return precision
+
+
+def resolve_wgrad_precision(precision, n_terms):
+    """The arithmetic of the weight gradient: its contraction runs over the ``n_terms`` = N * M pixels of the batch, so the
+    three-term split's per-product error (<= 1.15e-5) averages out over thousands of terms -- "auto" takes it from 4,096
+    pixels on (measured 4-7e-6 of max|dW| at nside 16 and above) and exact fp32 below; "bf16x6" has no weight-gradient
+    kernel and runs exact fp32 (include/dsphere.h)."""
+    if precision == "auto":
+        return "bf16x3" if n_terms >= 4096 else "fp32"
+    return "fp32" if precision == "bf16x6" else precision
 
 
 class _ChebConvFunction(torch.autograd.Function):
@@ -122,13 +134,14 @@ class _ChebConvFunction(torch.autograd.Function):
             plan_t = layer._get_plan(transposed=True)
             kernel_t = kernel.detach().reshape(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()
             dx, layer._workspace_t = _native.cheb_forward(
-                plan_t, dy, kernel_t, None, K, act=_native.ACT_NONE, precision=layer._prec_code(),
+                plan_t, dy, kernel_t, None, K, act=_native.ACT_NONE,
+                precision=_PRECISIONS[resolve_precision(layer.precision, Fout)],
                 algo=_ALGOS[layer.algo], workspace=layer._workspace_t, basis=layer._basis)
         if ctx.needs_input_grad[1]:
             plan = layer._get_plan()
             dk, layer._workspace_w = _native.cheb_backward_weights(
                 plan, x, dy, K, basis=layer._basis, algo=_ALGOS[layer.algo], workspace=getattr(layer, "_workspace_w", None),
-                precision=layer._prec_code())
+                precision=_PRECISIONS[resolve_wgrad_precision(layer.precision, N * M)])
         return dx, dk, None
 
 
@@ -175,7 +188,9 @@ class Chebyshev(torch.nn.Module):
             default: current CUDA device), ``precision`` ("auto", the default: "bf16x3" -- the three-term bf16 split, 2-6e-6 of
             max|y| from the float64 oracle -- for 16 or more input channels, else "bf16x6" | "bf16x6": fp32-equivalent six-term
             split, 2-7e-7 | "fp32": exact-fp32 MFMA, bitwise an fp32 fma chain; the recurrence is fp32 in all of them; see
-            DEFAULT_PRECISION) and ``algo`` ("auto" | "unfused" | "fused").
+            DEFAULT_PRECISION), ``algo`` ("auto" | "unfused" | "fused") and ``plan_options`` (a dict of
+            ``_native.OPT_*`` -> value handed to ``dsph_plan_set_option``, e.g. ``{OPT_STRIPS: STRIPS_NEVER}`` for results
+            that do not depend on the batch size).
         """
         super().__init__()
         self.L = L
@@ -192,6 +207,7 @@ class Chebyshev(torch.nn.Module):
         device = kwargs.pop("device", None)
         precision = kwargs.pop("precision", DEFAULT_PRECISION)
         algo = kwargs.pop("algo", "auto")
+        self._plan_options = dict(kwargs.pop("plan_options", None) or {})
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         if algo not in _ALGOS:
@@ -258,7 +274,8 @@ class Chebyshev(torch.nn.Module):
                 raise RuntimeError("the Chebyshev forward needs a HIP device; there is no CPU fallback")
             index = dev.index if dev.index is not None else torch.cuda.current_device()
             self._device = torch.device("cuda", index)
-            self._plan = _native.LaplacianPlan(self._ell_cols, self._ell_vals, device=index)
+            self._plan = _native.LaplacianPlan(self._ell_cols, self._ell_vals, device=index,
+                                               options=getattr(self, "_plan_options", None))
         if not transposed:
             return self._plan
         if getattr(self, "_plan_t", None) is None:
@@ -274,7 +291,8 @@ class Chebyshev(torch.nn.Module):
                 At = A.T.tocsr()
                 At.sort_indices()
                 tc, tv = utils.csr_to_ell(At)
-                self._plan_t = _native.LaplacianPlan(tc, tv, device=self._device.index)
+                self._plan_t = _native.LaplacianPlan(tc, tv, device=self._device.index,
+                                                     options=getattr(self, "_plan_options", None))
         return self._plan_t
 
     def _prec_code(self):
@@ -372,6 +390,7 @@ class Chebyshev(torch.nn.Module):
         device = kwargs.pop("device", None)
         self.precision = kwargs.pop("precision", DEFAULT_PRECISION)
         self.algo = kwargs.pop("algo", "auto")
+        self._plan_options = dict(kwargs.pop("plan_options", None) or {})
         if self.precision not in _PRECISIONS or self.algo not in _ALGOS:
             raise ValueError("unknown precision or algo")
         self.kwargs = kwargs

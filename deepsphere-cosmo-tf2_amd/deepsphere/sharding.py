@@ -268,13 +268,15 @@ class ShardedChebyshev:
     ``_compute``: test seam -- a callable ``(layout, x_ext, kernel) -> y`` replacing the HIP forward so
     that the exchange logic can be exercised under gloo on CPU; never set by product code (``_compute_wgrad``:
     the same for the rank's partial weight gradient, ``(layout, x_ext, dy) -> dkernel``).
+    ``plan_options``: ``_native.OPT_*`` -> value for the rank's plan (``dsph_plan_set_option``), e.g. ``{OPT_STRIPS: STRIPS_NEVER}``
+    when the shards must reproduce the unsharded rows bit for bit whatever their size.
     Pass ``kernel`` (and ``bias``) as torch tensors that require grad and the call is differentiable: see
     ``_ShardedConvFunction`` (one more halo exchange for dx, one all-reduce of dkernel).
     """
 
     def __init__(self, ell_cols, ell_vals, K, Fout=None, rank=0, world=1, device=None, precision="fp32",
                  algo="auto", kernel=None, bias=None, act=_native.ACT_NONE, group=None, _compute=None, M=None,
-                 _compute_wgrad=None):
+                 _compute_wgrad=None, plan_options=None):
         import torch.distributed as dist
 
         gather = int(world) > 1 and dist.is_available() and dist.is_initialized()
@@ -310,7 +312,7 @@ class ShardedChebyshev:
             if self.device.type != "cuda":
                 raise RuntimeError("ShardedChebyshev computes on a HIP device only; there is no CPU fallback")
             self.plan = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols,
-                                              device=self.device.index, levels=lay.levels)
+                                              device=self.device.index, levels=lay.levels, options=plan_options)
         self._x_ext = None
         self._dy_ext = None
         self._xbufs = {}                # packed send / receive rows per extended buffer, see _exchange_buffers

@@ -109,6 +109,34 @@ int dsph_plan_set_levels(dsph_plan* plan, int32_t n_levels, const int64_t* rows_
 #define DSPH_PREPARE_RELEASE_HOST 2
 int dsph_plan_prepare(dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
 
+/* Per-plan choices.  The library reads no environment variable: what used to be process-global switches of the fused path
+ * are options of the plan, set before the tables of a K are built (dsph_plan_prepare or the first forward) -- setting one that
+ * changes the tables drops the cached ones, like dsph_plan_set_levels, and after DSPH_PREPARE_RELEASE_HOST returns
+ * DSPH_E_UNSUPPORTED.  Not thread-safe against forwards in flight on the same plan.
+ *   DSPH_OPT_STRIPS         0 (default): whether the strip kernel takes its rectangles is decided per call by a cost rule that
+ *                           depends on the batch N and the device's CU count (csrc/cheb_fused.hip, strips_apply) -- so the
+ *                           same map on the same plan can be summed in Clenshaw order at one batch size and in forward order
+ *                           at another, equal to rounding, not bit for bit; 1: always (when the shape is the kernel's);
+ *                           2: never.  1 and 2 make the choice independent of batch, device and sharding.
+ *   DSPH_OPT_STRUCT         1 (default) / 0: the structured-tile kernel for tiles that verify as a 2-D stencil; 0 sends
+ *                           every tile to the breadth-first-table kernel
+ *   DSPH_OPT_TABLES         1 (default) / 0: per-tile tables (base-pixel borders, halo rows) on the structured kernel
+ *   DSPH_OPT_FORK           1 (default) / 0: the BFS-tile launch of a large forward on a plan-owned side stream
+ *   DSPH_OPT_STRIP_SEG      rows per strip segment, 0 (default) = chosen by the makespan rule          (tuning)
+ *   DSPH_OPT_STRIP_MINROWS  least height of a strip rectangle in tiles, default 4                      (tuning)
+ *   DSPH_OPT_STRIP_GENERIC  0 (default) / 1: the compiler-scheduled strip kernel at K = 5              (diagnosis)
+ *   DSPH_OPT_SPLIT          K > 5: 0 (default) the faster of the two routes by rule, 1 always the product identity
+ *                           T_{4+j} = 2 T_4 T_j - T_{|4-j|} (passes of K <= 5 on the fast kernels), 2 never */
+#define DSPH_OPT_STRIPS 1
+#define DSPH_OPT_STRUCT 2
+#define DSPH_OPT_TABLES 3
+#define DSPH_OPT_FORK 4
+#define DSPH_OPT_STRIP_SEG 5
+#define DSPH_OPT_STRIP_MINROWS 6
+#define DSPH_OPT_STRIP_GENERIC 7
+#define DSPH_OPT_SPLIT 8
+int dsph_plan_set_option(dsph_plan* plan, int32_t option, int64_t value);
+
 int64_t dsph_plan_rows(const dsph_plan* plan);
 int64_t dsph_plan_cols(const dsph_plan* plan);
 int32_t dsph_plan_ell_width(const dsph_plan* plan);
@@ -135,6 +163,12 @@ int dsph_plan_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, i
  * two plans of the same graph agree to rounding, not bit for bit. */
 int dsph_plan_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision,
                           int64_t* n_tiles);
+
+/* The strip kernel's work list for K terms, for tests and tools: `out` receives up to `capacity` records of twelve int32 --
+ * x0[2], w[2] (first output column and output width of the two strips of the pair), xs[2] (column of lane 0), y0, y1 (output
+ * rows [y0, y1)), xlo, xhi, ylo, yhi (the clamp rectangle) -- in the virtual Z-order plane of the row index (x = even bits,
+ * y = odd bits of the row number); *n_pairs the number of pairs the plan holds (also when capacity is smaller). */
+int dsph_plan_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_t capacity, int64_t* n_pairs);
 
 /* Bytes of scratch dsph_cheb_forward needs for this call shape (0 is possible). */
 size_t dsph_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout,
@@ -169,9 +203,9 @@ int dsph_poly_forward(const dsph_plan* plan, const float* x, const float* w, con
  * a sharded plan the tiles that read no halo row of another rank; DSPH_PART_BOUNDARY = the others.  Launching
  * INTERIOR while the halo exchange is in flight and BOUNDARY after it hides the exchange behind the interior
  * (deepsphere/sharding.py).  INTERIOR + BOUNDARY write exactly the rows DSPH_PART_ALL writes, with the same bits.
- * The two calls are a pair, INTERIOR first: with an activation other than NONE / RELU the kernels write the pre-activation
- * in both parts and the BOUNDARY call finishes with one elementwise pass over all output rows (so y is final only after
- * the BOUNDARY call, and calling BOUNDARY without its INTERIOR partner applies the activation to rows it did not write). */
+ * Each part finalises exactly the rows of its own tiles (with an activation other than NONE / RELU: the kernels write the
+ * pre-activation and one elementwise pass over those tiles' rows follows inside the same call), so the two parts may be
+ * issued in either order, alone, or repeated. */
 #define DSPH_PART_ALL 0
 #define DSPH_PART_INTERIOR 1
 #define DSPH_PART_BOUNDARY 2

@@ -278,3 +278,90 @@ def chebyshev_backward(Lt, x, kernel, K, dy, dtype=np.float64):
         g = dy @ Wr[:, k, :].T  # (N, M, Fin)
         dx += chebyshev_planes(LtT, g, k + 1, dtype=dtype)[k]
     return dx, dW
+
+
+# ----------------------------------------------------------------------------------------
+# residual block: gnn_layers.GCNN_ResidualLayer, gnn_layers.py:312-413
+# ----------------------------------------------------------------------------------------
+
+
+def keras_batch_norm(v, axis=-1, training=False, moving_mean=None, moving_var=None, gamma=None, beta=None, eps=1e-3):
+    """``tf.keras.layers.BatchNormalization(axis=axis)`` at its defaults (epsilon 1e-3, center and scale on, gamma 1,
+    beta 0, moving mean 0 / variance 1 at creation; what GCNN_ResidualLayer builds at gnn_layers.py:376-377 from
+    ``bn_kwargs = {"axis": -1}``, :357-361).  training: statistics of the batch over every axis but ``axis`` (biased
+    variance); inference: the moving statistics.  Third-party arithmetic (Keras, not vendored): the published
+    definition (v - mean) / sqrt(var + eps) * gamma + beta."""
+    v = np.asarray(v)
+    ax = axis % v.ndim
+    red = tuple(a for a in range(v.ndim) if a != ax)
+    shape = [1] * v.ndim
+    shape[ax] = v.shape[ax]
+    if training:
+        mean, var = v.mean(axis=red, keepdims=True), v.var(axis=red, keepdims=True)
+    else:
+        mean = np.zeros(shape, v.dtype) if moving_mean is None else np.reshape(np.asarray(moving_mean, v.dtype), shape)
+        var = np.ones(shape, v.dtype) if moving_var is None else np.reshape(np.asarray(moving_var, v.dtype), shape)
+    out = (v - mean) / np.sqrt(var + v.dtype.type(eps))
+    if gamma is not None:
+        out = out * np.reshape(np.asarray(gamma, v.dtype), shape)
+    if beta is not None:
+        out = out + np.reshape(np.asarray(beta, v.dtype), shape)
+    return out
+
+
+def keras_layer_norm(v, axis=-1, gamma=None, beta=None, eps=1e-3):
+    """``tf.keras.layers.LayerNormalization(axis=axis)`` at its defaults (epsilon 1e-3; gnn_layers.py:373-374): every
+    sample normalised over ``axis`` with the biased variance, then gamma / beta over the same axes."""
+    v = np.asarray(v)
+    axes = (axis,) if isinstance(axis, int) else tuple(axis)
+    axes = tuple(a % v.ndim for a in axes)
+    mean, var = v.mean(axis=axes, keepdims=True), v.var(axis=axes, keepdims=True)
+    out = (v - mean) / np.sqrt(var + v.dtype.type(eps))
+    shape = [v.shape[a] if a in axes else 1 for a in range(v.ndim)]
+    if gamma is not None:
+        out = out * np.reshape(np.asarray(gamma, v.dtype), shape)
+    if beta is not None:
+        out = out + np.reshape(np.asarray(beta, v.dtype), shape)
+    return out
+
+
+def residual_forward(Lt, x, kernels, K, layer_type="CHEBY", layer_biases=(None, None), layer_activation=None,
+                     activation=None, act_before=False, use_bn=False, norm_type="batch_norm", bn_axis=-1,
+                     bn_params=(None, None), training=False, alpha=1.0, dtype=np.float64):
+    """Literal restatement of ``GCNN_ResidualLayer.call`` (gnn_layers.py:385-413).
+
+    Lt                the prepared Laplacian both sub-layers hold (they are built from the same ``layer_kwargs``, :364-369;
+                      CHEBY: ``prepare_L(L, 0.75)``, MONO: ``prepare_L(L, 1)``)
+    kernels           (kernel of layer1, kernel of layer2), each (K*F, F)
+    layer_biases      their biases or None; layer_activation: the ``activation`` entry of ``layer_kwargs`` (both layers)
+    bn_params         per norm layer None or a dict of ``keras_batch_norm`` / ``keras_layer_norm`` keyword arguments
+    The quirks kept: ``activation is None`` returns x + input, ``alpha`` ignored (:407-408); an unknown ``layer_type``
+    raises IOError (:370), an unknown ``norm_type`` ValueError (:379)."""
+    if layer_type == "CHEBY":
+        fwd = chebyshev_forward
+    elif layer_type == "MONO":
+        fwd = monomial_forward
+    else:
+        raise IOError(f"Layertype not understood: {layer_type}")
+    if use_bn and norm_type not in ("layer_norm", "batch_norm"):
+        raise ValueError(f"norm_type <{norm_type}> not understood!")
+
+    def norm(v, p):
+        p = dict(p or {})
+        if norm_type == "layer_norm":
+            return keras_layer_norm(v, axis=bn_axis, **p)
+        return keras_batch_norm(v, axis=bn_axis, training=training, **p)
+
+    inp = np.asarray(x, dtype=dtype)
+    v = fwd(Lt, inp, kernels[0], K, bias=layer_biases[0], activation=layer_activation, dtype=dtype)  # (:393)
+    if use_bn:  # (:396-397)
+        v = norm(v, bn_params[0])
+    v = fwd(Lt, v, kernels[1], K, bias=layer_biases[1], activation=layer_activation, dtype=dtype)  # (:400)
+    if use_bn:  # (:403-404)
+        v = norm(v, bn_params[1])
+    act = _resolve_activation(activation)
+    if act is None:  # (:407-408)
+        return v + inp
+    if act_before:  # (:410-411)
+        return act(v) + alpha * inp
+    return act(v + alpha * inp)  # (:413)

@@ -145,6 +145,39 @@ def _headline_check(cols, vals, N, Fin, Fout, K, prec, centres_extra=(), seed=11
     return plan, x, W, b, y, s
 
 
+def _interleave(x, y):
+    """Row number of the pixel at (x, y) of the virtual Z-order plane (x = even bits, y = odd bits)."""
+    def spread(v):
+        v = np.asarray(v, dtype=np.uint64)
+        out = np.zeros_like(v)
+        for b in range(32):
+            out |= ((v >> np.uint64(b)) & np.uint64(1)) << np.uint64(2 * b)
+        return out
+    return (spread(x) | (spread(y) << np.uint64(1))).astype(np.int64)
+
+
+def _strip_seam_rows(pairs):
+    """Deterministic centres on every seam of the strip kernel's cut (dsph_plan_strip_pairs): the first and last output row
+    of every segment, and in between one row a third of the way down, at the first and last output column of both strips
+    of every pair -- strip edges every 24 columns, the shifted narrow last strip of a rectangle (xs != x0 - 4), segment
+    ends every ~992 rows."""
+    xs, ys = [], []
+    for p in pairs:
+        x0, w, lane0, y0, y1 = p[0:2], p[2:4], p[4:6], int(p[6]), int(p[7])
+        rows = sorted({y0, y0 + 1, y1 - 2, y1 - 1, y0 + (y1 - y0) // 3})
+        for e in range(2):
+            if w[e] <= 0:
+                continue
+            cols_ = {int(x0[e]), int(x0[e]) + 1, int(x0[e] + w[e]) - 1, int(x0[e] + w[e]) - 2}
+            if lane0[e] != x0[e] - 4:
+                cols_.add(int(x0[e] + w[e] // 2))  # the shifted strip: a column in its middle too
+            for cx in cols_:
+                for ry in rows:
+                    xs.append(cx)
+                    ys.append(ry)
+    return np.unique(_interleave(np.array(xs), np.array(ys)))
+
+
 def test_headline_config_as_benchmarked():
     """BASELINE configs[2] exactly as bench.py times it: nside 1024, K 5, 64 -> 64, BATCH 4 (element offsets beyond
     2^32 in maps 2 and 3), split-bf16 contraction, fused kernels, bias + ReLU -- the patch oracle at rows in every
@@ -156,7 +189,14 @@ def test_headline_config_as_benchmarked():
     n_struct, n_bfs = plan.tile_counts(K)
     assert n_struct > 0.9 * (M // 256), "the headline map must run on the structured-tile kernel"
     assert N * M * Fin > 2 ** 31 and (N - 1) * M * Fout > 2 ** 31
-    centres = _special_rows(nside, M, np.random.default_rng(3))
+    # the kernel bench.py times is the one checked here: the cost rule must hand the strip kernel its rectangles at this
+    # batch on this device (if the rule flipped on another box the test would silently check other kernels)
+    assert plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N) == 46128, "12 base pixels x (62 x 62) interior class-R tiles"
+    pairs = plan.strip_pairs(K)
+    assert pairs.shape == (252, 12), "21 pairs per base pixel"
+    seams = _strip_seam_rows(pairs)
+    assert seams.size > 1500 and seams.max() < M
+    centres = np.unique(np.concatenate([_special_rows(nside, M, np.random.default_rng(3)), seams]))
     ref = _patch_reference(cols, vals, x, W, K, centres, bias=b, activation="relu")
     got = y[:, torch.as_tensor(centres).cuda()].cpu().numpy()
     err = np.abs(got - ref).max(axis=(1, 2)) / s
@@ -193,6 +233,15 @@ def test_config5_partial_sky_as_benchmarked():
     err = np.abs(got - ref).max() / s
     print(f"config 5 as benchmarked: M = {M}, {border.size} border rows, tiles {plan.tile_counts(K)}, err {err:.2e}")
     assert err < TOL
+    # the cost rule at this size and batch (0.95 of the tile cost): the strips are taken, as bench.py --config c5 times it
+    n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
+    assert n_strip > 0, "C5 at batch 16 runs its rectangles on the strip kernel"
+    seams = _strip_seam_rows(plan.strip_pairs(K)[::7])  # every seventh pair of the ragged cut
+    seams = seams[seams < M]
+    ref2 = _patch_reference(cols, vals, x[:2], W, K, seams, bias=b, activation="relu")
+    err2 = np.abs(y[:2, torch.as_tensor(seams).cuda()].cpu().numpy() - ref2).max() / s
+    print(f"  {n_strip} strip tiles, {seams.size} seam centres, err {err2:.2e}")
+    assert err2 < TOL
 
 
 def test_config4_full_size():

@@ -36,32 +36,18 @@ def _csr(cols, vals):
     return sparse.csr_matrix((vals.reshape(-1).astype(np.float64), cols.reshape(-1), np.arange(0, W * M + 1, W)), shape=(M, M))
 
 
-class _force_strips:
-    """Small maps do not pay for the strip kernel (fewer strip pairs than CUs: cheb_fused.hip weighs that when the tile tables
-    are built) -- DSPH_STRIP_FORCE, read at that moment, hands it every rectangle anyway, which is what these tests are about."""
-
-    def __enter__(self):
-        os.environ["DSPH_STRIP_FORCE"] = "1"
-
-    def __exit__(self, *exc):
-        del os.environ["DSPH_STRIP_FORCE"]
-
-
 def _strip_plan(cols, vals, K, Fin):
-    with _force_strips():
-        plan = _native.LaplacianPlan(cols, vals, device=0)
-        plan.prepare(K, Fin)
+    """Small maps do not pay for the strip kernel (fewer strip pairs than CUs: the cost rule of cheb_fused.hip) -- the plan option
+    DSPH_OPT_STRIPS = always hands it every rectangle anyway, which is what these tests are about."""
+    plan = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
+    plan.prepare(K, Fin)
     return plan
 
 
 def _plan_without_strips(cols, vals, K, Fin):
-    """The same plan with the strip kernel switched off (DSPH_NO_STRIP is read when the tile tables are built)."""
-    os.environ["DSPH_NO_STRIP"] = "1"
-    try:
-        plan = _native.LaplacianPlan(cols, vals, device=0)
-        plan.prepare(K, Fin)
-    finally:
-        del os.environ["DSPH_NO_STRIP"]
+    """The same plan with the strip kernel switched off (DSPH_OPT_STRIPS = never)."""
+    plan = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_STRIPS: _native.STRIPS_NEVER})
+    plan.prepare(K, Fin)
     return plan
 
 
@@ -140,8 +126,9 @@ def test_strip_kernel_through_the_layer_default():
     x = rng.standard_normal((N, M, Fin)).astype(np.float32)
     W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
     layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=Fout, device="cuda:0", activation="relu",
-                                                   initializer=lambda t: t.copy_(torch.from_numpy(W)))
-    with _force_strips(), torch.no_grad():
+                                                   initializer=lambda t: t.copy_(torch.from_numpy(W)),
+                                                   plan_options={_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
+    with torch.no_grad():
         y = layer(_dev(x))
     assert layer._prec_code() == _native.PREC_BF16X3
     assert layer._get_plan().strip_tiles(Fin, Fout, K, layer._prec_code()) > 0
@@ -236,8 +223,6 @@ def _two_rank_worker(rank, world, port, act_name, out):
         torch.cuda.set_device(0)
         strips = act_name.endswith("+strips")  # the strip kernel's shape on a map with rectangles, the cost rule switched off
         act_name = act_name.split("+")[0]
-        if strips:
-            os.environ["DSPH_STRIP_FORCE"] = "1"
         nside, K, Fin, Fout, N = (256, 5, 64, 64, 2) if strips else (64, 5, 16, 32, 2)
         cols, vals = _grid_ell(nside)
         M = cols.shape[0]
@@ -247,7 +232,8 @@ def _two_rank_worker(rank, world, port, act_name, out):
         b = rng.standard_normal(Fout).astype(np.float32)
         act = {"none": _native.ACT_NONE, "relu": _native.ACT_RELU, "elu": _native.ACT_ELU}[act_name]
         sh = sharding.ShardedChebyshev(cols, vals, K, rank=rank, world=world, device="cuda:0", precision="bf16x3",
-                                       algo="fused", kernel=W, bias=b, act=act)
+                                       algo="fused", kernel=W, bias=b, act=act,
+                                       plan_options={_native.OPT_STRIPS: _native.STRIPS_ALWAYS} if strips else None)
         a, e = sh.layout.own
         xl = _dev(x[:, a:e].copy())
         ys = [sh(xl).clone() for _ in range(3)]
@@ -313,7 +299,7 @@ def test_two_ranks_on_one_gpu_real_exchange(act):
 
 def test_side_stream_launch_changes_no_bit():
     """Round 3: with enough work the BFS-tile launch of a forward runs on the plan's side stream, forked from and joined into the
-    caller's stream.  Same kernels, same tiles: the result equals the single-stream one (DSPH_NO_FORK, read at plan creation) bit
+    caller's stream.  Same kernels, same tiles: the result equals the single-stream one (plan option DSPH_OPT_FORK = 0) bit
     for bit, on the default stream and on a stream of the caller's, also when the output buffer is reused at once."""
     cols, vals = _grid_ell(64)
     M, N, Fin, Fout, K = cols.shape[0], 6, 16, 32, 5
@@ -321,11 +307,7 @@ def test_side_stream_launch_changes_no_bit():
     x = _dev(rng.standard_normal((N, M, Fin)).astype(np.float32))
     W = _dev((rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32))
     b = _dev(rng.standard_normal(Fout).astype(np.float32))
-    os.environ["DSPH_NO_FORK"] = "1"
-    try:
-        plan0 = _native.LaplacianPlan(cols, vals, device=0)
-    finally:
-        del os.environ["DSPH_NO_FORK"]
+    plan0 = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_FORK: 0})
     plan1 = _native.LaplacianPlan(cols, vals, device=0)
     ns, nb = plan1.tile_counts(K)
     assert ns > 0 and nb > 0 and N * ns >= 512  # both kinds of tiles, and past the fork's work threshold

@@ -1,0 +1,335 @@
+"""Round-4 GPU tests (all through the C ABI): the parity gaps VERDICT r3 listed -- BASELINE configs[1] as bench.py times it,
+the sharded form of configs[3] at its full size, the residual block against its oracle restatement on a k-NN graph --
+the per-plan options that replaced the environment switches, the two-part launch finishing only its own rows, and
+K > 5 through the product identity (passes of K <= 5 on the fast kernels)."""
+
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+from deepsphere import _native, gnn_layers, healpix, utils
+from helpers import rel_err
+from oracle import cheb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # max|y - y_ref| <= 1e-5 max|y_ref| against the float64 oracle, whatever the arithmetic
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+def _grid_ell(nside):
+    import bench
+
+    cols, vals, _ = bench.build_laplacian(nside, torch.device("cuda", 0))
+    return cols, vals
+
+
+def _csr(cols, vals):
+    M, W = cols.shape
+    return sparse.csr_matrix((vals.reshape(-1).astype(np.float64), cols.reshape(-1), np.arange(0, W * M + 1, W)), shape=(M, M))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[1] exactly as `bench.py --config c2` times it
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+def test_config2_as_benchmarked():
+    """nside 256, K 5, 16 -> 32, batch 8, the layer default for 16 input channels (three-term split), fused kernels, bias + ReLU:
+    the WHOLE map of every batch element against the float64 oracle (one map at a time: the op is batch independent)."""
+    nside, N, Fin, Fout, K = 256, 8, 16, 32, 5
+    assert gnn_layers.resolve_precision(gnn_layers.DEFAULT_PRECISION, Fin) == "bf16x3"
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    plan.prepare(K, Fin)
+    n_struct, n_bfs = plan.tile_counts(K)
+    assert n_struct == 3048 and n_bfs == 24, "every tile but the 24 at the sphere's 7-neighbour vertices is structured"
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((N, M, Fin), device="cuda", generator=gen)
+    rng = np.random.default_rng(13)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    y, _ = _native.cheb_forward(plan, x, _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=_native.PREC_BF16X3,
+                                algo=_native.ALGO_FUSED)
+    Lt = _csr(cols, vals)
+    worst = 0.0
+    for n in range(N):
+        ref = orc.chebyshev_forward(Lt, x[n : n + 1].cpu().numpy(), W, K, bias=b, activation="relu")
+        worst = max(worst, rel_err(y[n : n + 1].cpu().numpy(), ref))
+    print(f"config 2 as benchmarked: {n_struct} + {n_bfs} tiles, worst map error {worst:.2e}")
+    assert worst < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the sharded form of BASELINE configs[3] at its full size, every rank's plan on the one GPU
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+def test_config4_shards_at_full_size():
+    """nside 2048, K 8, 32 -> 32, batch 1, split over 4 ranks (3 base pixels each, 7-ring halo): every rank's local plan run
+    on this GPU with its halo rows taken from the global map must reproduce the unsharded rows BIT FOR BIT (both sides on
+    the breadth-first-table kernel: DSPH_OPT_SPLIT = never on the unsharded plan, a plan with levels never splits)."""
+    from deepsphere import sharding
+
+    nside, N, Fin, Fout, K, world = 2048, 1, 32, 32, 8, 4
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn((N, M, Fin), device="cuda", generator=gen)
+    rng = np.random.default_rng(44)
+    W = _dev((rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32))
+    plan = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_SPLIT: _native.SPLIT_NEVER})
+    full, _ = _native.cheb_forward(plan, x, W, None, K, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    plan.close()
+    for r in range(world):
+        lay = sharding.ShardLayout(cols, vals, K, r, world)
+        a, e = lay.own
+        assert e - a == 3 * nside * nside and lay.n_cols > lay.n_own
+        lp = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols, device=0, levels=lay.levels)
+        xl = x[:, torch.as_tensor(lay.local_ids).cuda()].contiguous()
+        y, _ = _native.cheb_forward(lp, xl, W, None, K, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+        same = bool(torch.equal(y, full[:, a:e]))
+        print(f"rank {r}: rows [{a}, {e}), {lay.n_cols - lay.n_own} halo rows, equal {same}")
+        assert same, f"rank {r}: a shard must reproduce the unsharded rows bit for bit"
+        lp.close()
+        del y, xl
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# VERDICT r3 item 2e / SURVEY 8 f2: the residual block against oracle.residual_forward on a graph that is not the identity
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+def _set_norm(mod, rng, F):
+    with torch.no_grad():
+        p = {"gamma": rng.standard_normal(F) * 0.5 + 1.0, "beta": rng.standard_normal(F) * 0.3}
+        mod.weight.copy_(torch.from_numpy(p["gamma"]).float())
+        mod.bias.copy_(torch.from_numpy(p["beta"]).float())
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            p["moving_mean"], p["moving_var"] = rng.standard_normal(F) * 0.2, rng.random(F) + 0.5
+            mod.running_mean.copy_(torch.from_numpy(p["moving_mean"]).float())
+            mod.running_var.copy_(torch.from_numpy(p["moving_var"]).float())
+    return p
+
+
+@pytest.mark.parametrize("layer_type,activation,act_before,alpha,norm", [
+    ("CHEBY", "relu", False, 0.5, None),
+    ("CHEBY", "elu", True, 0.25, None),
+    ("CHEBY", None, False, 7.0, None),            # alpha ignored without an activation (gnn_layers.py:407-408)
+    ("MONO", "tanh", False, 1.0, None),
+    ("CHEBY", "relu", False, 1.0, "batch_norm"),  # Keras defaults: epsilon 1e-3, affine, moving statistics in inference
+    ("CHEBY", "relu", True, 0.5, "layer_norm"),
+])
+def test_residual_block_against_the_oracle_on_a_knn_graph(layer_type, activation, act_before, alpha, norm):
+    """GCNN_ResidualLayer (reference gnn_layers.py:312-413) on the reference's kind of graph -- symmetrised 8-nearest-neighbour
+    HEALPix Laplacian, nside 16 -- with the sub-layers' own bias and activation: values against the float64 restatement
+    (oracle.residual_forward), inference mode, skip connection through the one-pass HIP epilogue."""
+    nside, N, F, K = 16, 3, 8, 4
+    L = healpix.healpix_laplacian(nside, n_neighbors=8, mode="knn")
+    M = L.shape[0]
+    rng = np.random.default_rng(sum(map(ord, repr((layer_type, activation, act_before, norm)))))
+    kw = {"L": L, "K": K, "use_bias": True, "activation": "relu", "device": "cuda:0", "precision": "bf16x6"}
+    block = gnn_layers.GCNN_ResidualLayer(layer_type, kw, activation=activation, act_before=act_before, alpha=alpha,
+                                          use_bn=norm is not None, norm_type=norm or "batch_norm")
+    x = rng.standard_normal((N, M, F)).astype(np.float32)
+    block.eval()
+    with torch.no_grad():
+        block(_dev(x))  # builds the sub-layers and the norm modules
+        k1 = (rng.standard_normal((F * K, F)) * 0.3).astype(np.float32)
+        k2 = (rng.standard_normal((F * K, F)) * 0.3).astype(np.float32)
+        b1, b2 = rng.standard_normal(F).astype(np.float32) * 0.1, rng.standard_normal(F).astype(np.float32) * 0.1
+        block.layer1.kernel.copy_(torch.from_numpy(k1))
+        block.layer2.kernel.copy_(torch.from_numpy(k2))
+        block.layer1.bias.copy_(torch.from_numpy(b1).reshape(1, 1, F))
+        block.layer2.bias.copy_(torch.from_numpy(b2).reshape(1, 1, F))
+        bn_params = (None, None)
+        if norm is not None:
+            bn_params = (_set_norm(block.bn1, rng, F), _set_norm(block.bn2, rng, F))
+        y = block(_dev(x)).cpu().numpy()
+    Lt, _ = orc.prepare_L(L, scale=0.75 if layer_type == "CHEBY" else 1.0)
+    ref = orc.residual_forward(Lt, x, (k1, k2), K, layer_type=layer_type, layer_biases=(b1, b2), layer_activation="relu",
+                               activation=activation, act_before=act_before, use_bn=norm is not None,
+                               norm_type=norm or "batch_norm", bn_params=bn_params, training=False, alpha=alpha)
+    err = rel_err(y, ref)
+    print(f"residual {layer_type} act={activation} before={act_before} norm={norm}: err {err:.2e}")
+    assert err < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# VERDICT r3 item 8 / ADVICE r3: plan options instead of environment switches; parts finish only their own rows
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+def test_plan_options_replace_the_environment_switches():
+    """dsph_plan_set_option: strips always / never fix the kernel choice independently of the batch; the structured and
+    table switches move tiles between the kernels; bad values are DSPH_E_BADARG; every combination computes the same map
+    to rounding."""
+    nside, K, Fin, Fout = 128, 5, 64, 64
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(9)
+    x = _dev(rng.standard_normal((1, M, Fin)).astype(np.float32))
+    W = _dev((rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32))
+    kw = dict(precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    assert plan.strip_tiles(Fin, Fout, K, N=1) == 0 and plan.strip_tiles(Fin, Fout, K, N=64) > 0  # the cost rule sees the batch
+    y_auto, _ = _native.cheb_forward(plan, x, W, None, K, **kw)
+    plan.set_option(_native.OPT_STRIPS, _native.STRIPS_ALWAYS)
+    n_always = plan.strip_tiles(Fin, Fout, K, N=1)
+    assert n_always > 0 and plan.strip_tiles(Fin, Fout, K, N=64) == n_always
+    assert plan.strip_tiles(Fin, 96, K, N=1) == n_always and plan.strip_tiles(Fin, 32, K, N=1) == 0  # first 64-column block
+    y_strips, _ = _native.cheb_forward(plan, x, W, None, K, **kw)
+    plan.set_option(_native.OPT_STRIPS, _native.STRIPS_NEVER)
+    assert plan.strip_tiles(Fin, Fout, K, N=64) == 0
+    y_never, _ = _native.cheb_forward(plan, x, W, None, K, **kw)
+    assert torch.equal(y_never, y_auto)  # one map at nside 128: the rule had left the strips out
+    s = float(y_auto.abs().max())
+    assert 0 < float((y_strips - y_auto).abs().max()) / s < 2 * TOL
+    ns0, nb0 = plan.tile_counts(K)
+    plan.set_option(_native.OPT_TABLES, 0)
+    ns1, nb1 = plan.tile_counts(K)
+    assert ns1 < ns0 and ns1 + nb1 == ns0 + nb0
+    plan.set_option(_native.OPT_STRUCT, 0)
+    assert plan.tile_counts(K) == (0, ns0 + nb0)
+    y_bfs, _ = _native.cheb_forward(plan, x, W, None, K, **kw)
+    assert float((y_bfs - y_auto).abs().max()) / s < 2 * TOL
+    for opt, bad in ((_native.OPT_STRIPS, 3), (_native.OPT_STRIP_MINROWS, 1), (99, 0), (_native.OPT_SPLIT, -1)):
+        with pytest.raises(ValueError):
+            plan.set_option(opt, bad)
+    plan.set_option(_native.OPT_STRUCT, 1)
+    plan.prepare(K, Fin, release_host=True)
+    with pytest.raises(RuntimeError):
+        plan.set_option(_native.OPT_TABLES, 1)  # the tables cannot be rebuilt any more
+    plan.set_option(_native.OPT_FORK, 0)  # does not touch the tables: still allowed
+
+
+@pytest.mark.parametrize("act", [_native.ACT_ELU, _native.ACT_TANH])
+def test_parts_finish_only_their_own_rows(act):
+    """with a deferred activation the BOUNDARY call used to run the elementwise pass over ALL output rows, so a
+    repeated or lone BOUNDARY call re-applied it to interior rows.  Each part now finalises exactly its tiles: either order,
+    repeated, or alone."""
+    from deepsphere import sharding
+
+    nside, K, Fin, Fout, N = 64, 5, 16, 32, 2
+    cols, vals = _grid_ell(nside)
+    lay = sharding.ShardLayout(cols, vals, K, 0, 2)
+    plan = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols, device=0, levels=lay.levels)
+    rng = np.random.default_rng(31)
+    x = _dev(rng.standard_normal((N, lay.n_cols, Fin)).astype(np.float32))
+    W = _dev((rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32))
+    b = _dev(rng.standard_normal(Fout).astype(np.float32))
+    kw = dict(act=act, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    whole, ws = _native.cheb_forward(plan, x, W, b, K, **kw)
+    out = torch.full_like(whole, float("nan"))
+    for part in (_native.PART_BOUNDARY, _native.PART_BOUNDARY, _native.PART_INTERIOR, _native.PART_INTERIOR):
+        _native.cheb_forward(plan, x, W, b, K, part=part, out=out, workspace=ws, **kw)
+    assert torch.equal(out, whole)
+    lone = torch.full_like(whole, float("nan"))
+    _native.cheb_forward(plan, x, W, b, K, part=_native.PART_BOUNDARY, out=lone, workspace=ws, **kw)
+    wrote = ~torch.isnan(lone)
+    assert bool(wrote.any()) and not bool(wrote.all())
+    assert torch.equal(lone[wrote], whole[wrote])  # the rows it wrote are final, the others untouched
+
+
+def test_backward_precision_is_resolved_per_contraction():
+    """"auto" used the layer's forward Fin for the input gradient too.  A 64 -> 4 layer runs its forward in the
+    three-term split and its dx (a contraction over 4 * K inputs) in the six-term split; gradients against the float64
+    oracle at the default, 1e-5 for dx, 2e-5 for dkernel."""
+    assert gnn_layers.resolve_precision("auto", 64) == "bf16x3" and gnn_layers.resolve_precision("auto", 4) == "bf16x6"
+    assert gnn_layers.resolve_wgrad_precision("auto", 49152) == "bf16x3" and gnn_layers.resolve_wgrad_precision("auto", 768) == "fp32"
+    assert gnn_layers.resolve_wgrad_precision("bf16x6", 10 ** 6) == "fp32"
+    nside, N, Fin, Fout, K = 32, 2, 64, 4, 5
+    L = healpix.healpix_laplacian(nside, mode="grid")
+    Lt, _ = orc.prepare_L(L)
+    cols, vals = utils.csr_to_ell(Lt)
+    rng = np.random.default_rng(77)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=Fout, device="cuda:0",
+                                                   initializer=lambda t: t.copy_(torch.from_numpy(W)))
+    x = rng.standard_normal((N, Lt.shape[0], Fin)).astype(np.float32)
+    dy = rng.standard_normal((N, Lt.shape[0], Fout)).astype(np.float32)
+    xt = _dev(x).requires_grad_(True)
+    y = layer(xt)
+    y.backward(_dev(dy))
+    dx_ref, dW_ref = orc.chebyshev_backward(Lt, x, W, K, dy)
+    e_dx, e_dw = rel_err(xt.grad.cpu().numpy(), dx_ref), rel_err(layer.kernel.grad.cpu().numpy(), dW_ref)
+    print(f"64 -> 4 at the default: dx err {e_dx:.2e}, dkernel err {e_dw:.2e}")
+    assert e_dx < TOL and e_dw < 2 * TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K > 5 through T_{4+j} = 2 T_4 T_j - T_{|4-j|}: passes of K <= 5 on the fast kernels
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-6), ("bf16x6", 2e-6), ("bf16x3", TOL)])
+@pytest.mark.parametrize("nside,N,Fin,Fout,K,basis", [
+    (64, 2, 32, 32, 8, "chebyshev"),    # BASELINE configs[3]'s channel counts and order: two passes (K 4, then K 5 on [x, u])
+    (64, 1, 16, 32, 10, "chebyshev"),   # the reference tutorials' K = 10 (examples/quick_start.ipynb:118-127): three passes
+    (64, 2, 8, 24, 6, "chebyshev"),     # K = 6: the inner pass is a single step
+    (64, 1, 4, 12, 13, "chebyshev"),    # three passes of K = 5
+    (128, 1, 32, 32, 8, "chebyshev"),   # several tiles per workgroup
+    (64, 2, 16, 16, 9, "monomial"),     # the other basis: L^{4+j} = L^4 L^j
+    (64, 1, 3, 5, 7, "chebyshev"),      # channel counts that get padded
+])
+def test_high_order_through_the_product_identity(nside, N, Fin, Fout, K, basis, prec, tol):
+    """Whole maps against the float64 oracle with the split route forced (DSPH_OPT_SPLIT = always), bias + ReLU in the last
+    pass; and against the breadth-first-table kernel's result for K <= 9."""
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(nside + Fin + Fout + K)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    fwd = orc.chebyshev_forward if basis == "chebyshev" else orc.monomial_forward
+    ref = fwd(_csr(cols, vals), x, W, K, bias=b, activation="relu")
+    P = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}[prec]
+    B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
+    plan = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_SPLIT: _native.SPLIT_ALWAYS})
+    y, ws = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=P, basis=B)
+    err = rel_err(y.cpu().numpy(), ref)
+    y2, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=P, basis=B, workspace=ws)
+    assert torch.equal(y, y2)
+    msg = f"split nside={nside} {Fin}->{Fout} K={K} {basis} {prec}: err {err:.2e}"
+    if K <= 9:
+        plain = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_SPLIT: _native.SPLIT_NEVER})
+        yb, _ = _native.cheb_forward(plain, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=P, basis=B)
+        eb = rel_err(yb.cpu().numpy(), ref)
+        msg += f" (breadth-first-table kernel: {eb:.2e})"
+        assert eb < tol
+    print(msg)
+    assert err < tol
+
+
+def test_high_order_layer_like_the_tutorials():
+    """HealpyChebyshev(K=10, ...) as in examples/quick_start.ipynb:118-127, through the layer API at its defaults, forward and
+    gradients (the backward runs the same split on dy; the weight gradient its own kernels)."""
+    nside, N, Fin, Fout, K = 32, 2, 16, 8, 10
+    L = healpix.healpix_laplacian(nside, mode="grid")
+    Lt, _ = orc.prepare_L(L)
+    cols, vals = utils.csr_to_ell(Lt)
+    rng = np.random.default_rng(10)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=Fout, device="cuda:0", activation="elu", use_bias=True,
+                                                   initializer=lambda t: t.copy_(torch.from_numpy(W)))
+    x = rng.standard_normal((N, Lt.shape[0], Fin)).astype(np.float32)
+    with torch.no_grad():
+        y = layer(_dev(x))
+        bias = layer.bias.detach().cpu().numpy().reshape(-1)
+    ref = orc.chebyshev_forward(Lt, x, W, K, bias=bias, activation="elu")
+    assert rel_err(y.cpu().numpy(), ref) < TOL
+    xt = _dev(x).requires_grad_(True)
+    lin = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=Fout, device="cuda:0",
+                                                 initializer=lambda t: t.copy_(torch.from_numpy(W)))
+    dy = rng.standard_normal((N, Lt.shape[0], Fout)).astype(np.float32)
+    lin(xt).backward(_dev(dy))
+    dx_ref, dW_ref = orc.chebyshev_backward(Lt, x, W, K, dy)
+    assert rel_err(xt.grad.cpu().numpy(), dx_ref) < 2 * TOL
+    assert rel_err(lin.kernel.grad.cpu().numpy(), dW_ref) < 2 * TOL

@@ -192,3 +192,88 @@ def test_monomial_literal_against_powers():
     P = [np.linalg.matrix_power(Ld, k) for k in range(4)]
     ref = np.einsum("kmp,npf,fko->nmo", np.stack(P), x, W.reshape(3, 4, 2))
     assert rel_err(orc.monomial_forward(Lt, x, W, 4), ref) < 1e-12
+
+
+# ---- residual block (reference gnn_layers.py:312-413) ---------------------------------------------------------
+
+
+def test_residual_identity_laplacian_known_answer():
+    """The reference's own residual-layer test graph (tests/test_gnn_layers.py:94-114: L = I_192, x (3, 192, 7), K = 5,
+    Fout = None): with L~ = t I every convolution is a per-pixel matrix product, so the whole block has a closed form."""
+    M, N, F, K = 192, 3, 7, 5
+    Lt, _ = orc.prepare_L(np.eye(M))
+    t = float(np.float32(1.5 / 1.02 - 1.0))
+    T = np.cos(np.arange(K) * np.arccos(t))
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((N, M, F))
+    k1, k2 = rng.standard_normal((F * K, F)) * 0.3, rng.standard_normal((F * K, F)) * 0.3
+    E1 = np.einsum("k,fko->fo", T, k1.reshape(F, K, F))
+    E2 = np.einsum("k,fko->fo", T, k2.reshape(F, K, F))
+    core = x @ E1 @ E2
+    relu = lambda v: np.maximum(v, 0)  # noqa: E731
+    assert rel_err(orc.residual_forward(Lt, x, (k1, k2), K, activation="relu", alpha=0.5), relu(core + 0.5 * x)) < 1e-12
+    assert rel_err(orc.residual_forward(Lt, x, (k1, k2), K, activation="relu", act_before=True, alpha=0.5),
+                   relu(core) + 0.5 * x) < 1e-12
+    # activation None: x + input, alpha ignored (gnn_layers.py:407-408)
+    assert rel_err(orc.residual_forward(Lt, x, (k1, k2), K, activation=None, alpha=7.0), core + x) < 1e-12
+    # the sub-layers' own activation (layer_kwargs) sits inside both convolutions
+    assert rel_err(orc.residual_forward(Lt, x, (k1, k2), K, layer_activation="relu", activation="relu"),
+                   relu(relu(relu(x @ E1) @ E2) + x)) < 1e-12
+    # monomial sub-layers: L~ = (2/1.02 - 1) I, T_k = t^k
+    Lm, _ = orc.prepare_L(np.eye(M), scale=1)
+    tm = float(np.float32(2 / 1.02 - 1.0))
+    P = tm ** np.arange(K)
+    M1 = np.einsum("k,fko->fo", P, k1.reshape(F, K, F))
+    M2 = np.einsum("k,fko->fo", P, k2.reshape(F, K, F))
+    assert rel_err(orc.residual_forward(Lm, x, (k1, k2), K, layer_type="MONO", activation="relu"), relu(x @ M1 @ M2 + x)) < 1e-12
+    with pytest.raises(IOError):
+        orc.residual_forward(Lt, x, (k1, k2), K, layer_type="juhu")
+    with pytest.raises(ValueError):
+        orc.residual_forward(Lt, x, (k1, k2), K, use_bn=True, norm_type="moving_norm")
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_residual_norms_against_an_independent_implementation(training):
+    """The two norm layers of the block (Keras defaults: epsilon 1e-3, affine) against torch's modules, which implement the
+    same published definitions independently: batch norm in both modes, layer norm over the channel axis."""
+    import torch
+
+    rng = np.random.default_rng(8)
+    v = rng.standard_normal((4, 30, 6)) * 2 + 0.7
+    mean, var = rng.standard_normal(6), rng.random(6) + 0.5
+    gamma, beta = rng.standard_normal(6), rng.standard_normal(6)
+    bn = torch.nn.BatchNorm1d(6, eps=1e-3, momentum=0.01).double()
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.from_numpy(mean))
+        bn.running_var.copy_(torch.from_numpy(var))
+        bn.weight.copy_(torch.from_numpy(gamma))
+        bn.bias.copy_(torch.from_numpy(beta))
+    bn.train(training)
+    with torch.no_grad():
+        want = bn(torch.from_numpy(v).transpose(1, 2)).transpose(1, 2).numpy()
+    got = orc.keras_batch_norm(v, axis=-1, training=training, moving_mean=mean, moving_var=var, gamma=gamma, beta=beta)
+    assert rel_err(got, want) < 1e-12
+    ln = torch.nn.LayerNorm(6, eps=1e-3).double()
+    with torch.no_grad():
+        ln.weight.copy_(torch.from_numpy(gamma))
+        ln.bias.copy_(torch.from_numpy(beta))
+        want = ln(torch.from_numpy(v)).numpy()
+    assert rel_err(orc.keras_layer_norm(v, axis=-1, gamma=gamma, beta=beta), want) < 1e-12
+
+
+def test_residual_block_with_norms_composes():
+    """residual_forward with norms == the composition of its parts on a random graph (both sub-layers share Lt)."""
+    L = _rand_graph_L(29, seed=4)
+    Lt, _ = orc.prepare_L(L)
+    rng = np.random.default_rng(14)
+    N, F, K = 3, 5, 4
+    x = rng.standard_normal((N, 29, F))
+    k1, k2 = rng.standard_normal((F * K, F)) * 0.4, rng.standard_normal((F * K, F)) * 0.4
+    b1, b2 = rng.standard_normal(F), rng.standard_normal(F)
+    p1 = dict(moving_mean=rng.standard_normal(F), moving_var=rng.random(F) + 0.5, gamma=rng.standard_normal(F), beta=rng.standard_normal(F))
+    p2 = dict(moving_mean=rng.standard_normal(F), moving_var=rng.random(F) + 0.5, gamma=rng.standard_normal(F), beta=rng.standard_normal(F))
+    got = orc.residual_forward(Lt, x, (k1, k2), K, layer_biases=(b1, b2), layer_activation="elu", activation="tanh", use_bn=True,
+                               bn_params=(p1, p2), alpha=0.3)
+    v = orc.keras_batch_norm(orc.chebyshev_forward(Lt, x, k1, K, bias=b1, activation="elu"), **p1)
+    v = orc.keras_batch_norm(orc.chebyshev_forward(Lt, v, k2, K, bias=b2, activation="elu"), **p2)
+    assert rel_err(got, np.tanh(v + 0.3 * x)) < 1e-13

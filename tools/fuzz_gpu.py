@@ -2,7 +2,7 @@
 """Randomised cross-check on the GPU: fused vs unfused forward, planes, weight gradient (fp32 and bf16x3) on
 random graphs / shapes.  Usage: fuzz_gpu.py [cases] [seed]
 FUZZ_STRIPS=1: every case has the strip kernel's shape (K 5, 64 input channels, 64 / 128 / 192 output columns, nside 64 / 128)
-and the plans are built with DSPH_STRIP_FORCE, so that the strip kernel runs whatever the cost gate says.
+and the plans are built with the option DSPH_OPT_STRIPS = always, so that the strip kernel runs whatever the cost gate says.
 Tolerances (of max|y|, the ones DESIGN.md section 2 states): exact fp32 and the six-term split 2e-6; the three-term split 1e-5
 with 16 or more input channels -- where the layers use it -- and 2e-5 below; behind tanh five times that (the reference scale
 shrinks to <= 1 while the pre-activation's error passes through with slope <= 1)."""
@@ -19,8 +19,7 @@ from deepsphere import _native, healpix, utils  # noqa: E402
 from oracle import cheb_oracle as orc  # noqa: E402
 
 STRIPS = os.environ.get("FUZZ_STRIPS") == "1"
-if STRIPS:
-    os.environ["DSPH_STRIP_FORCE"] = "1"
+PLAN_OPTIONS = {_native.OPT_STRIPS: _native.STRIPS_ALWAYS} if STRIPS else None
 NSIDES = [int(v) for v in os.environ.get("FUZZ_NSIDES", "64,128" if STRIPS else "8,16,32").split(",")]
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -43,7 +42,7 @@ for it in range(cases):
             L = healpix.healpix_laplacian(nside, mode=mode)
         Lt, _ = orc.prepare_L(L, scale=0.75 if basis == _native.BASIS_CHEBYSHEV else 1.0)
         cols, vals = utils.csr_to_ell(Lt)
-        plans[key] = (Lt, _native.LaplacianPlan(cols, vals, device=0))
+        plans[key] = (Lt, _native.LaplacianPlan(cols, vals, device=0, options=PLAN_OPTIONS))
     Lt, plan = plans[key]
     M = Lt.shape[0]
     K = int(rng.integers(2, 10))
