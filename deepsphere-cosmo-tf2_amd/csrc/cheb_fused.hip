@@ -875,9 +875,14 @@ int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_
 }
 
 // two fragment layouts: the BFS-tile kernel's and, behind it, the structured-tile kernel's
+// (one fragment area per 64-column block of the layer, so that the packed images of ALL blocks survive the call:
+// DSPH_FWD_KEEP_WEIGHTS)
+static size_t frag_area_bytes(int32_t Fp, int32_t Fout, int32_t K) {
+  return (size_t)((Fout + 63) / 64) * all_frag_bytes(Fp, std::min(Fout, 64), K);
+}
 size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t) {
   const int32_t Fp = pad4(Fin);
-  const size_t frag = all_frag_bytes(Fp, std::min(Fout, 64), K);
+  const size_t frag = frag_area_bytes(Fp, Fout, K);
   return frag + (Fp != Fin ? (size_t)N * (size_t)plan->n_cols * (size_t)Fp * 4 : 0);  // + the zero-padded copy of x
 }
 
@@ -941,12 +946,13 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream,
                                const float* dy = nullptr, float* dw = nullptr, int32_t ld = 0, int32_t part = 0,
-                               int32_t Fin_w = 0, int32_t only = 0);  // only: 0 every launch, 1 the structured ones, 2 the BFS-tile one
+                               int32_t Fin_w = 0, int32_t only = 0,  // only: 0 every launch, 1 the structured ones, 2 the BFS-tile one
+                               bool keep_weights = false);           // the weight images in the workspace are those of an earlier call
 
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream, int32_t part) {
+                      size_t workspace_bytes, hipStream_t stream, int32_t part, bool keep_weights) {
   // more than 64 output columns: one launch per 64-column block (the recurrence is repeated; still one pass
   // over x per block instead of the unfused path's K planes through HBM)
   // The structured-tile kernel fuses bias and ReLU; with any other activation both fused kernels write the pre-activation
@@ -962,7 +968,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
   const int32_t Fin_w = Fin;
   if (Fin != pad4(Fin)) {
     const int32_t Fp = pad4(Fin);
-    const size_t frag = all_frag_bytes(Fp, std::min(Fout, 64), K);
+    const size_t frag = frag_area_bytes(Fp, Fout, K);
     const size_t need = frag + (size_t)N * (size_t)plan->n_cols * (size_t)Fp * 4;
     if (!workspace || workspace_bytes < need) {
       set_error("cheb_fused: workspace %zu < %zu", workspace_bytes, need);
@@ -988,11 +994,17 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
     // BASELINE configs[0], 168 tile-maps, is 13 us faster without it, configs[1] 29 us faster with it)
     fork = ft.ok && ft.n_r + ft.n_t > 0 && ng > 0 && N * (int64_t)(ft.n_r + ft.n_t) >= 2 * (int64_t)fp->num_cu;
   }
+  const size_t blk_frag = all_frag_bytes(Fin, std::min(Fout, 64), K);
+  if (!workspace || workspace_bytes < frag_area_bytes(Fin, Fout, K)) {
+    set_error("cheb_fused: workspace %zu < %zu", workspace_bytes, frag_area_bytes(Fin, Fout, K));
+    return DSPH_E_WORKSPACE;
+  }
   for (int32_t cb = 0; cb < Fout; cb += 64) {
+    unsigned char* blk_ws = static_cast<unsigned char*>(workspace) + (size_t)(cb / 64) * blk_frag;  // this block's weight images
     auto run = [&](hipStream_t st, int32_t only) {
       return launch_fused_common(plan, x, w + cb, bias ? bias + cb : nullptr, y + cb, nullptr, N, Fin,
                                  std::min<int32_t>(64, Fout - cb), K, defer_act ? DSPH_ACT_NONE : act, precision, alpha_rest,
-                                 beta_rest, workspace, workspace_bytes, st, nullptr, nullptr, Fout, part, Fin_w, only);
+                                 beta_rest, blk_ws, blk_frag, st, nullptr, nullptr, Fout, part, Fin_w, only, keep_weights);
     };
     if (fork) {
       std::unique_lock<std::mutex> lock(fp->fork_mu);
@@ -1106,7 +1118,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream, const float* dy,
-                               float* dw, int32_t ld, int32_t part, int32_t Fin_w, int32_t only) {
+                               float* dw, int32_t ld, int32_t part, int32_t Fin_w, int32_t only, bool keep_weights) {
   if (ld <= 0) ld = Fout;
   if (Fin_w <= 0) Fin_w = Fin;  // channels of w; smaller than Fin when x is a zero-padded copy  // row stride of w, bias-less y / dy / dw: the layer's Fout when this is one column block
   const bool wgrad_mode = dy != nullptr;  // y then carries the slab workspace
@@ -1141,7 +1153,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     sl.Fin = Fin; sl.Fin_w = Fin_w; sl.Fout = Fout; sl.K = K; sl.act = act; sl.precision = precision; sl.ld = ld;
     sl.num_cu = plan->fused->num_cu;
     sl.cheb = beta_rest != 0.f;
-    sl.prep_weights = true;  // the first of the two launches packs the fragments
+    sl.prep_weights = !keep_weights;  // the first of the two launches packs the fragments
     // rectangles of interior class-R tiles: the strip kernel, when it has this shape; the class-R list shrinks to the rest
     const bool strips = strips_apply(plan, ft, Fin, Fout, K, precision, N, ld) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     if (strips && part != 2 && !dbg_only('b')) {
@@ -1156,6 +1168,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       st.num_cu = plan->fused->num_cu;
       st.cheb = sl.cheb;
       st.generic = plan->opt.strip_generic;
+      st.prep_weights = !keep_weights;
       const int rc = launch_cheb_strip(st, stream);
       if (rc != DSPH_OK) return rc;
     }
@@ -1187,7 +1200,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   if (only == 1) return DSPH_OK;
   // the BFS-tile kernel has two contraction arithmetics; the six-term split of the structured kernel is fp32-equivalent
   if (precision == DSPH_PREC_BF16X6) precision = DSPH_PREC_FP32;
-  if (!planes_mode) {
+  if (!planes_mode && !keep_weights) {
     hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,
                        static_cast<unsigned char*>(workspace), (int)Fin_w, (int)Fout, (int)K, C, NB,
                        (int)precision, (int)ld);

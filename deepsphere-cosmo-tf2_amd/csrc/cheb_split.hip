@@ -110,7 +110,8 @@ struct SplitLayout {
   size_t wgt = 0;        // weight matrices of the passes, back to back
   size_t wgt_pass[SPLIT_MAX_PASSES] = {};
   size_t lvl[SPLIT_MAX_PASSES] = {};  // terms W^l of the levels 1 .. L ([Fin * Kl, Fout]; level 0 is the layer's kernel)
-  size_t sub = 0;        // workspace of the pass that needs most
+  size_t sub_pass[SPLIT_MAX_PASSES] = {}, sub_bytes[SPLIT_MAX_PASSES] = {};  // every pass's own workspace (its packed weight
+                                                                             // images survive the call: DSPH_FWD_KEEP_WEIGHTS)
   size_t total = 0;
 };
 
@@ -137,10 +138,15 @@ bool split_layout(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fout, int3
     pass_shape(*s, Fin, Fout, l, &fi, &fo, &k);
     lay->wgt_pass[l] = off;
     off += align256((size_t)fi * k * fo * sizeof(float));
-    lay->sub = std::max(lay->sub, fused_workspace_bytes(p, N, fi, fo, k, precision));
   }
-  lay->sub = align256(lay->sub);
-  lay->total = off + lay->sub;
+  for (int l = s->L; l >= 0; --l) {
+    int32_t fi, fo, k;
+    pass_shape(*s, Fin, Fout, l, &fi, &fo, &k);
+    lay->sub_pass[l] = off;
+    lay->sub_bytes[l] = align256(fused_workspace_bytes(p, N, fi, fo, k, precision));
+    off += lay->sub_bytes[l];
+  }
+  lay->total = off;
   return true;
 }
 
@@ -175,7 +181,7 @@ int split_prepare(const dsph_plan* p, int32_t K, int32_t Fin, int32_t Fout, int3
 
 int launch_split_forward(const dsph_plan* p, const float* x, const float* w, const float* bias, float* y, int64_t N, int32_t Fin,
                          int32_t Fout, int32_t K, int32_t basis, int32_t act, int32_t precision, void* workspace,
-                         size_t workspace_bytes, hipStream_t stream) {
+                         size_t workspace_bytes, hipStream_t stream, bool keep_weights) {
   SplitShape s;
   SplitLayout lay;
   if (!split_layout(p, N, Fin, Fout, K, precision, &s, &lay)) { set_error("split_forward: K = %d does not split", K); return DSPH_E_UNSUPPORTED; }
@@ -187,12 +193,12 @@ int launch_split_forward(const dsph_plan* p, const float* x, const float* w, con
   // the terms of the levels, then the weight matrices of all passes (tiny), then the passes
   auto blocks = [](int64_t total) { return dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)); };
   auto level_w = [&](int l) -> const float* { return l == 0 ? w : reinterpret_cast<const float*>(ws + lay.lvl[l]); };
-  for (int l = 0; l < s.L; ++l) {
+  for (int l = 0; l < s.L && !keep_weights; ++l) {
     hipLaunchKernelGGL(split_next_kernel, blocks((int64_t)Fin * Fout * 8), dim3(256), 0, stream, level_w(l),
                        reinterpret_cast<float*>(ws + lay.lvl[l + 1]), (int)Fin, (int)Fout, s.Kl[l], cheb ? 1 : 0);
     DSPH_HIP(hipGetLastError());
   }
-  for (int l = s.L; l >= 0; --l) {
+  for (int l = s.L; l >= 0 && !keep_weights; --l) {
     int32_t fi, fo, k;
     pass_shape(s, Fin, Fout, l, &fi, &fo, &k);
     hipLaunchKernelGGL(split_weights_kernel, blocks((int64_t)fi * k * fo), dim3(256), 0, stream, level_w(l),
@@ -206,8 +212,8 @@ int launch_split_forward(const dsph_plan* p, const float* x, const float* w, con
     pass_shape(s, Fin, Fout, l, &fi, &fo, &k);
     float* out = l == 0 ? y : reinterpret_cast<float*>(ws + lay.z[(s.L - l) & 1]);
     const int rc = launch_cheb_fused(p, in, reinterpret_cast<const float*>(ws + lay.wgt_pass[l]), l == 0 ? bias : nullptr, out, N, fi, fo,
-                                     k, l == 0 ? act : DSPH_ACT_NONE, precision, alpha_rest, beta_rest, ws + lay.total - lay.sub, lay.sub,
-                                     stream);
+                                     k, l == 0 ? act : DSPH_ACT_NONE, precision, alpha_rest, beta_rest, ws + lay.sub_pass[l],
+                                     lay.sub_bytes[l], stream, DSPH_PART_ALL, keep_weights);
     if (rc != DSPH_OK) return rc;
     in = out;
   }

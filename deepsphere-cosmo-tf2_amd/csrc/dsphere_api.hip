@@ -286,6 +286,16 @@ int dsph_poly_forward_part(const dsph_plan* p, const float* x, const float* w, c
                            float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t basis,
                            int32_t act, int32_t precision, int32_t algo, int32_t part, void* workspace,
                            size_t workspace_bytes, void* hip_stream) {
+  return dsph_poly_forward_ex(p, x, w, bias, y, N, Fin, Fout, K, basis, act, precision, algo, part, 0, workspace, workspace_bytes,
+                              hip_stream);
+}
+
+int dsph_poly_forward_ex(const dsph_plan* p, const float* x, const float* w, const float* bias,
+                         float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t basis,
+                         int32_t act, int32_t precision, int32_t algo, int32_t part, int32_t flags, void* workspace,
+                         size_t workspace_bytes, void* hip_stream) {
+  if (flags & ~DSPH_FWD_KEEP_WEIGHTS) { set_error("poly_forward: unknown flags %d", flags); return DSPH_E_BADARG; }
+  const bool keep_weights = (flags & DSPH_FWD_KEEP_WEIGHTS) != 0;
   if (part != DSPH_PART_ALL && part != DSPH_PART_INTERIOR && part != DSPH_PART_BOUNDARY) {
     set_error("poly_forward: unknown part %d", part);
     return DSPH_E_BADARG;
@@ -316,7 +326,7 @@ int dsph_poly_forward_part(const dsph_plan* p, const float* x, const float* w, c
   if (use_split(p, Fin, Fout, K, algo, part)) {
     DeviceGuard guard(p->device);
     return launch_split_forward(p, x, w, bias, y, N, Fin, Fout, K, basis, act, precision, workspace, workspace_bytes,
-                                (hipStream_t)hip_stream);
+                                (hipStream_t)hip_stream, keep_weights);
   }
   const int a = resolve_algo(p, Fin, Fout, K, algo);
   if (a < 0) { set_error("cheb_forward: fused kernel cannot run this plan/shape (Fin=%d Fout=%d K=%d)", Fin, Fout, K); return DSPH_E_UNSUPPORTED; }
@@ -329,7 +339,7 @@ int dsph_poly_forward_part(const dsph_plan* p, const float* x, const float* w, c
   DeviceGuard guard(p->device);
   if (a == DSPH_ALGO_FUSED)
     return launch_cheb_fused(p, x, w, bias, y, N, Fin, Fout, K, act, precision, alpha_rest, beta_rest,
-                             workspace, workspace_bytes, stream, part);
+                             workspace, workspace_bytes, stream, part, keep_weights);
   if (part != DSPH_PART_ALL) {
     set_error("poly_forward: interior / boundary parts exist for the fused kernel only");
     return DSPH_E_UNSUPPORTED;

@@ -96,7 +96,7 @@ int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream, int32_t part = 0);
+                      size_t workspace_bytes, hipStream_t stream, int32_t part = 0, bool keep_weights = false);
 bool fused_planes_supported(const dsph_plan* plan, int32_t Fin, int32_t K);
 int launch_cheb_fused_planes(const dsph_plan* plan, const float* x, float* planes_out, int64_t N, int32_t Fin,
                              int32_t K, float alpha_rest, float beta_rest, hipStream_t stream);
@@ -115,7 +115,7 @@ size_t split_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int3
 int split_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t Fout, int32_t flags);
 int launch_split_forward(const dsph_plan* plan, const float* x, const float* w, const float* bias, float* y, int64_t N, int32_t Fin,
                          int32_t Fout, int32_t K, int32_t basis, int32_t act, int32_t precision, void* workspace,
-                         size_t workspace_bytes, hipStream_t stream);
+                         size_t workspace_bytes, hipStream_t stream, bool keep_weights = false);
 
 // structured-tile kernel (cheb_struct.hip)
 struct StructLaunch {

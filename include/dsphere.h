@@ -214,6 +214,19 @@ int dsph_poly_forward_part(const dsph_plan* plan, const float* x, const float* w
                            int32_t act, int32_t precision, int32_t algo, int32_t part, void* workspace,
                            size_t workspace_bytes, void* hip_stream);
 
+/* The same with flags:
+ *   DSPH_FWD_KEEP_WEIGHTS  `workspace` still holds the weight images that the previous call on this workspace packed from the
+ *                          same w (values, not only pointer), Fin, Fout, K, basis and precision: the fused kernels use them as
+ *                          they are and the call launches no weight-preparation kernel (three small launches per forward
+ *                          otherwise; on a small map they are a third of the forward).  The caller vouches for it -- a layer
+ *                          in inference does, by the version counter of its kernel tensor (deepsphere/gnn_layers.py).  The
+ *                          unfused path packs nothing and ignores the flag. */
+#define DSPH_FWD_KEEP_WEIGHTS 1
+int dsph_poly_forward_ex(const dsph_plan* plan, const float* x, const float* w, const float* bias,
+                         float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t basis,
+                         int32_t act, int32_t precision, int32_t algo, int32_t part, int32_t flags, void* workspace,
+                         size_t workspace_bytes, void* hip_stream);
+
 /* One recurrence step on (N, n_cols, F) planes:  out = alpha * (L~ @ in) - beta * prev
  * for rows [0, rows) of every map (rows <= n_rows; rows <= 0 means n_rows); prev may be NULL
  * when beta == 0.  Replaces one utils.split_sparse_dense_matmul call plus the `2*... - x0`
