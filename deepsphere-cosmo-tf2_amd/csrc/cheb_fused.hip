@@ -991,8 +991,15 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
     const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
     const int ng = !ft.ok ? 0 : (part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior));
     // (worth its two event operations only when the structured launches run for a while: two tile-maps per CU and more --
-    // BASELINE configs[0], 168 tile-maps, is 13 us faster without it, configs[1] 29 us faster with it)
-    fork = ft.ok && ft.n_r + ft.n_t > 0 && ng > 0 && N * (int64_t)(ft.n_r + ft.n_t) >= 2 * (int64_t)fp->num_cu;
+    // BASELINE configs[0], 168 tile-maps, is 13 us faster without it, configs[1] 29 us faster with it.  Under a stream
+    // capture the fork and the join are edges of the graph and cost nothing at replay: every forward with both kinds of tiles
+    // forks there, provided the side stream exists already -- dsph_plan_prepare made it)
+    bool big = N * (int64_t)(ft.n_r + ft.n_t) >= 2 * (int64_t)fp->num_cu;
+    if (!big && fp->side && stream != nullptr) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      big = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    }
+    fork = ft.ok && ft.n_r + ft.n_t > 0 && ng > 0 && big;
   }
   const size_t blk_frag = all_frag_bytes(Fin, std::min(Fout, 64), K);
   if (!workspace || workspace_bytes < frag_area_bytes(Fin, Fout, K)) {

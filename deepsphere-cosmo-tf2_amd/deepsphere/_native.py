@@ -18,6 +18,7 @@ ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
 ALGO_AUTO, ALGO_UNFUSED, ALGO_FUSED = 0, 1, 2
 PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
+FWD_KEEP_WEIGHTS = 1
 PREPARE_BACKWARD, PREPARE_RELEASE_HOST = 1, 2
 BASIS_CHEBYSHEV, BASIS_MONOMIAL = 0, 1
 # dsph_plan_set_option (include/dsphere.h: DSPH_OPT_*)
@@ -60,6 +61,11 @@ SIGNATURES = {
     "dsph_poly_forward_part": (
         ctypes.c_int,
         [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32,
+         _c_vp, ctypes.c_size_t, _c_vp],
+    ),
+    "dsph_poly_forward_ex": (
+        ctypes.c_int,
+        [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32,
          _c_vp, ctypes.c_size_t, _c_vp],
     ),
     "dsph_cheb_step": (
@@ -253,10 +259,12 @@ def _check_dev(t, plan, name):
 
 
 def cheb_forward(plan, x, w, bias, K, act=ACT_NONE, precision=PREC_FP32, algo=ALGO_AUTO, workspace=None, out=None,
-                 basis=BASIS_CHEBYSHEV, part=PART_ALL):
-    """y = dsph_poly_forward(...) on torch CUDA tensors; x (N, n_cols, Fin), w (Fin*K, Fout).
+                 basis=BASIS_CHEBYSHEV, part=PART_ALL, keep_weights=False):
+    """y = dsph_poly_forward_ex(...) on torch CUDA tensors; x (N, n_cols, Fin), w (Fin*K, Fout).
     ``part``: PART_ALL, or PART_INTERIOR / PART_BOUNDARY (fused kernel only) to write only the tiles that do not /
-    do touch halo rows -- pass the same ``out`` to both calls."""
+    do touch halo rows -- pass the same ``out`` to both calls.
+    ``keep_weights``: the caller vouches that ``workspace`` was last used by a call with the same weight values, shape,
+    basis and precision (DSPH_FWD_KEEP_WEIGHTS: no weight-preparation launches); dropped when the workspace is replaced."""
     import torch
 
     _check_dev(x, plan, "x")
@@ -274,6 +282,7 @@ def cheb_forward(plan, x, w, bias, K, act=ACT_NONE, precision=PREC_FP32, algo=AL
     need = plan.workspace_bytes(N, Fin, Fout, K, precision, algo)
     if need > 0 and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        keep_weights = False
     orows = plan.out_rows
     if out is None:
         out = torch.empty((N, orows, Fout), dtype=torch.float32, device=x.device)
@@ -281,12 +290,13 @@ def cheb_forward(plan, x, w, bias, K, act=ACT_NONE, precision=PREC_FP32, algo=AL
         _check_dev(out, plan, "out")
         if tuple(out.shape) != (N, orows, Fout):
             raise ValueError("out has the wrong shape")
-    rc = lib().dsph_poly_forward_part(
+    rc = lib().dsph_poly_forward_ex(
         plan.handle, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), int(N), int(Fin), Fout, int(K), int(basis), int(act),
-        int(precision), int(algo), int(part), _ptr(workspace) if need > 0 else _c_vp(),
+        int(precision), int(algo), int(part), FWD_KEEP_WEIGHTS if (keep_weights and need > 0) else 0,
+        _ptr(workspace) if need > 0 else _c_vp(),
         (workspace.numel() * workspace.element_size()) if need > 0 else 0, _stream_ptr(x.device),
     )
-    check(rc, "dsph_poly_forward_part")
+    check(rc, "dsph_poly_forward_ex")
     return out, workspace
 
 

@@ -117,6 +117,7 @@ class _ChebConvFunction(torch.autograd.Function):
             plan, x, kernel.detach(), None, layer.K, act=_native.ACT_NONE,
             precision=layer._prec_code(), algo=_ALGOS[layer.algo], workspace=layer._workspace,
             basis=layer._basis)
+        layer._wkey = None  # (training: the weights change between steps; the inference path re-packs once afterwards)
         ctx.layer = layer
         ctx.save_for_backward(x, kernel)
         return y
@@ -190,7 +191,10 @@ class Chebyshev(torch.nn.Module):
             split, 2-7e-7 | "fp32": exact-fp32 MFMA, bitwise an fp32 fma chain; the recurrence is fp32 in all of them; see
             DEFAULT_PRECISION), ``algo`` ("auto" | "unfused" | "fused") and ``plan_options`` (a dict of
             ``_native.OPT_*`` -> value handed to ``dsph_plan_set_option``, e.g. ``{OPT_STRIPS: STRIPS_NEVER}`` for results
-            that do not depend on the batch size).
+            that do not depend on the batch size).  ``graph=True`` (inference only): the prepared forward is captured into
+            a HIP graph on first use and replayed while the input buffer, the weights and the shapes stay the same -- one
+            graph launch instead of three to six kernel launches, the BFS-tile launch beside the structured ones; the
+            returned tensor is then the SAME buffer on every call (copy it if it must outlive the next forward).
         """
         super().__init__()
         self.L = L
@@ -208,6 +212,7 @@ class Chebyshev(torch.nn.Module):
         precision = kwargs.pop("precision", DEFAULT_PRECISION)
         algo = kwargs.pop("algo", "auto")
         self._plan_options = dict(kwargs.pop("plan_options", None) or {})
+        self._use_graph = bool(kwargs.pop("graph", False))
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         if algo not in _ALGOS:
@@ -348,11 +353,20 @@ class Chebyshev(torch.nn.Module):
 
         fuse_epilogue = not self.use_bn
         act_code = self._act_code if (fuse_epilogue and self._act_code is not None) else _native.ACT_NONE
-        y, self._workspace = _native.cheb_forward(
-            plan, x, self.kernel.detach(), bias if fuse_epilogue else None, self.K, act=act_code,
-            precision=self._prec_code(), algo=_ALGOS[self.algo], workspace=self._workspace,
-            basis=self._basis,
-        )
+        # Inference steady state: the packed weight images of the previous forward are still in the workspace -- same kernel
+        # tensor at the same version (torch bumps it on every in-place write: optimiser step, copy_, load_state_dict), same
+        # arithmetic, same workspace -- so the call launches no weight-preparation kernel (DSPH_FWD_KEEP_WEIGHTS).
+        wkey = (self.kernel.data_ptr(), self.kernel._version, self._prec_code(), self.algo,
+                None if self._workspace is None else self._workspace.data_ptr())
+        if getattr(self, "_use_graph", False):
+            y = self._graph_forward(plan, x, bias if fuse_epilogue else None, act_code, wkey[:4])
+        else:
+            y, self._workspace = _native.cheb_forward(
+                plan, x, self.kernel.detach(), bias if fuse_epilogue else None, self.K, act=act_code,
+                precision=self._prec_code(), algo=_ALGOS[self.algo], workspace=self._workspace,
+                basis=self._basis, keep_weights=getattr(self, "_wkey", None) == wkey,
+            )
+            self._wkey = wkey[:4] + (self._workspace.data_ptr() if self._workspace is not None else None,)
         if self.use_bn:  # BN -> bias -> activation, the reference's order (gnn_layers.py:152-159)
             was_training = self.bn.training
             self.bn.train(self.training if training is None else bool(training))
@@ -367,6 +381,31 @@ class Chebyshev(torch.nn.Module):
         return y
 
     call = forward
+
+    def _graph_forward(self, plan, x, bias, act_code, wkey):
+        """The prepared forward as one HIP-graph launch (``graph=True``).  Captured after an ordinary forward has packed the
+        weight images and sized the workspace; the captured call keeps them (DSPH_FWD_KEEP_WEIGHTS), so the graph holds the
+        compute kernels only -- and under capture the BFS-tile launch always runs beside the structured ones
+        (csrc/cheb_fused.hip).  Re-captured when the input buffer, the shapes, the weights' version or the epilogue change."""
+        key = (x.data_ptr(), tuple(x.shape), wkey, None if bias is None else bias.data_ptr(), act_code)
+        g = getattr(self, "_graph", None)
+        if g is None or g["key"] != key:
+            kw = dict(act=act_code, precision=self._prec_code(), algo=_ALGOS[self.algo], basis=self._basis)
+            y, self._workspace = _native.cheb_forward(plan, x, self.kernel.detach(), bias, self.K, workspace=self._workspace, **kw)
+            self._wkey = None
+            graph = torch.cuda.CUDAGraph()
+            out = torch.empty_like(y)
+            cur = torch.cuda.current_stream(x.device)
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(cur)
+            kernel = self.kernel.detach()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    _native.cheb_forward(plan, x, kernel, bias, self.K, workspace=self._workspace, out=out, keep_weights=True, **kw)
+            cur.wait_stream(side)
+            g = self._graph = {"key": key, "graph": graph, "out": out, "hold": (x, kernel, bias, self._workspace)}
+        g["graph"].replay()
+        return g["out"]
 
     @classmethod
     def from_prepared_ell(cls, ell_cols, ell_vals, K, lmax=None, **kwargs):
@@ -391,6 +430,7 @@ class Chebyshev(torch.nn.Module):
         self.precision = kwargs.pop("precision", DEFAULT_PRECISION)
         self.algo = kwargs.pop("algo", "auto")
         self._plan_options = dict(kwargs.pop("plan_options", None) or {})
+        self._use_graph = bool(kwargs.pop("graph", False))
         if self.precision not in _PRECISIONS or self.algo not in _ALGOS:
             raise ValueError("unknown precision or algo")
         self.kwargs = kwargs

@@ -336,3 +336,54 @@ def test_high_order_layer_like_the_tutorials():
     dx_ref, dW_ref = orc.chebyshev_backward(Lt, x, W, K, dy)
     assert rel_err(xt.grad.cpu().numpy(), dx_ref) < 2 * TOL
     assert rel_err(lin.kernel.grad.cpu().numpy(), dW_ref) < 2 * TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# small-map latency -- weight images kept between forwards, the forward as one graph launch
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("Fin,Fout,K", [(1, 16, 5), (16, 96, 5), (16, 32, 10)])
+def test_kept_weight_images_and_graph_replay(Fin, Fout, K):
+    """DSPH_FWD_KEEP_WEIGHTS through the layer: the second and later inference forwards launch no weight-preparation kernel
+    and give the same bits; an in-place update of the kernel (its version counter moves) re-packs; graph=True replays the
+    same bits from one graph launch, follows weight updates and new inputs.  (1 -> 16: BASELINE configs[0]; 96 columns: two
+    column blocks, each with its own image area; K = 10: the split route's per-pass areas.)"""
+    nside, N = 64, 2
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(Fin + Fout + K)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    mk = lambda **kw: gnn_layers.Chebyshev.from_prepared_ell(  # noqa: E731
+        cols, vals, K, Fout=Fout, device="cuda:0", activation="relu", use_bias=True,
+        initializer=lambda t: t.copy_(torch.from_numpy(W)), **kw)
+    layer, glayer = mk(), mk(graph=True)
+    x = _dev(rng.standard_normal((N, M, Fin)).astype(np.float32))
+    Lt = _csr(cols, vals)
+    with torch.no_grad():
+        glayer(x)
+        layer(x)  # (both built: the biases are random, make them the same)
+        glayer.bias.copy_(layer.bias)
+        y0 = layer(x).clone()
+        assert layer._wkey is not None
+        y1 = layer(x).clone()   # weight images kept
+        y2 = layer(x).clone()
+        assert torch.equal(y0, y1) and torch.equal(y0, y2)
+        ref = orc.chebyshev_forward(Lt, x.cpu().numpy(), W, K, bias=layer.bias.cpu().numpy().reshape(-1), activation="relu")
+        assert rel_err(y0.cpu().numpy(), ref) < 2 * TOL
+        g0 = glayer(x).clone()
+        g1 = glayer(x).clone()  # replay
+        assert torch.equal(g0, y0) and torch.equal(g1, y0)
+        # a weight update moves the version counter: both layers re-pack (the graph is re-captured)
+        layer.kernel.mul_(0.5)
+        glayer.kernel.mul_(0.5)
+        y3 = layer(x).clone()
+        ref3 = orc.chebyshev_forward(Lt, x.cpu().numpy(), 0.5 * W, K, bias=layer.bias.cpu().numpy().reshape(-1), activation="relu")
+        assert rel_err(y3.cpu().numpy(), ref3) < 2 * TOL and not torch.equal(y3, y0)
+        assert torch.equal(glayer(x), y3)
+        # new contents in the same input buffer: the replay reads them; a new buffer: re-captured
+        x.mul_(-1.0)
+        y4 = layer(x).clone()
+        assert torch.equal(glayer(x), y4)
+        x2 = x.clone()
+        assert torch.equal(glayer(x2), y4)
