@@ -515,6 +515,32 @@ int dsph_rows_unpack(float* dst, int64_t dst_rows, const int32_t* idx, int64_t n
   return launch_rows_pack(dst, dst_rows, idx, n_idx, const_cast<float*>(buf), N, F, true, (hipStream_t)hip_stream);
 }
 
+static int pool_args_ok(const void* a, const void* b, int64_t N, int64_t rows_out, int32_t F, int32_t group, int32_t type) {
+  if (!a || !b || N < 0 || rows_out < 0 || F <= 0 || group <= 0 || (type != DSPH_POOL_MAX && type != DSPH_POOL_AVG)) {
+    set_error("healpix_pool: bad arguments (NULL pointer, negative size or unknown pooling type %d)", (int)type);
+    return DSPH_E_BADARG;
+  }
+  if (group > (1 << 20)) { set_error("healpix_pool: group %d too large", (int)group); return DSPH_E_UNSUPPORTED; }
+  return DSPH_OK;
+}
+
+int dsph_healpix_pool(const float* x, float* y, int64_t N, int64_t rows_out, int32_t F, int32_t group, int32_t type, int device,
+                      void* hip_stream) {
+  const int rc = pool_args_ok(x, y, N, rows_out, F, group, type);
+  if (rc != DSPH_OK) return rc;
+  DeviceGuard guard(device);
+  return launch_healpix_pool(x, y, N * rows_out, F, group, type == DSPH_POOL_MAX, (hipStream_t)hip_stream);
+}
+
+int dsph_healpix_pool_backward(const float* x, const float* dy, float* dx, int64_t N, int64_t rows_out, int32_t F, int32_t group,
+                               int32_t type, int device, void* hip_stream) {
+  const int rc = pool_args_ok(dy, dx, N, rows_out, F, group, type);
+  if (rc != DSPH_OK) return rc;
+  if (type == DSPH_POOL_MAX && !x) { set_error("healpix_pool_backward: max pooling needs the forward input"); return DSPH_E_BADARG; }
+  DeviceGuard guard(device);
+  return launch_healpix_pool_backward(x, dy, dx, N * rows_out, F, group, type == DSPH_POOL_MAX, (hipStream_t)hip_stream);
+}
+
 int dsph_residual_epilogue(float* y, const float* skip, int64_t n, float alpha, int32_t act, int32_t act_before,
                            int device, void* hip_stream) {
   if (!y || !skip || n < 0) { set_error("residual_epilogue: bad arguments"); return DSPH_E_BADARG; }

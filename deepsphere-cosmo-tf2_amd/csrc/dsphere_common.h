@@ -159,6 +159,11 @@ bool strip_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
 size_t strip_wimg_bytes(int32_t Fin, int32_t Fout, int32_t K);
 int launch_cheb_strip(const StripLaunch& s, hipStream_t stream);
 
+// NEST pooling (healpix_pool.hip)
+int launch_healpix_pool(const float* x, float* y, int64_t rows_out, int32_t F, int32_t group, bool maxp, hipStream_t stream);
+int launch_healpix_pool_backward(const float* x, const float* dy, float* dx, int64_t rows_out, int32_t F, int32_t group, bool maxp,
+                                 hipStream_t stream);
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case DSPH_ACT_RELU: return v > 0.f ? v : 0.f;

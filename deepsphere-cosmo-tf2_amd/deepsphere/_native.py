@@ -19,6 +19,7 @@ PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
 ALGO_AUTO, ALGO_UNFUSED, ALGO_FUSED = 0, 1, 2
 PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
 FWD_KEEP_WEIGHTS = 1
+POOL_MAX, POOL_AVG = 0, 1
 PREPARE_BACKWARD, PREPARE_RELEASE_HOST = 1, 2
 BASIS_CHEBYSHEV, BASIS_MONOMIAL = 0, 1
 # dsph_plan_set_option (include/dsphere.h: DSPH_OPT_*)
@@ -95,6 +96,8 @@ SIGNATURES = {
     ),
     "dsph_rows_pack": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_i64, _c_i32, ctypes.c_int, _c_vp]),
     "dsph_rows_unpack": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_i64, _c_i32, ctypes.c_int, _c_vp]),
+    "dsph_healpix_pool": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, ctypes.c_int, _c_vp]),
+    "dsph_healpix_pool_backward": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, ctypes.c_int, _c_vp]),
     "dsph_residual_epilogue": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_float, _c_i32, _c_i32, ctypes.c_int, _c_vp]),
 }
 
@@ -432,3 +435,31 @@ def residual_epilogue(y, skip, alpha=1.0, act=ACT_NONE, act_before=False):
                                       int(y.device.index), _stream_ptr(y.device))
     check(rc, "dsph_residual_epilogue")
     return y
+
+
+def healpix_pool(x, group, pool_type=POOL_MAX):
+    """y[n, m, f] = max | mean over the ``group`` = 4^p consecutive (NEST children) rows of x (``dsph_healpix_pool``)."""
+    import torch
+
+    if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 3:
+        raise ValueError("healpix_pool works on a contiguous float32 (N, rows, F) HIP tensor")
+    N, M, F = x.shape
+    if M % group != 0:
+        raise ValueError(f"{M} rows are not a multiple of the group size {group}")
+    y = torch.empty((N, M // group, F), dtype=torch.float32, device=x.device)
+    rc = lib().dsph_healpix_pool(_ptr(x), _ptr(y), int(N), int(M // group), int(F), int(group), int(pool_type), x.device.index,
+                                 _stream_ptr(x.device))
+    check(rc, "dsph_healpix_pool")
+    return y
+
+
+def healpix_pool_backward(x, dy, group, pool_type=POOL_MAX):
+    """Gradient of ``healpix_pool`` with respect to its input (``dsph_healpix_pool_backward``)."""
+    import torch
+
+    N, Mo, F = dy.shape
+    dx = torch.empty((N, Mo * group, F), dtype=torch.float32, device=dy.device)
+    rc = lib().dsph_healpix_pool_backward(_ptr(x), _ptr(dy.contiguous()), _ptr(dx), int(N), int(Mo), int(F), int(group),
+                                          int(pool_type), dy.device.index, _stream_ptr(dy.device))
+    check(rc, "dsph_healpix_pool_backward")
+    return dx

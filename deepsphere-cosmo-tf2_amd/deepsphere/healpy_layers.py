@@ -9,6 +9,7 @@ Laplacian of the current resolution (``healpy_networks.py:110-137``).
 import numpy as np
 import torch
 
+from . import _native
 from .gnn_layers import Chebyshev, GCNN_ResidualLayer, Monomial
 
 
@@ -16,10 +17,27 @@ def _as_tensor(x):
     return x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x), dtype=torch.float32)
 
 
+class _NestPoolFunction(torch.autograd.Function):
+    """HealpyPool on the GPU: ``dsph_healpix_pool`` forward, ``dsph_healpix_pool_backward`` for the input gradient (the
+    reference gets the latter from TensorFlow's autodiff of the Keras pooling layer)."""
+
+    @staticmethod
+    def forward(ctx, x, group, pool_type):
+        ctx.group, ctx.pool_type = group, pool_type
+        ctx.save_for_backward(x if pool_type == _native.POOL_MAX else x.new_empty(0))
+        return _native.healpix_pool(x, group, pool_type)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return _native.healpix_pool_backward(x if ctx.pool_type == _native.POOL_MAX else None, dy, ctx.group, ctx.pool_type), None, None
+
+
 class HealpyPool(torch.nn.Module):
     """Pooling over the 4^p NEST children of a HEALPix pixel (reference ``healpy_layers.py:20-78``: a Keras
-    MaxPool1D / AveragePooling1D with size = stride = 4^p on (batch, pixels, channels)).  A dense strided
-    op on the host framework's side of the boundary; it only works for NEST ordering."""
+    MaxPool1D / AveragePooling1D with size = stride = 4^p on (batch, pixels, channels)).  On a HIP device: the
+    ``dsph_healpix_pool`` kernels (one contiguous run of 4^p rows per output row); on the CPU (shape checks, tests without a
+    GPU) the same reduction as a strided op of the host framework.  It only works for NEST ordering."""
 
     def __init__(self, p, pool_type="MAX", **kwargs):
         super().__init__()
@@ -37,6 +55,9 @@ class HealpyPool(torch.nn.Module):
         N, M, F = x.shape
         if M % self.filter_size != 0:
             raise IOError(f"Input shape {tuple(x.shape)} not compatible with the filter size {self.filter_size}")
+        if x.is_cuda and x.dtype == torch.float32:
+            return _NestPoolFunction.apply(x.contiguous(), self.filter_size,
+                                           _native.POOL_MAX if self.pool_type == "MAX" else _native.POOL_AVG)
         x = x.reshape(N, M // self.filter_size, self.filter_size, F)
         return x.amax(dim=2) if self.pool_type == "MAX" else x.mean(dim=2)
 
@@ -72,7 +93,14 @@ class HealpyPseudoConv(torch.nn.Module):
         if self.filter is None:
             self.build(x.shape)
             self.filter.to(x.device)
-        return self.filter(x.transpose(1, 2)).transpose(1, 2)
+        # kernel = stride = 4^p on NEST-ordered rows: the 4^p children of an output pixel are consecutive rows, so the input
+        # is, without any copy, a (N * M / 4^p) x (4^p * Fin) matrix and the layer one plain library GEMM against the
+        # [4^p * Fin, Fout] view of the Conv1D weights (no transposes of the map, which Conv1d on channels-last data needs)
+        N, M, Fin = x.shape
+        g = self.filter_size
+        w2 = self.filter.weight.permute(2, 1, 0).reshape(g * Fin, self.Fout)  # row (i, f) <- weight[o, f, i]
+        y = torch.addmm(self.filter.bias, x.reshape(N * (M // g), g * Fin), w2.to(x.dtype))
+        return y.reshape(N, M // g, self.Fout)
 
     call = forward
 
@@ -107,7 +135,13 @@ class HealpyPseudoConv_Transpose(torch.nn.Module):
         if self.filter is None:
             self.build(x.shape)
             self.filter.to(x.device)
-        return self.filter(x.transpose(1, 2)).transpose(1, 2)
+        # the mirror image: every input pixel writes its 4^p NEST children, consecutive rows of the output -- one GEMM of the
+        # (N * M) x Fin map against the [Fin, 4^p * Fout] view of the transposed-convolution weights, reshaped for free
+        N, M, Fin = x.shape
+        g = self.filter_size
+        w2 = self.filter.weight.permute(0, 2, 1).reshape(Fin, g * self.Fout)  # column (i, o) <- weight[f, o, i]
+        y = x.reshape(N * M, Fin) @ w2.to(x.dtype)
+        return y.reshape(N, M * g, self.Fout) + self.filter.bias
 
     call = forward
 

@@ -299,6 +299,20 @@ int dsph_rows_unpack(float* dst, int64_t dst_rows, const int32_t* idx, int64_t n
 int dsph_residual_epilogue(float* y, const float* skip, int64_t n, float alpha, int32_t act, int32_t act_before,
                            int device, void* hip_stream);
 
+/* Pooling over the 4^p NEST children of a HEALPix pixel, the step between two convolutions of every reference model.
+ * Replaces: the Keras MaxPool1D / AveragePooling1D inside healpy_layers.HealpyPool.call (healpy_layers.py:48-63,77-85;
+ * pool_size = strides = 4^p, padding "valid", channels last).
+ *   x  device (N, rows_out * group, F) fp32      y  device (N, rows_out, F) fp32      group = 4^p
+ *   y[n, m, f] = max | mean over i < group of x[n, group * m + i, f]
+ * The backward (the reference gets it from TensorFlow's autodiff): dx[n, group * m + i, f] = dy[n, m, f] / group for the mean;
+ * for the maximum dy[n, m, f] at the first child that holds it and 0 at the others (x: the forward input; may be NULL for the mean). */
+#define DSPH_POOL_MAX 0
+#define DSPH_POOL_AVG 1
+int dsph_healpix_pool(const float* x, float* y, int64_t N, int64_t rows_out, int32_t F, int32_t group, int32_t type, int device,
+                      void* hip_stream);
+int dsph_healpix_pool_backward(const float* x, const float* dy, float* dx, int64_t N, int64_t rows_out, int32_t F, int32_t group,
+                               int32_t type, int device, void* hip_stream);
+
 const char* dsph_last_error(void);
 int dsph_abi_version(void);
 

@@ -365,3 +365,51 @@ def residual_forward(Lt, x, kernels, K, layer_type="CHEBY", layer_biases=(None, 
     if act_before:  # (:410-411)
         return act(v) + alpha * inp
     return act(v + alpha * inp)  # (:413)
+
+
+# ----------------------------------------------------------------------------------------
+# the callers either side of the convolution: healpy_layers.HealpyPool / HealpyPseudoConv(_Transpose)
+# ----------------------------------------------------------------------------------------
+
+
+def healpy_pool(x, p, pool_type="MAX"):
+    """``HealpyPool.call`` (healpy_layers.py:20-85): Keras MaxPool1D / AveragePooling1D with pool_size = strides = 4^p,
+    padding "valid", channels last, on (batch, nodes, channels) -- i.e. the maximum / mean over each run of 4^p consecutive
+    nodes (the NEST children of one coarse pixel).  Raises IOError like the reference for p < 1, an unknown type
+    (:39-40, :64-65) or a node count that is not a multiple of 4^p (:73-75)."""
+    if not p >= 1:
+        raise IOError("The reduction factors has to be at least 2!")
+    if pool_type not in ("MAX", "AVG"):
+        raise IOError(f"Pooling type not understood: {pool_type}")
+    x = np.asarray(x)
+    g = int(4 ** p)
+    N, M, F = x.shape
+    if M % g != 0:
+        raise IOError(f"Input shape {x.shape} not compatible with the filter size {g}")
+    blocks = x.reshape(N, M // g, g, F)
+    return blocks.max(axis=2) if pool_type == "MAX" else blocks.mean(axis=2)
+
+
+def healpy_pseudo_conv(x, kernel, bias, p):
+    """``HealpyPseudoConv.call`` (healpy_layers.py:88-146): Keras Conv1D(Fout, 4^p, strides=4^p, padding "valid",
+    channels last); ``kernel`` in the Keras layout (4^p, Fin, Fout):  y[n, m, o] = sum_{i, f} x[n, 4^p m + i, f] kernel[i, f, o] + bias[o]."""
+    x = np.asarray(x)
+    g = int(4 ** p)
+    N, M, Fin = x.shape
+    kernel = np.asarray(kernel)
+    assert kernel.shape[:2] == (g, Fin)
+    y = np.einsum("nmif,ifo->nmo", x.reshape(N, M // g, g, Fin), kernel)
+    return y if bias is None else y + np.asarray(bias)
+
+
+def healpy_pseudo_conv_transpose(x, kernel, bias, p):
+    """``HealpyPseudoConv_Transpose.call`` (healpy_layers.py:156-216): Conv2DTranspose with kernel = strides = (1, 4^p) on the
+    map viewed as (batch, 1, nodes, channels); ``kernel`` (4^p, Fout, Fin) like Keras stores it (the leading 1 dropped):
+    y[n, 4^p m + i, o] = sum_f x[n, m, f] kernel[i, o, f] + bias[o]."""
+    x = np.asarray(x)
+    g = int(4 ** p)
+    N, M, Fin = x.shape
+    kernel = np.asarray(kernel)
+    assert kernel.shape[0] == g and kernel.shape[2] == Fin
+    y = np.einsum("nmf,iof->nmio", x, kernel).reshape(N, M * g, kernel.shape[1])
+    return y if bias is None else y + np.asarray(bias)

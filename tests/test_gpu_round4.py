@@ -387,3 +387,65 @@ def test_kept_weight_images_and_graph_replay(Fin, Fout, K):
         assert torch.equal(glayer(x), y4)
         x2 = x.clone()
         assert torch.equal(glayer(x2), y4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the callers either side of the convolution on the device -- NEST pooling kernels, pseudo-convolutions as GEMMs
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("p,F,pool_type", [(1, 16, "MAX"), (1, 16, "AVG"), (2, 5, "MAX"), (3, 7, "AVG"), (1, 64, "MAX")])
+def test_nest_pooling_kernels(p, F, pool_type):
+    """HealpyPool on the GPU (dsph_healpix_pool) against the oracle restatement of healpy_layers.py:20-85, bit for bit for
+    the maximum, to rounding for the mean; the input gradient (dsph_healpix_pool_backward) against the host framework's
+    autograd of the same reduction."""
+    from deepsphere import healpy_layers
+
+    nside, N = 16, 3
+    M = 12 * nside * nside
+    rng = np.random.default_rng(p * 100 + F)
+    x = rng.standard_normal((N, M, F)).astype(np.float32)
+    layer = healpy_layers.HealpyPool(p, pool_type)
+    xt = _dev(x).requires_grad_(True)
+    y = layer(xt)
+    ref = orc.healpy_pool(x.astype(np.float64), p, pool_type)
+    assert y.shape == ref.shape
+    if pool_type == "MAX":
+        assert np.array_equal(y.detach().cpu().numpy(), ref.astype(np.float32))
+    else:
+        assert rel_err(y.detach().cpu().numpy(), ref) < 1e-6
+    dy = rng.standard_normal(ref.shape).astype(np.float32)
+    y.backward(_dev(dy))
+    xr = torch.from_numpy(x).requires_grad_(True)
+    g = 4 ** p
+    blocks = xr.reshape(N, M // g, g, F)
+    (blocks.amax(dim=2) if pool_type == "MAX" else blocks.mean(dim=2)).backward(torch.from_numpy(dy))
+    assert rel_err(xt.grad.cpu().numpy(), xr.grad.numpy()) < 1e-6
+    with pytest.raises(IOError):
+        layer(_dev(x[:, : M - 1]))
+
+
+def test_pseudo_convolutions_against_the_oracle():
+    """HealpyPseudoConv / HealpyPseudoConv_Transpose (healpy_layers.py:88-216) as single GEMMs on the free reshaped views,
+    against the oracle restatements with the weights mapped to the Keras layouts."""
+    from deepsphere import healpy_layers
+
+    rng = np.random.default_rng(12)
+    N, M, Fin, Fout, p = 2, 768, 6, 10, 1
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    pc = healpy_layers.HealpyPseudoConv(p, Fout).cuda()
+    with torch.no_grad():
+        y = pc(_dev(x))
+        pc.filter.bias.normal_()
+        y = pc(_dev(x))
+        k = pc.filter.weight.permute(2, 1, 0).cpu().numpy()  # torch (Fout, Fin, 4^p) -> Keras (4^p, Fin, Fout)
+        ref = orc.healpy_pseudo_conv(x.astype(np.float64), k.astype(np.float64), pc.filter.bias.cpu().numpy().astype(np.float64), p)
+    assert rel_err(y.cpu().numpy(), ref) < 1e-5
+    pt = healpy_layers.HealpyPseudoConv_Transpose(p, Fout).cuda()
+    with torch.no_grad():
+        z = pt(_dev(x))
+        pt.filter.bias.normal_()
+        z = pt(_dev(x))
+        kt = pt.filter.weight.permute(2, 1, 0).cpu().numpy()  # torch (Fin, Fout, 4^p) -> (4^p, Fout, Fin)
+        reft = orc.healpy_pseudo_conv_transpose(x.astype(np.float64), kt.astype(np.float64), pt.filter.bias.cpu().numpy().astype(np.float64), p)
+    assert z.shape == (N, 4 * M, Fout) and rel_err(z.cpu().numpy(), reft) < 1e-5

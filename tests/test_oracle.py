@@ -277,3 +277,26 @@ def test_residual_block_with_norms_composes():
     v = orc.keras_batch_norm(orc.chebyshev_forward(Lt, x, k1, K, bias=b1, activation="elu"), **p1)
     v = orc.keras_batch_norm(orc.chebyshev_forward(Lt, v, k2, K, bias=b2, activation="elu"), **p2)
     assert rel_err(got, np.tanh(v + 0.3 * x)) < 1e-13
+
+
+def test_pooling_restatements_known_answers():
+    """HealpyPool / HealpyPseudoConv(_Transpose) (healpy_layers.py:20-216): known answers that need no oracle -- the children
+    of coarse pixel m are the rows 4^p m .. 4^p (m+1) - 1; a pseudo-convolution with a one-hot kernel picks one child; the
+    transposed one writes its input into one child."""
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 48, 3))
+    mx, av = orc.healpy_pool(x, 1, "MAX"), orc.healpy_pool(x, 1, "AVG")
+    assert mx.shape == (2, 12, 3)
+    assert np.array_equal(mx[1, 5], x[1, 20:24].max(axis=0)) and np.allclose(av[0, 11], x[0, 44:48].mean(axis=0))
+    assert np.array_equal(orc.healpy_pool(x, 2, "MAX")[0, 2], x[0, 32:48].max(axis=0))
+    for bad in (lambda: orc.healpy_pool(x, 0), lambda: orc.healpy_pool(x, 1, "MEAN"), lambda: orc.healpy_pool(x[:, :46], 1)):
+        with pytest.raises(IOError):
+            bad()
+    k = np.zeros((4, 3, 2))
+    k[2, 1, 0] = 1.0  # output channel 0 <- child 2, input channel 1
+    y = orc.healpy_pseudo_conv(x, k, np.array([0.5, -1.0]), 1)
+    assert np.allclose(y[..., 0], x[:, 2::4, 1] + 0.5) and np.allclose(y[..., 1], -1.0)
+    kt = np.zeros((4, 2, 3))
+    kt[3, 1, 2] = 2.0  # child 3, output channel 1 <- 2 * input channel 2
+    z = orc.healpy_pseudo_conv_transpose(x, kt, None, 1)
+    assert z.shape == (2, 192, 2) and np.allclose(z[:, 3::4, 1], 2.0 * x[:, :, 2]) and np.count_nonzero(z[:, 0::4]) == 0
