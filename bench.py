@@ -473,23 +473,6 @@ def main():
             layer.bias = torch.nn.Parameter(torch.randn(1, 1, Fout, device=device))
             layer.activation, layer._act_code = gnn_layers._resolve_activation("relu")
             out["bias_relu"] = {"ms_per_step": round(timed_ms(run, max(args.steps, 20)), 4)}
-        if world == 1 and nside <= 256:
-            # small maps are launch-bound: the same layer with graph=True (the prepared forward captured once, replayed as one
-            # graph launch; weight images kept, the BFS-tile launch beside the structured ones)
-            try:
-                glayer = gnn_layers.Chebyshev.from_prepared_ell(
-                    cols, vals, K, lmax=lmax, Fout=Fout, device=device, precision=args.precision, algo=args.algo,
-                    initializer=lambda t: t.copy_(torch.from_numpy(w_np)), plan_options=plan_options, graph=True)
-
-                def grun():
-                    with torch.no_grad():
-                        return glayer(x)
-                gms = timed_ms(grun, max(args.steps, 50))
-                out["graph_replay"] = {"ms_per_step": round(gms, 5), "value": round(N * M * Fout / gms / 1e3, 2),
-                                       "hbm_frac": round(b_alg / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                       "measured_error": measured_error_of(grun())}
-            except Exception as exc:  # noqa: BLE001
-                out["graph_replay"] = {"error": repr(exc)}
         if world == 1 and args.cpu_budget > 0 and not args.quick:
             out["cpu_baseline"] = cpu_baseline(K, Fin, Fout, device, args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -278,7 +278,7 @@ def test_backward_precision_is_resolved_per_contraction():
     (128, 1, 32, 32, 8, "chebyshev"),   # several tiles per workgroup
     (64, 2, 16, 16, 9, "monomial"),     # the other basis: L^{4+j} = L^4 L^j
     (64, 1, 3, 5, 7, "chebyshev"),      # channel counts that get padded
-    (64, 1, 8, 8, 17, "chebyshev"),     # K > 13: the terms of the inner levels are no longer plain slices of the kernel
+    (64, 1, 16, 16, 17, "chebyshev"),   # K > 13: the terms of the inner levels are no longer plain slices of the kernel
 ])
 def test_high_order_through_the_product_identity(nside, N, Fin, Fout, K, basis, prec, tol):
     """Whole maps against the float64 oracle with the split route forced (DSPH_OPT_SPLIT = always), bias + ReLU in the last
@@ -307,8 +307,9 @@ def test_high_order_through_the_product_identity(nside, N, Fin, Fout, K, basis, 
         assert eb < (2 * tol if (prec == "bf16x3" and Fin < 16) else tol)
     print(msg)
     # (the three-term split with fewer than 16 input channels has no 1e-5 guarantee -- a handful of products per output --
-    # and no layer uses it there unless asked: held to 2e-5 like tools/fuzz_gpu.py does)
-    assert err < (2 * tol if (prec == "bf16x3" and Fin < 16) else tol)
+    # and no layer uses it there unless asked: held to 2e-5 like tools/fuzz_gpu.py does; with four passes,
+    # K > 13, every pass re-rounds its input to bf16 hi + lo: 2e-5 there too)
+    assert err < (2 * tol if (prec == "bf16x3" and (Fin < 16 or K > 13)) else tol)
 
 
 def test_high_order_layer_like_the_tutorials():
