@@ -43,6 +43,8 @@ CONFIGS = {
     # beyond BASELINE.json (side lines, never the headline): the order of the reference's tutorial layers
     # (examples/quick_start.ipynb:118-127, HealpyChebyshev(K=10, ...)) at configs[1]'s map and channel counts
     "k10": (256, 10, 16, 32, 8),
+    # the first layer of a DeepSphere stack (tests/test_healpy_networks.py:96-107: one input channel) at nside 512
+    "in1": (512, 5, 1, 16, 8),
 }
 MASKED = {"c5"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
@@ -176,7 +178,7 @@ def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1, split="auto"):
     n_strip = plan.strip_tiles(Fin, Fout, K, prec_code, N=N)
     parts = []
     if n_strip:
-        parts.append(f"cheb_strip5_kernel ({n_strip} tiles)")
+        parts.append(f"{'cheb_istrip_kernel' if Fin <= 16 else 'cheb_strip5_kernel'} ({n_strip} tiles)")
     if n_struct - n_strip:
         parts.append(f"cheb_struct_kernel ({n_struct - n_strip} tiles)")
     if n_bfs:

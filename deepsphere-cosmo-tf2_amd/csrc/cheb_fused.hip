@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "cheb_fused_kernel.h"
+#include "cheb_istrip_kernel.h"
 #include "cheb_strip_kernel.h"
 #include "cheb_struct_kernel.h"
 
@@ -76,6 +77,13 @@ struct FusedTiles {
   std::vector<StripPair> h_pairs;          // host copy of d_pairs (dsph_plan_strip_pairs: what the seam tests read)
   mutable std::map<int64_t, int64_t> strip_span;  // batch N -> steps of the busiest workgroup (strip_makespan; under FusedPlan::mu)
   bool strip_forced = false;               // DSPH_OPT_STRIPS = 1 when the tables were built: the cost gate is off
+  // input-side strip kernel (cheb_istrip_kernel.h): the same rectangles, uncut along y (the kernel cuts every strip into the
+  // number of row segments that istrip_segments picks for the batch)
+  StripPair* d_ipairs = nullptr;
+  int n_ipairs = 0;
+  std::vector<int32_t> ipair_h;             // rows of every pair
+  std::vector<unsigned char> ipair_second;  // whether its second strip exists
+  mutable std::map<int64_t, int> iseg;      // batch N -> row segments per strip (under FusedPlan::mu)
   // every tile of the plan, the interior ones first (d_all[0 .. n_all_interior)): what a two-part launch with a deferred
   // activation finishes per part (launch_struct_act_tiles)
   int32_t* d_all = nullptr;
@@ -128,6 +136,7 @@ static void free_tiles(FusedTiles& ft) {
   if (ft.d_pairs) (void)hipFree(ft.d_pairs);
   if (ft.d_rrest) (void)hipFree(ft.d_rrest);
   if (ft.d_all) (void)hipFree(ft.d_all);
+  if (ft.d_ipairs) (void)hipFree(ft.d_ipairs);
   ft = FusedTiles();
 }
 
@@ -351,9 +360,11 @@ static int64_t strip_makespan(const std::vector<int32_t>& steps, int64_t N, int 
 // least 4 tile rows; a rectangle is cut into 32-column strips with 24 output columns each, two strips per workgroup item,
 // and into row segments sized so that the items fill the CUs evenly.  The other tiles stay with the tile kernels (`rest`).
 static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_cu, const PlanOptions& opt,
-                         std::vector<StripPair>& pairs, std::vector<int32_t>& rest, int64_t* n_taken, std::vector<int32_t>& steps) {
+                         std::vector<StripPair>& pairs, std::vector<int32_t>& rest, int64_t* n_taken, std::vector<int32_t>& steps,
+                         std::vector<StripPair>& whole) {  // whole: the same strips uncut along y (input-side strip kernel)
   steps.clear();
   pairs.clear();
+  whole.clear();
   rest.clear();
   *n_taken = 0;
   struct Rect { int tx, ty, wt, ht; };
@@ -500,6 +511,7 @@ static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_
   if (opt.strip_seg > 0) best_h = std::max(16, opt.strip_seg);  // (tuning, DSPH_OPT_STRIP_SEG: the segment height, in rows)
   cut(best_h, pairs);
   steps_of(pairs, steps);
+  cut(1 << 30, whole);
 #ifdef DSPH_ABLATE
   if (getenv("DSPH_STRIP_DEBUG"))
     fprintf(stderr, "build_strips: segments of %d rows, %zu pairs, busiest workgroup %ld / %ld / %ld steps for 1 / 4 / 16 maps; tile cost "
@@ -699,18 +711,27 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   interior.insert(interior.end(), boundary.begin(), boundary.end());
   ft.n_part = (int)interior.size();
   if (interior.empty()) interior.push_back(0);
-  std::vector<StripPair> pairs;
+  std::vector<StripPair> pairs, ipairs;
   std::vector<int32_t> rrest;
   ft.n_strip_tiles = 0;
   ft.strip_steps.clear();
   ft.strip_span.clear();
   ft.strip_forced = plan->opt.strips == 1;
   if (!full && D <= SP_DMAX && plan->opt.strips != 2)
-    build_strips(r_interior, D, fp->num_cu, plan->opt, pairs, rrest, &ft.n_strip_tiles, ft.strip_steps);
+    build_strips(r_interior, D, fp->num_cu, plan->opt, pairs, rrest, &ft.n_strip_tiles, ft.strip_steps, ipairs);
   else
     rrest = r_interior;
   ft.n_pairs = (int)pairs.size();
   ft.h_pairs = pairs;
+  ft.n_ipairs = (int)ipairs.size();
+  ft.ipair_h.clear();
+  ft.ipair_second.clear();
+  ft.iseg.clear();
+  for (const StripPair& ip : ipairs) {
+    ft.ipair_h.push_back(ip.y1 - ip.y0);
+    ft.ipair_second.push_back(ip.w[1] > 0 ? 1 : 0);
+  }
+  if (ipairs.empty()) ipairs.push_back(StripPair());
   ft.n_rrest_interior = (int)rrest.size();
   rrest.insert(rrest.end(), r_boundary.begin(), r_boundary.end());
   ft.n_rrest = (int)rrest.size();
@@ -739,7 +760,8 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
               up((void**)&ft.d_rlist, r_interior.data(), r_interior.size() * 4) &&
               up((void**)&ft.d_rrest, rrest.data(), rrest.size() * 4) &&
               up((void**)&ft.d_all, all_tiles.data(), all_tiles.size() * 4) &&
-              up((void**)&ft.d_pairs, pairs.data(), pairs.size() * sizeof(StripPair));
+              up((void**)&ft.d_pairs, pairs.data(), pairs.size() * sizeof(StripPair)) &&
+              up((void**)&ft.d_ipairs, ipairs.data(), ipairs.size() * sizeof(StripPair));
   if (!good) {
     FusedTiles keep = ft;
     free_tiles(ft);
@@ -765,7 +787,8 @@ static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
 
 // weight images of the three fused kernels, back to back in the workspace: BFS-tile | structured-tile | strip
 static size_t all_frag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
-  return wfrag_bytes(Fin, Fout, K) + struct_wfrag_bytes(Fin, Fout, K) + strip_wimg_bytes(Fin, Fout, K);
+  return wfrag_bytes(Fin, Fout, K) + struct_wfrag_bytes(Fin, Fout, K) + strip_wimg_bytes(Fin, Fout, K) +
+         2 * istrip_wimg_bytes(K, DSPH_PREC_BF16X6);  // (the largest of the three arithmetics, two 32-column blocks)
 }
 
 // The structured-tile kernel addresses x by 32-bit byte offsets inside a map: larger maps take BFS tables throughout.
@@ -853,10 +876,29 @@ static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fi
   return span * 30 * 103 < ft.n_strip_tiles * N * 187 / fp->num_cu * 100;
 }
 
+// The input-side strip kernel takes the rectangles of every layer with at most 16 input channels (any arithmetic, K = 2 .. 5,
+// any output width), unless DSPH_OPT_STRIPS says never.  No cost rule: its workers are single waves and the kernel cuts the
+// strips into as many row segments as the batch needs, so small maps fill the device too (istrip_segments).
+static bool istrips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t K) {
+  return ft.n_ipairs > 0 && plan->opt.strips != 2 && istrip_shape_ok(Fin, K);
+}
+static int istrip_nseg(const dsph_plan* plan, const FusedTiles& ft, int64_t N, int D) {
+  FusedPlan* fp = plan->fused;
+  std::lock_guard<std::mutex> lock(fp->mu);
+  auto it = ft.iseg.find(N);
+  if (it == ft.iseg.end()) it = ft.iseg.emplace(N, istrip_segments(ft.ipair_h, ft.ipair_second, N, fp->num_cu, D)).first;
+  return it->second;
+}
+
 // tiles a forward of this shape hands to the strip kernel: the same predicate the launch uses, for the layer's first 64-column
 // block (a layer with Fout = 96 runs its first block through the strips and reports them; one with Fout < 64 has none)
 int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision) {
-  if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX || Fin != pad4(Fin) || Fout < 64) return 0;
+  if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return 0;
+  if (istrip_shape_ok(pad4(Fin), K)) {
+    const FusedTiles& fti = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
+    return fti.ok && istrips_apply(plan, fti, pad4(Fin), K) ? fti.n_strip_tiles : 0;
+  }
+  if (Fin != pad4(Fin) || Fout < 64) return 0;
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
   if (!ft.ok) return 0;
   return strips_apply(plan, ft, Fin, 64, K, precision, N, Fout) ? ft.n_strip_tiles : 0;
@@ -1179,8 +1221,26 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       const int rc = launch_cheb_strip(st, stream);
       if (rc != DSPH_OK) return rc;
     }
-    const int32_t* rl = strips ? ft.d_rrest : ft.d_rlist;
-    const int rl_n = strips ? ft.n_rrest : ft.n_r, rl_ni = strips ? ft.n_rrest_interior : ft.n_r_interior;
+    const bool istrips = !strips && istrips_apply(plan, ft, Fin, K);
+    if (istrips && part != 2 && !dbg_only('b')) {
+      IStripLaunch is;
+      is.x = x; is.w = w; is.bias = bias; is.y = y;
+      is.wimg = static_cast<unsigned char*>(workspace) + wb + struct_wfrag_bytes(Fin, Fout, K) + strip_wimg_bytes(Fin, Fout, K);
+      is.pairs = ft.d_ipairs;
+      is.gvals8 = plan->fused->d_gvals8;
+      is.gdiag = plan->fused->d_gdiag;
+      is.x_rows = sl.x_rows; is.y_rows = sl.y_rows; is.N = N;
+      is.npairs = ft.n_ipairs; is.Fin = Fin; is.Fin_w = Fin_w; is.Fout = Fout; is.K = K; is.act = act; is.precision = precision; is.ld = ld;
+      is.num_cu = plan->fused->num_cu;
+      is.nseg = istrip_nseg(plan, ft, N, K - 1);
+      is.cheb = sl.cheb;
+      is.prep_weights = !keep_weights;
+      const int rc = launch_cheb_istrip(is, stream);
+      if (rc != DSPH_OK) return rc;
+    }
+    const bool stripped = strips || istrips;
+    const int32_t* rl = stripped ? ft.d_rrest : ft.d_rlist;
+    const int rl_n = stripped ? ft.n_rrest : ft.n_r, rl_ni = stripped ? ft.n_rrest_interior : ft.n_r_interior;
     const int nr = part == 0 ? rl_n : (part == 1 ? rl_ni : rl_n - rl_ni);
     if (nr > 0 && !dbg_only('b')) {
       sl.tiles = part == 2 ? rl + rl_ni : rl;

@@ -1,0 +1,375 @@
+// Input-side strip form of the fused Chebyshev forward (round 4): layers with few input channels.
+//
+// The strip kernel of round 3 (cheb_strip_kernel.h) runs Clenshaw's recurrence on OUTPUT-channel planes; that is the right
+// side when the layer has as many input as output channels.  The layers a DeepSphere stack starts with have few inputs
+// and more outputs (1 -> 16 -> 32 -> 64, reference tests/test_healpy_networks.py:96-107; BASELINE configs[0] and [1]):
+// there the recurrence belongs on the INPUT side, exactly as the reference writes it (gnn_layers.py:134-143),
+//     T_0 = x,  T_1 = L~ x,  T_k = 2 L~ T_{k-1} - T_{k-2},      y = sum_k T_k W_k            (gnn_layers.py:144-150)
+// and with at most 16 input channels a whole strip of it fits ONE wave:
+//   * lane = (pixel column px = lane & 31 of a 32-pixel strip row, half g = lane >> 5), registers = CH of the row's input
+//     channels (CH = 8: channels 8 g .. 8 g + 7 of 16; CH = 4: channels 4 g .. 4 g + 3 of 8) -- which is, register for
+//     register, the B operand of v_mfma_f32_32x32x16_bf16 (column = pixel, inner index 8 g + j): a plane row goes from
+//     the recurrence into the matrix pipe with a bf16 split and nothing else, no LDS, no re-layout;
+//   * the strip is streamed along y, level k lagging k rows behind x: the y-neighbours of a pixel are the previous / next
+//     rows in the same lane's registers (three rows per plane, rotated through a 3-phase unrolled step), the
+//     x-neighbours the adjacent lanes, read through the DPP operand of the multiply-add (as in cheb_strip_kernel.h);
+//   * y[r] collects W_0 T_0[r] + W_1 T_1[r] + W_2 T_2[r] in the step that makes T_2[r] (T_0[r] and T_1[r] are still in
+//     their rings then), W_3 T_3[r] one step later, W_4 T_4[r] after that: three accumulator rows in flight; the weights
+//     of all levels sit in LDS as MFMA A-operand fragments (10 KiB, read per contraction: fifteen 1 KiB reads per step);
+//   * a wave needs nothing from any other wave: no barrier, no hand-over, no roles.  A workgroup is eight independent
+//     workers; the work items are (strip segment, map).  LDS holds, per wave, a ring of the last rows of L~ (nine values per
+//     pixel) and the 4 KiB block through which a finished y row is turned so that eight lanes store 128 contiguous bytes.
+// x is read once per strip row (1.33 x in all: 24 of 32 columns are output) straight into the registers, y written once.
+// Shapes: K = 2 .. 5, at most 16 input channels (a multiple of four; other counts arrive zero-padded), 32 output columns
+// per launch (wider layers: one launch per block), all three contraction arithmetics, both bases.
+// Which pixels: the strip rectangles of cheb_fused.hip (class-R tiles), cut into single strips and short segments.
+#pragma once
+
+#include <type_traits>
+
+#include "cheb_strip_kernel.h"
+
+namespace dsph {
+
+constexpr int IS_THREADS = 512;
+constexpr int IS_WAVES = 8;
+constexpr int IS_CRING = 6;                    // rows of L~ held per wave: ytop - 4 .. ytop + 1
+constexpr int IS_CROWB = 32 * 32 + 32 * 4;     // one ring row: [px][8 directions] + [px] diagonal
+constexpr int IS_YSTB = 4096;                  // y staging block: 32 pixels x 32 channels
+constexpr int IS_WAVEB = IS_CRING * IS_CROWB + IS_YSTB;
+
+struct IStripArgs {
+  const float* x;
+  const float* bias;          // of this launch's 32-column block, or NULL
+  float* y;                   // column 0 of this launch's block
+  const unsigned char* wimg;  // istrip_wprep_kernel: [level][term][64 lanes][16 B]
+  const float* gvals8;
+  const float* gdiag;
+  const StripPair* pairs;     // every pair is two single strips here
+  int64_t x_rows, y_rows;
+  int npairs, N, Fin, Fout, ld, act;  // Fout: columns of this block (<= 32)
+  int nseg;                           // every strip is cut into nseg row segments (chosen per call: istrip_segments)
+  float alpha_rest, beta_rest;        // T_k = alpha L~ T_{k-1} - beta T_{k-2}, k >= 2 (2, 1 Chebyshev; 1, 0 monomial)
+};
+
+typedef float is_f32x8 __attribute__((ext_vector_type(8)));
+
+// number of A-operand fragments per level: hi | lo (three-term split), hi | mid | lo (six-term), 8 fp32 steps (exact)
+__host__ __device__ constexpr int is_terms(int prec) { return prec == DSPH_PREC_BF16X3 ? 2 : (prec == DSPH_PREC_BF16X6 ? 3 : 8); }
+__host__ __device__ constexpr int is_term_bytes(int prec) { return prec == DSPH_PREC_FP32 ? 256 : 1024; }
+
+// acc += cw * src[x-1] + cc * src[x] + ce * src[x+1] for the lane's CH channels (see sp_row)
+template <int CH>
+__device__ __forceinline__ void is_row(float (&acc)[CH], const float (&src)[CH], float cw, float cc, float ce) {
+#pragma unroll
+  for (int c = 0; c < CH; ++c) acc[c] = fmaf(cc, src[c], acc[c]);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    float t = acc[c];
+    sp_fmac_left(t, src[c], cw);
+    sp_fmac_right(t, src[c], ce);
+    acc[c] = t;
+  }
+}
+// (a VALU result read through DPP, or as an MFMA operand, needs two wait states: the row as an operand of an s_nop)
+template <int CH> __device__ __forceinline__ void is_fence(float (&v)[CH]) {
+  if (CH == 8)
+    asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4 % CH]), "+v"(v[5 % CH]), "+v"(v[6 % CH]), "+v"(v[7 % CH]));
+  else
+    asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+
+// the B operand(s) of a plane row: 8 inner-index slots per lane, slot j <- channel j of the lane's CH (zero beyond CH)
+struct IsFrag {
+  sp_bf16x8 t[3];  // hi, lo (three-term) / hi, mid, lo (six-term)
+};
+template <int CH, int PREC>
+__device__ __forceinline__ IsFrag is_split(const float (&v)[CH]) {
+  IsFrag f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = j < CH ? v[j < CH ? j : 0] : 0.f;
+    if (PREC == DSPH_PREC_BF16X3) {
+      const __bf16 h = (__bf16)a;
+      f.t[0][j] = h;
+      f.t[1][j] = (__bf16)(a - (float)h);
+      f.t[2][j] = (__bf16)0.f;
+    } else {
+      // exact split into 8 + 8 + 8 mantissa bits by truncation (cheb_struct_kernel.h, st_contract): a = h + m + l
+      const unsigned au = __builtin_bit_cast(unsigned, a);
+      const float h = __builtin_bit_cast(float, au & 0xffff0000u);
+      const float r = a - h;
+      const unsigned ru = __builtin_bit_cast(unsigned, r);
+      const float m = __builtin_bit_cast(float, ru & 0xffff0000u);
+      const float l = r - m;
+      f.t[0][j] = __builtin_bit_cast(__bf16, (unsigned short)(au >> 16));
+      f.t[1][j] = __builtin_bit_cast(__bf16, (unsigned short)(ru >> 16));
+      f.t[2][j] = (__bf16)l;  // (at most 8 significant bits left: exact)
+    }
+  }
+  return f;
+}
+
+// acc (+)= W_level . row: the contraction of one plane row with the weights of its level
+template <int CH, int PREC, bool INIT>
+__device__ __forceinline__ void is_contract(sp_f32x16& acc, const float (&row)[CH], const unsigned char* __restrict__ wlev, int lane) {
+  if (INIT) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  }
+  if (PREC == DSPH_PREC_FP32) {
+    // v_mfma_f32_32x32x2_f32: inner index = 2 s + (lane >> 5); the lane's operand of step s is slot j = s of the OTHER layout,
+    // so the eight steps walk the lane's eight slots: step s contracts channels {slot s of half 0, slot s of half 1}
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      const float b = row[s];
+      const float wa = *reinterpret_cast<const float*>(wlev + s * 256 + lane * 4);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, b, acc, 0, 0, 0);
+    }
+    return;
+  }
+  const IsFrag f = is_split<CH, PREC>(row);
+  const sp_bf16x8 w0 = *reinterpret_cast<const sp_bf16x8*>(wlev + lane * 16);
+  const sp_bf16x8 w1 = *reinterpret_cast<const sp_bf16x8*>(wlev + 1024 + lane * 16);
+  if (PREC == DSPH_PREC_BF16X3) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, f.t[1], acc, 0, 0, 0);  // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f.t[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, f.t[0], acc, 0, 0, 0);
+  } else {
+    const sp_bf16x8 w2 = *reinterpret_cast<const sp_bf16x8*>(wlev + 2048 + lane * 16);
+    // the six products down to 2^-16: hl, lh, mm, hm, mh, hh (w index first)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, f.t[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, f.t[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f.t[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, f.t[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f.t[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, f.t[0], acc, 0, 0, 0);
+  }
+}
+
+template <int K, int CH, int PREC>
+__global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a) {
+  constexpr int D = K - 1;
+  constexpr int G = K - 1 < 2 ? K - 1 : 2;          // y[r] is opened in the step that makes T_G[r]
+  constexpr int NP = K - 1;                          // planes with a ring: T_0 .. T_{K-2}
+  constexpr int WLEVB = is_terms(PREC) * is_term_bytes(PREC);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[IS_WAVES * IS_WAVEB + K * WLEVB + 128];
+  unsigned char* const sW = smem + IS_WAVES * IS_WAVEB;   // the weights of all levels (read per contraction: 2 - 3 ds_read_b128)
+  float* const sBias = reinterpret_cast<float*>(sW + K * WLEVB);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 31, g = lane >> 5;
+  unsigned char* const cring = smem + wave * IS_WAVEB;
+  unsigned char* const yst = cring + IS_CRING * IS_CROWB;
+
+  for (int i = tid; i < K * WLEVB / 16; i += IS_THREADS) reinterpret_cast<sp_f32x4*>(sW)[i] = reinterpret_cast<const sp_f32x4*>(a.wimg)[i];
+  if (tid < 32) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
+  __syncthreads();  // (the only barrier of the kernel)
+
+  const int G_ = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+  const int nslots = (G_ + 7 - xcd) / 8;
+  // work items: (pair, strip of the pair, row segment, map); a contiguous eighth of them per XCD, dealt to the XCD's waves in turn
+  const int64_t n_items = (int64_t)a.npairs * 2 * a.nseg * a.N;
+  const int64_t q_begin = n_items * xcd / 8, q_end = n_items * (xcd + 1) / 8;
+  const unsigned xrowb = (unsigned)a.Fin * 4u, yrowb = (unsigned)a.ld * 4u;
+  const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
+  const int nch = a.Fin;  // real channels (multiple of four); this lane's are CH * g .. CH * g + CH - 1
+
+  for (int64_t q = q_begin + slot0 * IS_WAVES + wave; q < q_end; q += (int64_t)nslots * IS_WAVES) {
+    const int n = (int)(q % a.N);
+    const int sg = (int)((q / a.N) % a.nseg);
+    const int e = (int)((q / ((int64_t)a.N * a.nseg)) & 1);
+    const int p = (int)(q / (2 * (int64_t)a.N * a.nseg));
+    StripPair pr = a.pairs[p];
+    {
+      const int H = pr.y1 - pr.y0, ya = pr.y0 + (int)((int64_t)H * sg / a.nseg), yb = pr.y0 + (int)((int64_t)H * (sg + 1) / a.nseg);
+      pr.y0 = ya;
+      pr.y1 = yb;
+      if (yb <= ya) continue;
+    }
+    const int x0 = e ? pr.x0[1] : pr.x0[0], wuse = e ? pr.w[1] : pr.w[0], xs = e ? pr.xs[1] : pr.xs[0];
+    if (wuse <= 0) continue;
+    const unsigned sX = st_spread((unsigned)min(max(xs + px, pr.xlo), pr.xhi));
+    const unsigned sXs = st_spread((unsigned)(xs + (lane >> 3)));  // the pixel whose y chunk this lane stores (instruction 0)
+    const int pfirst = x0 - xs, plast = x0 - xs + wuse;
+    const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)n * a.x_rows * xrowb;
+    char* __restrict__ ymap = reinterpret_cast<char*>(a.y) + (size_t)n * a.y_rows * yrowb;
+    auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
+      return st_spread((unsigned)min(max(yrow, pr.ylo), pr.yhi)) << 1;
+    };
+
+    float P[NP > 0 ? NP : 1][3][CH];
+    sp_f32x16 Y[3];
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) P[k][s][c] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int c = 0; c < 16; ++c) Y[s][c] = 0.f;
+
+    // the row of x being fetched (this lane's CH channels) and the row of L~ being fetched
+    float xin[CH];
+    sp_f32x4 cv;
+    float cd;
+    auto xfetch = [&](int yrow) __attribute__((always_inline)) {
+      const char* src = xmap + (size_t)(sX | spread_y(yrow)) * xrowb + (unsigned)(CH * g) * 4u;
+#pragma unroll
+      for (int c4 = 0; c4 < CH / 4; ++c4) {
+        sp_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (CH * g + 4 * c4 < nch) v = *reinterpret_cast<const sp_f32x4*>(src + 16 * c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xin[4 * c4 + j] = v[j];
+      }
+    };
+    auto cfetch = [&](int yrow) __attribute__((always_inline)) {
+      const unsigned rid = sX | spread_y(yrow);
+      cv = *reinterpret_cast<const sp_f32x4*>(reinterpret_cast<const char*>(a.gvals8) + (size_t)rid * 32u + (unsigned)g * 16u);
+      cd = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.gdiag) + (size_t)rid * 4u);
+    };
+    auto cstore = [&](int slot) __attribute__((always_inline)) {
+      unsigned char* pr_ = cring + (unsigned)slot * IS_CROWB;
+      *reinterpret_cast<sp_f32x4*>(pr_ + (unsigned)px * 32u + (unsigned)g * 16u) = cv;
+      if (g == 0) *reinterpret_cast<float*>(pr_ + 1024 + (unsigned)px * 4u) = cd;
+    };
+    auto c9 = [&](int slot) __attribute__((always_inline)) -> SpCoef {
+      const unsigned char* pr_ = cring + (unsigned)slot * IS_CROWB;
+      SpCoef c;
+      c.a = *reinterpret_cast<const sp_f32x4*>(pr_ + (unsigned)px * 32u);
+      c.b = *reinterpret_cast<const sp_f32x4*>(pr_ + (unsigned)px * 32u + 16u);
+      c.d = *reinterpret_cast<const float*>(pr_ + 1024 + (unsigned)px * 4u);
+      return c;
+    };
+
+    // steps t = 0 .. : row ytop = y0 - D + t of x arrives; ring slot of the row with step index u is u mod 3 (planes and
+    // accumulators), u mod IS_CRING (rows of L~).  Prologue: the rows of x and L~ of step 0.
+    const int ybase = pr.y0 - D;
+    const int T3 = ((pr.y1 - pr.y0) + 2 * D + 2) / 3;  // steps, in threes: output row yr leaves at step yr + D - ybase = yr - y0 + 2 D
+    xfetch(ybase);
+    cfetch(ybase);
+    int cs = 0;  // L~ ring slot of row ybase + t
+    auto step = [&](auto ph_c, int t) __attribute__((always_inline)) {
+      constexpr int PH = decltype(ph_c)::value;  // t mod 3
+      const int ytop = ybase + t;
+      // this step's rows land: x -> T_0[new], the row of L~ -> its ring slot; the next ones go out
+#pragma unroll
+      for (int c = 0; c < CH; ++c) P[0][PH][c] = xin[c];
+      cstore(cs);
+      xfetch(ytop + 1);
+      cfetch(ytop + 1);
+      __builtin_amdgcn_wave_barrier();  // (the ring row just written is read below by other lanes of this wave)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+      // levels 1 .. K-1: T_k[ytop - k] from the rows ytop-k-1, ytop-k, ytop-k+1 of T_{k-1}
+      float top[CH];  // T_{K-1}[ytop - (K-1)]: never stored
+#pragma unroll
+      for (int k = 1; k <= K - 1; ++k) {
+        constexpr int dummy = 0; (void)dummy;
+        // ring slots: row with step index u sits in slot u mod 3; T_{k-1}'s newest row has index t - (k-1)
+        const int s_new = ((PH - (k - 1)) % 3 + 3) % 3, s_mid = (s_new + 2) % 3, s_old = (s_new + 1) % 3;
+        int cslot = cs - k;
+        cslot += cslot < 0 ? IS_CRING : 0;
+        const SpCoef cf = c9(cslot);
+        float acc[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+        is_row<CH>(acc, P[k - 1][s_old], cf.b[3], cf.b[2], cf.b[1]);  // y-1: directions 7, 6, 5
+        is_row<CH>(acc, P[k - 1][s_mid], cf.a[0], cf.d, cf.b[0]);     // y  : 0, diagonal, 4
+        is_row<CH>(acc, P[k - 1][s_new], cf.a[1], cf.a[2], cf.a[3]);  // y+1: 1, 2, 3
+        if (k >= 2) {
+          // T_k = alpha (L~ T_{k-1}) - beta T_{k-2}[ytop - k]: the oldest row of T_{k-2}'s ring (index t - k = (t - (k-2)) - 2)
+          const int s2 = (((PH - (k - 2)) % 3 + 3) % 3 + 1) % 3;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) acc[c] = fmaf(a.alpha_rest, acc[c], -a.beta_rest * P[k - 2][s2][c]);
+        }
+        is_fence<CH>(acc);
+        if (k <= K - 2) {
+          const int s_k = ((PH - k) % 3 + 3) % 3;  // T_k's newest row, index t - k
+#pragma unroll
+          for (int c = 0; c < CH; ++c) P[k][s_k][c] = acc[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) top[c] = acc[c];
+        }
+      }
+      // contraction.  Row r = ytop - G is opened with levels 0 .. G; every level k > G adds to row ytop - k; row ytop - (K-1) is
+      // complete.  Accumulator slot of the row with step index u: u mod 3.
+      {
+        const int sy = ((PH - G) % 3 + 3) % 3;
+#pragma unroll
+        for (int k = 0; k <= G; ++k) {
+          // T_k[ytop - G]: index t - G in T_k's ring (k <= K-2), or the transient top row (k == K-1 == G)
+          if (k <= K - 2) {
+            const int s = ((PH - G) % 3 + 3) % 3;
+            if (k == 0) is_contract<CH, PREC, true>(Y[sy], P[k][s], sW + k * WLEVB, lane);
+            else is_contract<CH, PREC, false>(Y[sy], P[k][s], sW + k * WLEVB, lane);
+          } else {
+            is_contract<CH, PREC, false>(Y[sy], top, sW + k * WLEVB, lane);
+          }
+        }
+#pragma unroll
+        for (int k = G + 1; k <= K - 1; ++k) {
+          const int syk = ((PH - k) % 3 + 3) % 3;
+          if (k <= K - 2) is_contract<CH, PREC, false>(Y[syk], P[k][((PH - k) % 3 + 3) % 3], sW + k * WLEVB, lane);
+          else is_contract<CH, PREC, false>(Y[syk], top, sW + k * WLEVB, lane);
+        }
+      }
+      // y of row ytop - (K-1): through the staging block so that eight lanes store 128 contiguous bytes (cheb_strip_kernel.h)
+      {
+        const int yr = ytop - D;
+        const sp_f32x16& Yd = Y[((PH - D) % 3 + 3) % 3];
+        auto run_base = [](unsigned run) -> unsigned { return run * 256u; };
+        {
+          const unsigned run = (unsigned)px >> 1;
+          unsigned char* wp = yst + run_base(run) + ((unsigned)px & 1u) * 128u;
+#pragma unroll
+          for (int tq = 0; tq < 4; ++tq)
+            *reinterpret_cast<sp_f32x4*>(wp + (((unsigned)(2 * tq + g)) ^ (run & 7u)) * 16u) =
+                sp_f32x4{Yd[4 * tq], Yd[4 * tq + 1], Yd[4 * tq + 2], Yd[4 * tq + 3]};
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool row_ok = yr >= pr.y0 && yr < pr.y1;
+        const unsigned sY = st_spread((unsigned)max(yr, 0)) << 1;
+        const int och = 4 * (lane & 7);
+        const sp_f32x4 bv = *reinterpret_cast<const sp_f32x4*>(sBias + och);
+        sp_f32x4 yo4[4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const unsigned pk = 8u * k4 + ((unsigned)lane >> 3), run = pk >> 1;
+          yo4[k4] = *reinterpret_cast<const sp_f32x4*>(yst + run_base(run) + (pk & 1u) * 128u + ((((unsigned)lane & 7u)) ^ (run & 7u)) * 16u);
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const unsigned pk = 8u * k4 + ((unsigned)lane >> 3);
+          if (row_ok && (int)pk >= pfirst && (int)pk < plast && och < a.Fout) {
+            const unsigned rid = (((sXs | 0xAAAAAAAAu) + st_spread(8u * k4)) & 0x55555555u) | sY;
+            float* dst = reinterpret_cast<float*>(ymap + (size_t)rid * yrowb) + och;
+            sp_f32x4 o;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) o[e4] = fmaxf(yo4[k4][e4] + bv[e4], floor_v);
+            if (och + 4 <= a.Fout && (a.ld & 3) == 0) *reinterpret_cast<sp_f32x4*>(dst) = o;
+            else {
+#pragma unroll
+              for (int e4 = 0; e4 < 4; ++e4)
+                if (och + e4 < a.Fout) dst[e4] = o[e4];
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // (the block is rewritten in the next step)
+      }
+      cs = cs + 1 == IS_CRING ? 0 : cs + 1;
+    };
+    for (int t3 = 0; t3 < T3; ++t3) {
+      step(std::integral_constant<int, 0>{}, 3 * t3);
+      step(std::integral_constant<int, 1>{}, 3 * t3 + 1);
+      step(std::integral_constant<int, 2>{}, 3 * t3 + 2);
+    }
+  }
+}
+
+}  // namespace dsph

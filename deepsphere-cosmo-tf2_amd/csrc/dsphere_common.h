@@ -164,6 +164,23 @@ int launch_healpix_pool(const float* x, float* y, int64_t rows_out, int32_t F, i
 int launch_healpix_pool_backward(const float* x, const float* dy, float* dx, int64_t rows_out, int32_t F, int32_t group, bool maxp,
                                  hipStream_t stream);
 
+// input-side strip kernel (cheb_istrip.hip): layers with at most 16 input channels, one wave per strip
+struct IStripLaunch {
+  const float* x; const float* w; const float* bias; float* y;
+  unsigned char* wimg;       // workspace: istrip_wimg_bytes() per 32-column block
+  const StripPair* pairs;    // device list; every pair is two single strips
+  const float* gvals8; const float* gdiag;
+  int64_t x_rows, y_rows, N;
+  int32_t npairs, Fin, Fin_w, Fout, K, act, precision, ld, num_cu;
+  int32_t nseg = 1;          // row segments per strip (istrip_segments)
+  bool cheb;
+  bool prep_weights = true;
+};
+int istrip_segments(const std::vector<int32_t>& heights, const std::vector<unsigned char>& second, int64_t N, int num_cu, int D);
+bool istrip_shape_ok(int32_t Fin, int32_t K);
+size_t istrip_wimg_bytes(int32_t K, int32_t precision);
+int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream);
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case DSPH_ACT_RELU: return v > 0.f ? v : 0.f;

@@ -450,3 +450,100 @@ def test_pseudo_convolutions_against_the_oracle():
         kt = pt.filter.weight.permute(2, 1, 0).cpu().numpy()  # torch (Fin, Fout, 4^p) -> (4^p, Fout, Fin)
         reft = orc.healpy_pseudo_conv_transpose(x.astype(np.float64), kt.astype(np.float64), pt.filter.bias.cpu().numpy().astype(np.float64), p)
     assert z.shape == (N, 4 * M, Fout) and rel_err(z.cpu().numpy(), reft) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a fast kernel for the shapes a network starts with -- the input-side strip kernel (Fin <= 16)
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("nside,N,Fin,Fout,K,basis,act", [
+    (128, 2, 16, 32, 5, "chebyshev", "relu"),   # BASELINE configs[1]'s channel counts
+    (128, 3, 1, 16, 5, "chebyshev", None),      # configs[0]'s: one input channel (zero-padded to four), CH = 4
+    (128, 1, 8, 64, 4, "chebyshev", "relu"),    # CH = 4 with both halves, two 32-column blocks, K = 4
+    (128, 2, 12, 40, 3, "chebyshev", "elu"),    # three quads, a ragged second block, deferred activation, K = 3
+    (128, 2, 4, 7, 2, "chebyshev", None),       # K = 2, a narrow block whose stores are not 16-byte aligned
+    (128, 1, 16, 96, 5, "monomial", "relu"),    # the other basis, three column blocks over two 64-column launches
+    (256, 2, 5, 24, 5, "chebyshev", "tanh"),    # padded channel count, larger map
+])
+def test_input_side_strip_kernel_whole_map(nside, N, Fin, Fout, K, basis, act, prec):
+    """Whole maps against the float64 oracle: the rectangles on cheb_istrip_kernel, the rest on the tile kernels; the kernel
+    must really have been used, must be deterministic, and must equal the same plan with DSPH_OPT_STRIPS = never to rounding."""
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    n_strip = plan.strip_tiles(Fin, Fout, K, N=N)
+    n_struct, n_bfs = plan.tile_counts(K)
+    assert 0 < n_strip <= n_struct, "the rectangles of this map go to the input-side strip kernel"
+    rng = np.random.default_rng(nside + Fin + Fout + K)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    fwd = orc.chebyshev_forward if basis == "chebyshev" else orc.monomial_forward
+    ref = fwd(_csr(cols, vals), x, W, K, bias=b, activation=act)
+    P = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}[prec]
+    B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
+    A = {None: _native.ACT_NONE, "relu": _native.ACT_RELU, "elu": _native.ACT_ELU, "tanh": _native.ACT_TANH}[act]
+    y, ws = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
+    err = rel_err(y.cpu().numpy(), ref)
+    tol = (2e-6 if prec != "bf16x3" else (TOL if Fin >= 16 else 2 * TOL)) * (5 if act == "tanh" else 1)
+    print(f"istrip nside={nside} {Fin}->{Fout} K={K} {basis} {act} {prec}: {n_strip} strip tiles of {n_struct} + {n_bfs}, err {err:.2e}")
+    assert err < tol
+    y2, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B, workspace=ws)
+    assert torch.equal(y, y2)
+    plain = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_STRIPS: _native.STRIPS_NEVER})
+    assert plain.strip_tiles(Fin, Fout, K, N=N) == 0
+    y3, _ = _native.cheb_forward(plain, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
+    assert rel_err(y.cpu().numpy(), y3.cpu().numpy()) < 2 * tol
+
+
+def test_input_side_strip_kernel_partial_sky_and_batches():
+    """A cap of the sphere at nside 256 (ragged rectangles), 16 -> 32, at batch sizes that change the row-segment count the
+    kernel is launched with (1, 2, 5, 16 maps): every batch equals the oracle, and a map's result does not depend on the batch
+    it came in (the segments only move where a strip's run-in rows lie: same sums, same bits)."""
+    import bench
+
+    nside, K, Fin, Fout = 256, 5, 16, 32
+    cols, vals, _ = bench.build_laplacian_masked(nside, torch.device("cuda", 0))
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    assert plan.strip_tiles(Fin, Fout, K, N=1) > 0
+    rng = np.random.default_rng(256)
+    x = rng.standard_normal((16, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    Lt = _csr(cols, vals)
+    ref = orc.chebyshev_forward(Lt, x[:2], W, K)
+    y16, _ = _native.cheb_forward(plan, _dev(x), _dev(W), None, K, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    assert rel_err(y16[:2].cpu().numpy(), ref) < TOL
+    for N in (1, 2, 5):
+        yN, _ = _native.cheb_forward(plan, _dev(x[:N]), _dev(W), None, K, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+        assert torch.equal(yN, y16[:N]), f"batch {N}"
+
+
+def test_input_side_strips_in_a_two_part_launch():
+    """A rank's plan at nside 128 (two ranks): the interior part runs the strips, the boundary part the tile kernels; the two
+    parts together equal the single launch bit for bit, with a deferred activation."""
+    from deepsphere import sharding
+
+    nside, K, Fin, Fout, N = 128, 5, 16, 32, 2
+    cols, vals = _grid_ell(nside)
+    lay = sharding.ShardLayout(cols, vals, K, 1, 2)
+    plan = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols, device=0, levels=lay.levels)
+    assert plan.strip_tiles(Fin, Fout, K, N=N) > 0
+    rng = np.random.default_rng(41)
+    x = _dev(rng.standard_normal((N, lay.n_cols, Fin)).astype(np.float32))
+    W = _dev((rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32))
+    b = _dev(rng.standard_normal(Fout).astype(np.float32))
+    kw = dict(act=_native.ACT_ELU, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    whole, ws = _native.cheb_forward(plan, x, W, b, K, **kw)
+    out = torch.full_like(whole, float("nan"))
+    _native.cheb_forward(plan, x, W, b, K, part=_native.PART_INTERIOR, out=out, workspace=ws, **kw)
+    _native.cheb_forward(plan, x, W, b, K, part=_native.PART_BOUNDARY, out=out, workspace=ws, **kw)
+    assert torch.equal(out, whole)
+    # and against the oracle on the rank's own rows
+    full_x = np.zeros((N, cols.shape[0], Fin), dtype=np.float32)
+    full_x[:, lay.local_ids] = x.cpu().numpy()
+    ref = orc.chebyshev_forward(_csr(cols, vals), full_x, W.cpu().numpy(), K, bias=b.cpu().numpy(), activation="elu")
+    a, e = lay.own
+    assert rel_err(whole.cpu().numpy(), ref[:, a:e]) < TOL
