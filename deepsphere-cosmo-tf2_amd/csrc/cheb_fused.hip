@@ -879,8 +879,8 @@ static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fi
 // The input-side strip kernel takes the rectangles of every layer with at most 16 input channels (any arithmetic, K = 2 .. 5,
 // any output width), unless DSPH_OPT_STRIPS says never.  No cost rule: its workers are single waves and the kernel cuts the
 // strips into as many row segments as the batch needs, so small maps fill the device too (istrip_segments).
-static bool istrips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t K) {
-  return ft.n_ipairs > 0 && plan->opt.strips != 2 && istrip_shape_ok(Fin, K);
+static bool istrips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t K, int32_t Fout, int32_t ld) {
+  return ft.n_ipairs > 0 && plan->opt.strips != 2 && istrip_shape_ok(Fin, K) && Fout % 4 == 0 && ld % 4 == 0;
 }
 static int istrip_nseg(const dsph_plan* plan, const FusedTiles& ft, int64_t N, int D) {
   FusedPlan* fp = plan->fused;
@@ -896,7 +896,7 @@ int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t
   if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return 0;
   if (istrip_shape_ok(pad4(Fin), K)) {
     const FusedTiles& fti = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
-    return fti.ok && istrips_apply(plan, fti, pad4(Fin), K) ? fti.n_strip_tiles : 0;
+    return fti.ok && istrips_apply(plan, fti, pad4(Fin), K, std::min(Fout, 64), Fout) ? fti.n_strip_tiles : 0;
   }
   if (Fin != pad4(Fin) || Fout < 64) return 0;
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
@@ -1221,7 +1221,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       const int rc = launch_cheb_strip(st, stream);
       if (rc != DSPH_OK) return rc;
     }
-    const bool istrips = !strips && istrips_apply(plan, ft, Fin, K);
+    const bool istrips = !strips && istrips_apply(plan, ft, Fin, K, Fout, ld) && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     if (istrips && part != 2 && !dbg_only('b')) {
       IStripLaunch is;
       is.x = x; is.w = w; is.bias = bias; is.y = y;

