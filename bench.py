@@ -253,7 +253,7 @@ def main():
     layer_default = args.precision is None
     if layer_default:
         args.precision = gnn_layers.DEFAULT_PRECISION
-    resolved = gnn_layers.resolve_precision(args.precision, Fin)
+    resolved = gnn_layers.resolve_precision(args.precision, Fin, K)
     prec_code = gnn_layers._PRECISIONS[resolved]
     t0 = time.time()
     cols, vals, lmax = build_laplacian_masked(nside, device) if args.config in MASKED else build_laplacian(nside, device)

@@ -74,12 +74,15 @@ def _resolve_activation(activation):
 DEFAULT_PRECISION = "auto"
 
 
-def resolve_precision(precision, Fin):
+def resolve_precision(precision, Fin, K=None):
     """The arithmetic a contraction over ``Fin`` input channels runs for ``precision`` ("auto" | "fp32" | "bf16x3" |
     "bf16x6").  "auto" is resolved PER CONTRACTION: the forward with the layer's Fin, the input gradient -- the forward of
-    the transposed layer on dy -- with the layer's Fout (a 64 -> 1 layer runs its dx through the six-term split)."""
+    the transposed layer on dy -- with the layer's Fout (a 64 -> 1 layer runs its dx through the six-term split).  A layer
+    with more than nine terms runs as a chain of passes (csrc/cheb_split.hip), each of which rounds its input to bf16
+    hi + lo again under the three-term split (1.0e-5 measured at K = 10, three passes): "auto" gives those the
+    fp32-equivalent six-term split."""
     if precision == "auto":
-        return "bf16x3" if Fin >= 16 else "bf16x6"
+        return "bf16x3" if (Fin >= 16 and (K is None or K <= 9)) else "bf16x6"
     return precision
 
 
@@ -136,7 +139,7 @@ class _ChebConvFunction(torch.autograd.Function):
             kernel_t = kernel.detach().reshape(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()
             dx, layer._workspace_t = _native.cheb_forward(
                 plan_t, dy, kernel_t, None, K, act=_native.ACT_NONE,
-                precision=_PRECISIONS[resolve_precision(layer.precision, Fout)],
+                precision=_PRECISIONS[resolve_precision(layer.precision, Fout, K)],
                 algo=_ALGOS[layer.algo], workspace=layer._workspace_t, basis=layer._basis)
         if ctx.needs_input_grad[1]:
             plan = layer._get_plan()
@@ -302,7 +305,7 @@ class Chebyshev(torch.nn.Module):
 
     def _prec_code(self):
         """C-ABI code of the contraction arithmetic of this (built) layer: ``precision="auto"`` resolved with its Fin."""
-        return _PRECISIONS[resolve_precision(self.precision, self._Fin)]
+        return _PRECISIONS[resolve_precision(self.precision, self._Fin, self.K)]
 
     # -- forward --------------------------------------------------------------------------------
     def forward(self, input_tensor, training=False):
