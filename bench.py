@@ -392,12 +392,14 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 return repr(exc)
 
+        issue = {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath))
                 key = f"{args.config}:{resolved}:{'fused' if fused else 'unfused'}:{world}"
                 traffic = rec.get(key, {}).get("hbm_bytes_per_forward")
+                issue = rec.get(key, {})
             except Exception:
                 traffic = None
         out = {
@@ -436,7 +438,7 @@ def main():
                 "frac_of_measured_copy_6290": round(achieved / 6290.0, 4),
                 "median_forward_ms_hip_events": round(float(np.median(per_fwd_ms)), 4),
                 "traffic": traffic,
-                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of tools/measure_round3.sh; not re-measured in this run)" if traffic else None,
+                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of tools/measure_round3.sh / measure_round4.sh; not re-measured in this run)" if traffic else None,
                 "algorithmic_bytes": b_alg,
                 "avg_forward_ms_hip_events": round(dev_ms, 4),
                 "min_max_forward_ms_hip_events": [round(float(np.min(per_fwd_ms)), 4), round(float(np.max(per_fwd_ms)), 4)],
@@ -454,6 +456,14 @@ def main():
                                              "8 + 8 + 8 mantissa bits, products down to 2^-16 kept)", "mfma_bf16 x6", 6 * f_d / 2500e12 * 1e3),
                     "bf16x3": ("bf16_split3", "three-term split on v_mfma_f32_32x32x16_bf16", "mfma_bf16 x3", 3 * f_d / 2500e12 * 1e3)}
             out["roofline"]["bounds_ms"] = {"hbm": round(t_hbm, 3), legs[resolved][2]: round(legs[resolved][3], 3)}
+            if issue.get("valu_insts_per_forward"):
+                # what the kernels of this forward ISSUE (counters of the same build, profiles/hbm_traffic.json): a wave64
+                # vector instruction holds its SIMD's 16 lanes for 4 cycles, a 32x32x16 MFMA the matrix pipe for 32; 1,024 SIMDs;
+                # the nominal 2.4 GHz (the chip grants ~1.95 GHz under this kernel's matrix load: DESIGN 4.0)
+                simd_hz = 1024 * 2.4e9
+                out["roofline"]["bounds_ms"]["valu_issue"] = round(issue["valu_insts_per_forward"] * 4 / simd_hz * 1e3, 3)
+                out["roofline"]["bounds_ms"]["mfma_issued"] = round(issue.get("mfma_insts_per_forward", 0) * 32 / simd_hz * 1e3, 3)
+                out["roofline"]["bounds_ms"]["issue_source"] = "SQ_INSTS_VALU / SQ_INSTS_MFMA per forward, replayed from profiles/hbm_traffic.json"
             for prec_name, (key, note, pipe, t_pipe) in legs.items():
                 if resolved == prec_name:
                     continue
