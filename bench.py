@@ -270,7 +270,7 @@ def main():
         def run():
             with torch.no_grad():  # inference forward: bias/activation fused in the kernel epilogue
                 return layer(x)
-        fused = (layer._get_plan().fused_ok(Fin, Fout, K) or (K > 9 and args.split != "never")) and args.algo != "unfused"
+        fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
         kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N, args.split) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
     else:
         from deepsphere import sharding

@@ -198,8 +198,11 @@ int64_t dsph_plan_cols(const dsph_plan* p) { return p ? p->n_cols : 0; }
 int32_t dsph_plan_ell_width(const dsph_plan* p) { return p ? p->width : 0; }
 int64_t dsph_plan_out_rows(const dsph_plan* p, int32_t K) { (void)K; return p ? out_rows(p) : 0; }
 
+static bool use_split(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo, int32_t part);
+
 int dsph_plan_fused_ok(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K) {
-  return (p && fused_supported(p, Fin, Fout, K)) ? 1 : 0;  // (tables are built under the plan's device: get_tiles)
+  // (tables are built under the plan's device: get_tiles)
+  return (p && (fused_supported(p, Fin, Fout, K) || use_split(p, Fin, Fout, K, DSPH_ALGO_AUTO, DSPH_PART_ALL))) ? 1 : 0;
 }
 
 int dsph_plan_tile_counts(const dsph_plan* p, int32_t K, int64_t* n_struct, int64_t* n_bfs) {

@@ -141,7 +141,8 @@ int64_t dsph_plan_rows(const dsph_plan* plan);
 int64_t dsph_plan_cols(const dsph_plan* plan);
 int32_t dsph_plan_ell_width(const dsph_plan* plan);
 int64_t dsph_plan_out_rows(const dsph_plan* plan, int32_t K); /* rows y is produced for */
-/* 1 if the fused single-launch kernel can run this (plan, shape); 0 otherwise */
+/* 1 if the fused kernels can run this (plan, shape) -- in one forward, or, for K > 5 where the plan's options allow it, as the
+ * chain of <= 5-term passes; 0 otherwise (the unfused kernels then serve dsph_cheb_forward under DSPH_ALGO_AUTO) */
 int dsph_plan_fused_ok(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 
 /* How the fused forward with K terms splits the plan's 256-row tiles between its two kernels: *n_struct tiles whose
