@@ -547,3 +547,19 @@ def test_input_side_strips_in_a_two_part_launch():
     ref = orc.chebyshev_forward(_csr(cols, vals), full_x, W.cpu().numpy(), K, bias=b.cpu().numpy(), activation="elu")
     a, e = lay.own
     assert rel_err(whole.cpu().numpy(), ref[:, a:e]) < TOL
+
+
+def test_fuzz_input_side_strips_and_pass_chains():
+    """A short run of tools/fuzz_gpu.py in its round-4 mode (FUZZ_ISTRIPS=1: random shapes of the input-side strip kernel on
+    nside-128 grids and caps, every third case K 6..13 through the chain of passes), all three arithmetics against the unfused
+    kernels."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_ISTRIPS="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "12", "7"], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "ALL OK" in res.stdout

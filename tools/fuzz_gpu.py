@@ -74,9 +74,13 @@ for it in range(cases):
     e6 = rel(y6.cpu().numpy(), yu.cpu().numpy())
     same = True
     if Fin % 4 == 0 and K <= 9:  # (the planes / weight-gradient modes of the BFS kernel take whole 16-byte pieces only)
-        pf = _native.cheb_planes(plan, xd, K, basis=basis, algo=_native.ALGO_FUSED)
-        pu = _native.cheb_planes(plan, xd, K, basis=basis, algo=_native.ALGO_UNFUSED)
-        same = all(torch.equal(a, b2) for a, b2 in zip(pf, pu))
+        try:
+            pf = _native.cheb_planes(plan, xd, K, basis=basis, algo=_native.ALGO_FUSED)
+            pu = _native.cheb_planes(plan, xd, K, basis=basis, algo=_native.ALGO_UNFUSED)
+            same = all(torch.equal(a, b2) for a, b2 in zip(pf, pu))
+        except RuntimeError as exc:  # a forward that runs as a chain of passes has no fused planes mode: refused loudly, fine
+            if "cannot run" not in str(exc):
+                raise
     du, _ = _native.cheb_backward_weights(plan, xd, dyd, K, basis=basis, algo=_native.ALGO_UNFUSED)
     e3 = e4 = -1.0
     try:
