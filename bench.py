@@ -45,8 +45,13 @@ CONFIGS = {
     "k10": (256, 10, 16, 32, 8),
     # the first layer of a DeepSphere stack (tests/test_healpy_networks.py:96-107: one input channel) at nside 512
     "in1": (512, 5, 1, 16, 8),
+    # the reference's own graphs (healpy_networks.py:38-41,108-118: k nearest neighbours, symmetrised; every shipped model uses
+    # n_neighbors = 20) at configs[1]'s map and channel counts: ELL width 11 / 23
+    "knn8": (256, 5, 16, 32, 8),
+    "knn20": (256, 5, 16, 32, 8),
 }
 MASKED = {"c5"}
+KNN = {"knn8": 8, "knn20": 20}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 
@@ -81,6 +86,21 @@ def build_laplacian_masked(nside, device, fraction=1.0 / 3.0):
     plan_L.close()
     lmax = 1.02 * lam
     cols, vals = utils.csr_to_ell(utils.rescale_L(L, lmax=lmax, scale=0.75))  # diagonal wherever CSR order puts it
+    return cols, vals.astype(np.float32), lmax
+
+
+def build_laplacian_knn(nside, device, k):
+    """The reference's kind of graph: symmetrised k-nearest-neighbour Gaussian-kernel graph on the pixel centres, normalised
+    Laplacian (deepsphere/healpix.py; parity with the pygsp fork is unverifiable here), rescaled like Chebyshev.__init__."""
+    from deepsphere import _native, healpix, utils
+
+    L = healpix.healpix_laplacian(nside, n_neighbors=k, mode="knn")
+    cols, vals64 = utils.csr_to_ell(L)
+    plan_L = _native.LaplacianPlan(cols, vals64.astype(np.float32), device=device.index)
+    lam = utils.lanczos_lmax(plan_L, iters=64)
+    plan_L.close()
+    lmax = 1.02 * lam
+    cols, vals = utils.csr_to_ell(utils.rescale_L(L, lmax=lmax, scale=0.75))
     return cols, vals.astype(np.float32), lmax
 
 
@@ -256,7 +276,10 @@ def main():
     resolved = gnn_layers.resolve_precision(args.precision, Fin, K)
     prec_code = gnn_layers._PRECISIONS[resolved]
     t0 = time.time()
-    cols, vals, lmax = build_laplacian_masked(nside, device) if args.config in MASKED else build_laplacian(nside, device)
+    if args.config in KNN:
+        cols, vals, lmax = build_laplacian_knn(nside, device, KNN[args.config])
+    else:
+        cols, vals, lmax = build_laplacian_masked(nside, device) if args.config in MASKED else build_laplacian(nside, device)
     M, W_ell = cols.shape
     w_np = (np.random.default_rng(13).standard_normal((Fin * K, Fout)) / np.sqrt(Fin * (K + 0.5) / 2)).astype(np.float32)
 
@@ -423,7 +446,8 @@ def main():
                 "workload": f"nside={nside} {'partial sky (cap of 1/3 of the sphere, nside-8 superpixels)' if args.config in MASKED else 'full-sphere'}, K={K}, Fin={Fin}, Fout={Fout}, batch={N} ({args.config})",
                 "pixels": M,
                 "ell_width": W_ell,
-                "graph": "8-neighbour HEALPix grid stencil, normalised Laplacian, lmax by 64-step Lanczos",
+                "graph": (f"symmetrised {KNN[args.config]}-nearest-neighbour Gaussian-kernel graph on the HEALPix pixel centres" if args.config in KNN
+                          else "8-neighbour HEALPix grid stencil") + ", normalised Laplacian, lmax by 64-step Lanczos",
                 "algo": "fused" if fused else "unfused",
                 "sharding": "none" if world == 1 else (replicas_note or f"{world} contiguous NEST ranges, (K-1)-ring halo of x per step, exchange hidden behind the interior tiles"),
                 "setup_s": round(setup_s, 1),
