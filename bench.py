@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--split", default="auto", choices=["auto", "always", "never"],
                     help="K > 5: the product-identity chain of K <= 5 passes (csrc/cheb_split.hip) -- plan option DSPH_OPT_SPLIT")
     ap.add_argument("--strips", default="auto", choices=["auto", "always", "never"], help="plan option DSPH_OPT_STRIPS")
+    ap.add_argument("--tstep", default="on", choices=["on", "off"], help="plan option DSPH_OPT_TSTEP (wide graphs: tiled step)")
     ap.add_argument("--quick", action="store_true", help="the headline leg only: no side legs in the other arithmetics, no CPU baseline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = halo rows "
@@ -267,7 +268,8 @@ def main():
     from deepsphere import _native, gnn_layers
 
     plan_options = {_native.OPT_SPLIT: {"auto": 0, "always": 1, "never": 2}[args.split],
-                    _native.OPT_STRIPS: {"auto": 0, "always": 1, "never": 2}[args.strips]}
+                    _native.OPT_STRIPS: {"auto": 0, "always": 1, "never": 2}[args.strips],
+                    _native.OPT_TSTEP: 1 if args.tstep == "on" else 0}
     nside, K, Fin, Fout, N = CONFIGS[args.config]
     # what is timed is what a user of the layer gets: the layer's default arithmetic unless --precision says otherwise
     layer_default = args.precision is None
@@ -294,7 +296,8 @@ def main():
             with torch.no_grad():  # inference forward: bias/activation fused in the kernel epilogue
                 return layer(x)
         fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-        kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N, args.split) if fused else f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
+        step_name = "cheb_tstep_kernel" if (12 < W_ell <= 32 and args.tstep == "on" and Fin % 4 == 0) else "cheb_step_kernel"
+        kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N, args.split) if fused else f"{step_name} x{K - 1} + cheb_contract_f32_kernel"
     else:
         from deepsphere import sharding
 

@@ -104,6 +104,7 @@ struct FusedPlan {
   unsigned char* d_rowflag = nullptr;
   bool rows_tried = false;
   bool host_released = false;  // DSPH_PREPARE_RELEASE_HOST: no tables for further depths
+  bool wide = false;           // ELL wider than the fused kernels' templates: only the depth-1 tables of the tiled step exist
   // The BFS-tile launch of a forward writes tiles of y that the structured launches do not touch: it runs on this side stream,
   // forked from and joined back into the caller's stream by the two events (a few dozen face-corner tiles would otherwise
   // hold the whole device for the latency of one tile: 14 of the 44 us of BASELINE configs[0], 57 of 544 us of configs[1]).
@@ -141,8 +142,9 @@ static void free_tiles(FusedTiles& ft) {
 }
 
 FusedPlan* fused_plan_build(const dsph_plan* plan, const int32_t* h_cols, const float* h_vals) {
-  if (template_width(plan->width) == 0) return nullptr;
+  if (template_width(plan->width) == 0 && tstep_width(plan->width) == 0) return nullptr;
   FusedPlan* fp = new FusedPlan();
+  fp->wide = template_width(plan->width) == 0;
   const size_t nnz = (size_t)plan->n_rows * plan->width;
   fp->h_cols.assign(h_cols, h_cols + nnz);
   fp->h_vals.assign(h_vals, h_vals + nnz);
@@ -534,9 +536,13 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
     static const FusedTiles none;
     return none;
   }
+  if (fp->wide && !(D == 1 && full)) {  // a wide graph has the tiled step's tables and nothing else
+    static const FusedTiles none;
+    return none;
+  }
   FusedTiles& ft = fp->by_depth[key];
   ft.D = D;
-  ft.width = template_width(plan->width);
+  ft.width = fp->wide ? tstep_width(plan->width) : template_width(plan->width);
   const int W = plan->width, WT = ft.width;
   const int64_t out_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
   const int64_t nt64 = (out_rows + FUSED_P - 1) / FUSED_P;
@@ -798,7 +804,7 @@ static bool want_full(const dsph_plan* plan, int32_t Fin, bool full) {
 
 static bool supported_impl(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K, bool full) {
   full = want_full(plan, Fin, full);
-  if (!plan->fused) return false;
+  if (!plan->fused || plan->fused->wide) return false;
   if (K < 2 || K - 1 > FUSED_DMAX) return false;
   if (Fin % 4 != 0 || Fin < 4 || Fout < 1) return false;  // Fout > 64: one launch per 64-column block
   const FusedTiles& ft = get_tiles(plan, K - 1, full);
@@ -816,12 +822,41 @@ static bool supported_impl(const dsph_plan* plan, int32_t Fin, int32_t Fout, int
 static inline int32_t pad4(int32_t Fin) { return (Fin + 3) & ~3; }
 
 int fused_dmax() { return FUSED_DMAX; }
+int fused_num_cu(const dsph_plan* plan) { return plan->fused ? plan->fused->num_cu : 256; }
+
+// Depth-1 breadth-first tables of a whole graph too wide for the fused kernels: what the tiled step gathers from (cheb_tstep.hip)
+bool fused_tstep_tables(const dsph_plan* plan, TStepTables* out) {
+  if (!plan->fused || !plan->fused->wide || plan->n_cols != plan->n_rows || !plan->levels.empty()) return false;
+  const FusedTiles& ft = get_tiles(plan, 1, true);
+  if (!ft.ok || ft.rmax > 768 || ft.n_part != ft.ntiles) return false;  // (TS_RMAX of cheb_tstep.hip)
+  out->tile_off = ft.d_tile_off;
+  out->ring_end = ft.d_ring_end;
+  out->ell_off = ft.d_ell_off;
+  out->region = ft.d_region;
+  out->lcols = ft.d_lcols;
+  out->lvals = ft.d_lvals;
+  out->ntiles = ft.ntiles;
+  out->width = ft.width;
+  return true;
+}
 
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
   return Fin >= 1 && supported_impl(plan, pad4(Fin), Fout, K, false);
 }
 
 int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags) {
+  if (plan->fused && plan->fused->wide) {  // the tiled step's tables, so that the first forward does not build them
+    TStepTables tb;
+    if (K >= 2) (void)fused_tstep_tables(plan, &tb);
+    if (flags & DSPH_PREPARE_RELEASE_HOST) {
+      FusedPlan* fpw = plan->fused;
+      std::lock_guard<std::mutex> lock(fpw->mu);
+      std::vector<int32_t>().swap(fpw->h_cols);
+      std::vector<float>().swap(fpw->h_vals);
+      fpw->host_released = true;
+    }
+    return DSPH_OK;
+  }
   if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return DSPH_OK;  // nothing to build: the unfused path serves it
   const FusedTiles& ftp = get_tiles(plan, K - 1, want_full(plan, pad4(std::max(Fin, 1)), false));
   if (ftp.ok && plan->opt.fork && ftp.n_r + ftp.n_t > 0 && ftp.n_part > 0) {  // a forward of this K may fork: the side stream exists before it

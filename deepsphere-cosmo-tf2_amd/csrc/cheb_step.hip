@@ -87,6 +87,19 @@ int launch_cheb_step(const dsph_plan* plan, const float* in, int64_t in_rows, co
                      int64_t prev_rows, float* out, int64_t out_rows, int64_t N, int32_t F,
                      float alpha, float beta, int64_t rows, hipStream_t stream) {
   if (rows <= 0 || N <= 0) return DSPH_OK;
+  if (beta != 0.f && prev == nullptr) {
+    set_error("cheb_step: beta != 0 needs prev");
+    return DSPH_E_BADARG;
+  }
+  // graphs wider than the fused kernels' templates (the reference's 20 / 40 neighbours): the step through LDS tiles, every row of
+  // `in` read once per tile region instead of once per neighbour (cheb_tstep.hip) -- whole graphs, whole planes, 16-byte rows
+  if (plan->fused != nullptr && plan->opt.tstep && rows == plan->n_rows && in_rows == plan->n_rows && out_rows == plan->n_rows &&
+      (prev == nullptr || beta == 0.f || prev_rows == plan->n_rows) && F % 4 == 0 &&
+      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(prev)) & 15) == 0) {
+    TStepTables tb;
+    if (fused_tstep_tables(plan, &tb))
+      return launch_cheb_tstep(tb, in, prev, out, rows, N, F, alpha, beta, fused_num_cu(plan), stream);
+  }
   const bool vec4 = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                     (prev == nullptr || (reinterpret_cast<uintptr_t>(prev) & 15) == 0);

@@ -1,0 +1,188 @@
+// One recurrence step through LDS tiles, for graphs too wide for the fused kernels (round 4).
+//
+// The reference's own models use 20 / 40 / 60 nearest neighbours (healpy_networks.py:38-41; every shipped example: 20): padded ELL
+// width 23 and up.  No fused kernel holds a 4-ring halo of such a graph, so they run one step per launch -- and the gather step of
+// cheb_step.hip pulls every neighbour row through the L2 again: 23 x |x| of L2 -> CU traffic per step (0.95 ms per step at nside
+// 256, 16 channels, batch 8, where the three planes it touches are 1.2 GB).  Here a workgroup owns a tile of 256 consecutive rows
+// (a 16 x 16 pixel square in NEST order), stages the rows within ONE hop of it -- the breadth-first region tables the fused path
+// builds (cheb_fused.hip, depth 1) -- into LDS, 16 channels at a time, and gathers from there:
+//     out[n, m, :] = alpha * sum_j vals[m, j] * in[n, cols[m, j], :] - beta * prev[n, m, :]          (reference utils.py:49-78,
+//                                                                                                  gnn_layers.py:138,141)
+// with every row of `in` read 1.7 x instead of 23 x (a 21 x 21 region per 16 x 16 tile at 20 neighbours).  A lane owns one (row,
+// 4-channel chunk) of the tile for the whole tile: the row's tile-local columns, as swizzled LDS byte addresses, and its values
+// stay in registers across all maps and channel slices (WT of each: the template parameter).  The next (map, slice)'s region is
+// fetched into registers while the current one is summed; two planes alternate.  Summation order: slot j ascending, fused
+// multiply-add -- the gather kernel's, so the two agree bit for bit.
+// Generic in the graph: rings come from the plan's own pattern; whole graphs only (no halo columns, all rows).
+#include <algorithm>
+
+#include "cheb_fused_kernel.h"
+
+namespace dsph {
+
+constexpr int TS_THREADS = 512;   // 128 tile rows x 4 chunks of 4 channels per pass, two passes: a lane owns two rows
+constexpr int TS_RP = 2;
+constexpr int TS_RMAX = 768;      // region rows a plane holds (64 B each): a 27 x 27 pixel region
+constexpr int TS_SQ = TS_RMAX * 4 / TS_THREADS;  // staged 16-byte pieces per lane
+
+struct TStepArgs {
+  const float* in;
+  const float* prev;  // or NULL
+  float* out;
+  const int32_t* tile_off;
+  const int32_t* ring_end;   // [ntiles][FUSED_DMAX + 1]
+  const int64_t* ell_off;    // rows
+  const int32_t* region;
+  const uint16_t* lcols;     // per tile [WT][E] tile-local columns
+  const float* lvals;
+  int64_t rows;              // rows of every plane (= the plan's rows)
+  int ntiles, N, F;
+  float alpha, beta;
+};
+
+template <int WT>
+__global__ __launch_bounds__(TS_THREADS, 2) void cheb_tstep_kernel(TStepArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TS_RMAX * 64];
+  const int tid = threadIdx.x, row_l = tid >> 2, slot = tid & 3;
+  const int nslices = (a.F + 15) / 16;
+  const unsigned nblk = gridDim.x;
+  for (unsigned tb = xcd_remap(blockIdx.x, nblk); tb < (unsigned)a.ntiles; tb += nblk) {
+    const int t = (int)tb;
+    const int base = a.tile_off[t];
+    const int E = a.ring_end[(size_t)t * (FUSED_DMAX + 1)];       // the tile's own rows (the last tile may be ragged)
+    const int R = a.ring_end[(size_t)t * (FUSED_DMAX + 1) + 1];   // rows within one hop
+    const int64_t r0 = (int64_t)t * FUSED_P;
+    // this lane's rows of the tile-local ELL (row_l and row_l + 128): LDS byte addresses of the neighbours' chunk, and the values
+    unsigned pre[TS_RP][WT / 2];  // two 16-bit addresses per register
+    float val[TS_RP][WT];
+    {
+      const uint16_t* lc = a.lcols + a.ell_off[t] * WT;
+      const float* lv = a.lvals + a.ell_off[t] * WT;
+#pragma unroll
+      for (int p = 0; p < TS_RP; ++p) {
+        const int row = row_l + 128 * p;
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+          const unsigned c = row < E ? lc[(size_t)j * E + row] : 0u;
+          const unsigned addr = plane_byte(c, (unsigned)slot);  // < 768 * 64 = 48 KiB: 16 bits
+          if (j & 1) pre[p][j >> 1] |= addr << 16;
+          else pre[p][j >> 1] = addr;
+          val[p][j] = row < E ? lv[(size_t)j * E + row] : 0.f;
+        }
+      }
+    }
+    // staging: region row i = row_l + 128 q, q < TS_SQ, this lane's chunk
+    int grow[TS_SQ];
+#pragma unroll
+    for (int q = 0; q < TS_SQ; ++q) {
+      const int i = row_l + 128 * q;
+      grow[q] = i < R ? a.region[base + i] : -1;
+    }
+    float4 st[TS_SQ];
+    auto fetch = [&](int it) __attribute__((always_inline)) {
+      const int n = it / nslices, c = it - n * nslices;
+      const int ch = 16 * c + 4 * slot;
+#pragma unroll
+      for (int q = 0; q < TS_SQ; ++q) {
+        st[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow[q] >= 0 && ch < a.F) st[q] = *reinterpret_cast<const float4*>(a.in + ((int64_t)n * a.rows + (int64_t)grow[q]) * a.F + ch);
+      }
+    };
+    auto stage = [&](unsigned char* plane) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < TS_SQ; ++q) {
+        const int i = row_l + 128 * q;
+        if (i < R) *reinterpret_cast<float4*>(plane + plane_byte((unsigned)i, (unsigned)slot)) = st[q];
+      }
+    };
+    const int iters = a.N * nslices;
+    fetch(0);
+    __syncthreads();  // (the previous tile's last reads of plane 0)
+    stage(smem);
+    for (int it = 0; it < iters; ++it) {
+      if (it + 1 < iters) fetch(it + 1);
+      __syncthreads();  // plane `it & 1` is staged; the other one's readers of iteration it - 1 are done
+      const int n = it / nslices, c = it - n * nslices;
+      const int ch = 16 * c + 4 * slot;
+      unsigned po = (unsigned)(it & 1) * (TS_RMAX * 64);
+      asm volatile("" : "+v"(po));
+#pragma unroll
+      for (int p = 0; p < TS_RP; ++p) {
+        const int row = row_l + 128 * p;
+        if (row < E && ch < a.F) {
+          float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+          // eight gathers in flight at a time (all WT at once cost WT x 4 registers of landing space).  The packed addresses are
+          // unpacked from a copy hipcc cannot see through: it would otherwise hoist the unpacked, plane-relative addresses of
+          // both planes out of the loop over (map, slice) -- 4 WT registers instead of WT / 2
+#pragma unroll
+          for (int j0 = 0; j0 < WT; j0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              unsigned w2 = pre[p][(j0 + j) >> 1];
+              asm volatile("" : "+v"(w2));
+              v[j] = *reinterpret_cast<const float4*>(smem + (po + (w2 & 0xffffu)));
+              v[j + 1] = *reinterpret_cast<const float4*>(smem + (po + (w2 >> 16)));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              s.x = fmaf(val[p][j0 + j], v[j].x, s.x);
+              s.y = fmaf(val[p][j0 + j], v[j].y, s.y);
+              s.z = fmaf(val[p][j0 + j], v[j].z, s.z);
+              s.w = fmaf(val[p][j0 + j], v[j].w, s.w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const int64_t o = ((int64_t)n * a.rows + r0 + row) * a.F + ch;
+          float4 r;
+          if (a.prev != nullptr) {
+            const float4 q = *reinterpret_cast<const float4*>(a.prev + o);
+            r = make_float4(a.alpha * s.x - a.beta * q.x, a.alpha * s.y - a.beta * q.y, a.alpha * s.z - a.beta * q.z, a.alpha * s.w - a.beta * q.w);
+          } else {
+            r = make_float4(a.alpha * s.x, a.alpha * s.y, a.alpha * s.z, a.alpha * s.w);
+          }
+          *reinterpret_cast<float4*>(a.out + o) = r;
+        }
+      }
+      if (it + 1 < iters) stage(smem + ((it + 1) & 1) * (TS_RMAX * 64));
+    }
+  }
+}
+
+int tstep_width(int w) {
+  if (w <= 16) return 16;
+  if (w <= 24) return 24;
+  if (w <= 32) return 32;
+  return 0;  // (a 48-wide instantiation spills two hundred registers: 40 and 60 neighbours keep the gather kernel of cheb_step.hip)
+}
+
+int launch_cheb_tstep(const TStepTables& tb, const float* in, const float* prev, float* out, int64_t rows, int64_t N, int32_t F, float alpha,
+                      float beta, int num_cu, hipStream_t stream) {
+  TStepArgs a;
+  a.in = in;
+  a.prev = beta != 0.f ? prev : nullptr;
+  a.out = out;
+  a.tile_off = tb.tile_off;
+  a.ring_end = tb.ring_end;
+  a.ell_off = tb.ell_off;
+  a.region = tb.region;
+  a.lcols = tb.lcols;
+  a.lvals = tb.lvals;
+  a.rows = rows;
+  a.ntiles = tb.ntiles;
+  a.N = (int)N;
+  a.F = F;
+  a.alpha = alpha;
+  a.beta = beta;
+  const int grid = std::max(8, std::min(tb.ntiles, num_cu) / 8 * 8);
+  switch (tb.width) {
+    case 16: hipLaunchKernelGGL(cheb_tstep_kernel<16>, dim3(grid), dim3(TS_THREADS), 0, stream, a); break;
+    case 24: hipLaunchKernelGGL(cheb_tstep_kernel<24>, dim3(grid), dim3(TS_THREADS), 0, stream, a); break;
+    case 32: hipLaunchKernelGGL(cheb_tstep_kernel<32>, dim3(grid), dim3(TS_THREADS), 0, stream, a); break;
+    default: set_error("cheb_tstep: no kernel for table width %d", tb.width); return DSPH_E_UNSUPPORTED;
+  }
+  DSPH_HIP(hipGetLastError());
+  return DSPH_OK;
+}
+
+}  // namespace dsph

@@ -46,6 +46,7 @@ struct PlanOptions {
   int strip_min_rows = 4;    // DSPH_OPT_STRIP_MINROWS: least height of a strip rectangle, in tiles
   bool strip_generic = false;  // DSPH_OPT_STRIP_GENERIC: compiler-scheduled strip kernel instead of the hand-ordered one
   int split_order = 0;       // DSPH_OPT_SPLIT: K > 5 by the product identity (0 auto, 1 always when possible, 2 never)
+  bool tstep = true;         // DSPH_OPT_TSTEP: wide graphs step through LDS tiles (cheb_tstep.hip) instead of the gather kernel
 };
 
 }  // namespace dsph
@@ -116,6 +117,18 @@ int split_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t Fout, i
 int launch_split_forward(const dsph_plan* plan, const float* x, const float* w, const float* bias, float* y, int64_t N, int32_t Fin,
                          int32_t Fout, int32_t K, int32_t basis, int32_t act, int32_t precision, void* workspace,
                          size_t workspace_bytes, hipStream_t stream, bool keep_weights = false);
+
+// one recurrence step through LDS tiles, for graphs wider than the fused kernels' templates (cheb_tstep.hip)
+struct TStepTables {
+  const int32_t* tile_off; const int32_t* ring_end; const int64_t* ell_off; const int32_t* region;
+  const uint16_t* lcols; const float* lvals;
+  int ntiles = 0, width = 0;
+};
+int tstep_width(int ell_width);  // table width the tiled step is instantiated for (0: none)
+bool fused_tstep_tables(const dsph_plan* plan, TStepTables* out);  // depth-1 tables of a wide whole graph, built on first use
+int launch_cheb_tstep(const TStepTables& tb, const float* in, const float* prev, float* out, int64_t rows, int64_t N, int32_t F, float alpha,
+                      float beta, int num_cu, hipStream_t stream);
+int fused_num_cu(const dsph_plan* plan);
 
 // structured-tile kernel (cheb_struct.hip)
 struct StructLaunch {

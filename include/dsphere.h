@@ -126,7 +126,10 @@ int dsph_plan_prepare(dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
  *   DSPH_OPT_STRIP_MINROWS  least height of a strip rectangle in tiles, default 4                      (tuning)
  *   DSPH_OPT_STRIP_GENERIC  0 (default) / 1: the compiler-scheduled strip kernel at K = 5              (diagnosis)
  *   DSPH_OPT_SPLIT          K > 5: 0 (default) the faster of the two routes by rule, 1 always the product identity
- *                           T_{4+j} = 2 T_4 T_j - T_{|4-j|} (passes of K <= 5 on the fast kernels), 2 never */
+ *                           T_{4+j} = 2 T_4 T_j - T_{|4-j|} (passes of K <= 5 on the fast kernels), 2 never
+ *   DSPH_OPT_TSTEP          1 (default) / 0: graphs wider than the fused kernels take (ELL width 13 .. 32: the reference's 20
+ *                           neighbours) run every recurrence step through LDS tiles (csrc/cheb_tstep.hip); 0: the gather kernel.
+ *                           Same bits either way. */
 #define DSPH_OPT_STRIPS 1
 #define DSPH_OPT_STRUCT 2
 #define DSPH_OPT_TABLES 3
@@ -135,6 +138,7 @@ int dsph_plan_prepare(dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
 #define DSPH_OPT_STRIP_MINROWS 6
 #define DSPH_OPT_STRIP_GENERIC 7
 #define DSPH_OPT_SPLIT 8
+#define DSPH_OPT_TSTEP 9
 int dsph_plan_set_option(dsph_plan* plan, int32_t option, int64_t value);
 
 int64_t dsph_plan_rows(const dsph_plan* plan);

@@ -563,3 +563,52 @@ def test_fuzz_input_side_strips_and_pass_chains():
                          timeout=900, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "ALL OK" in res.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's 20-neighbour graphs -- every recurrence step through LDS tiles (cheb_tstep.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("nside,k,N,F,K,basis", [
+    (32, 20, 3, 16, 5, "chebyshev"),   # ELL width 23 -> the 24-wide instantiation; one 16-channel slice
+    (32, 20, 2, 40, 4, "chebyshev"),   # three slices, the last one partial
+    (16, 20, 2, 4, 3, "monomial"),     # one 4-channel chunk, the other basis, 12 tiles
+    (32, 8, 2, 8, 5, "chebyshev"),     # width 11: the fused kernels' territory -- the tiled step is not used, same answer
+])
+def test_tiled_step_on_wide_graphs(nside, k, N, F, K, basis):
+    """A symmetrised k-nearest-neighbour graph as the reference's models build it: single steps through dsph_cheb_step with the
+    tiled kernel and with the gather kernel (DSPH_OPT_TSTEP = 0) agree BIT FOR BIT (same summation order), the whole forward
+    agrees with the float64 oracle, and so does the weight gradient (its planes come from the same steps)."""
+    L = healpix.healpix_laplacian(nside, n_neighbors=k, mode="knn")
+    Lt, _ = orc.prepare_L(L, scale=0.75 if basis == "chebyshev" else 1.0)
+    cols, vals = utils.csr_to_ell(Lt)
+    M, W_ell = cols.shape
+    assert (W_ell > 12) == (k == 20)
+    rng = np.random.default_rng(nside + k + F)
+    x = rng.standard_normal((N, M, F)).astype(np.float32)
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    plain = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_TSTEP: 0})
+    xd, pd = _dev(x), _dev(rng.standard_normal((N, M, F)).astype(np.float32))
+    a = _native.cheb_step(plan, xd, None, 1.0, 0.0)
+    b = _native.cheb_step(plain, xd, None, 1.0, 0.0)
+    assert torch.equal(a, b)
+    a2 = _native.cheb_step(plan, a, pd, 2.0, 1.0)
+    b2 = _native.cheb_step(plain, b, pd, 2.0, 1.0)
+    assert torch.equal(a2, b2)
+    ref1 = (Lt.astype(np.float64) @ x.transpose(1, 0, 2).reshape(M, -1)).reshape(M, N, F).transpose(1, 0, 2)
+    assert rel_err(a.cpu().numpy(), ref1) < 2e-6
+    Fout = 12
+    Wk = (rng.standard_normal((F * K, Fout)) * orc.default_kernel_stddev(F, K)).astype(np.float32)
+    bias = rng.standard_normal(Fout).astype(np.float32)
+    fwd = orc.chebyshev_forward if basis == "chebyshev" else orc.monomial_forward
+    B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
+    y, _ = _native.cheb_forward(plan, xd, _dev(Wk), _dev(bias), K, act=_native.ACT_RELU, precision=_native.PREC_BF16X6, basis=B)
+    yp, _ = _native.cheb_forward(plain, xd, _dev(Wk), _dev(bias), K, act=_native.ACT_RELU, precision=_native.PREC_BF16X6, basis=B)
+    assert rel_err(y.cpu().numpy(), fwd(Lt, x, Wk, K, bias=bias, activation="relu")) < 2e-6
+    assert torch.equal(y, yp)
+    if basis == "chebyshev":
+        dy = rng.standard_normal((N, M, Fout)).astype(np.float32)
+        dw, _ = _native.cheb_backward_weights(plan, xd, _dev(dy), K)
+        _, dW_ref = orc.chebyshev_backward(Lt, x, Wk, K, dy)
+        assert rel_err(dw.cpu().numpy(), dW_ref) < 1e-5
