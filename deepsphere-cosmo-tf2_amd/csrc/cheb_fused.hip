@@ -679,6 +679,39 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
       if (r >= plan->n_rows) return ft;
       const int32_t* c = cols + (size_t)r * W;
       const float* v = vals + (size_t)r * W;
+      if (fp->wide) {
+        // The tiled step (cheb_tstep.hip) reads slot j of four consecutive rows in one 16-lane LDS access: conflict-free when
+        // the four neighbours' local indices differ mod 4.  So the slots of a row are dealt by residue: slot j of local row i
+        // takes a neighbour with (local index & 3) == ((i + j) & 3) while there is one, else one from the fullest residue
+        // class (the sum's ORDER changes, not its terms).
+        std::vector<std::pair<uint16_t, float>> bucket[4];
+        for (int j = 0; j < W; ++j)
+          if (v[j] != 0.f) bucket[local[c[j]] & 3].push_back({(uint16_t)local[c[j]], v[j]});
+        size_t head[4] = {0, 0, 0, 0};
+        for (int j = 0; j < WT; ++j) {
+          int b = (i + j) & 3;
+          if (head[b] >= bucket[b].size()) {
+            size_t best = 0;
+            int bb = -1;
+            for (int q = 0; q < 4; ++q)
+              if (bucket[q].size() - head[q] > best) { best = bucket[q].size() - head[q]; bb = q; }
+            b = bb;
+          }
+          uint16_t lc = (uint16_t)i;
+          float lv = 0.f;
+          if (b >= 0) {
+            lc = bucket[b][head[b]].first;
+            lv = bucket[b][head[b]].second;
+            ++head[b];
+          } else {
+            const int want = (i & ~3) | ((i + j) & 3);  // padding: a row of this quad with the slot's residue (value 0)
+            lc = (uint16_t)(want < R ? want : i);
+          }
+          lcols[lbase + (size_t)j * E + i] = lc;
+          lvals[lbase + (size_t)j * E + i] = lv;
+        }
+        continue;
+      }
       for (int j = 0; j < WT; ++j) {
         uint16_t lc = (uint16_t)i;
         float lv = 0.f;

@@ -11,8 +11,10 @@
 // with every row of `in` read 1.7 x instead of 23 x (a 21 x 21 region per 16 x 16 tile at 20 neighbours).  A lane owns one (row,
 // 4-channel chunk) of the tile for the whole tile: the row's tile-local columns, as swizzled LDS byte addresses, and its values
 // stay in registers across all maps and channel slices (WT of each: the template parameter).  The next (map, slice)'s region is
-// fetched into registers while the current one is summed; two planes alternate.  Summation order: slot j ascending, fused
-// multiply-add -- the gather kernel's, so the two agree bit for bit.
+// fetched into registers while the current one is summed; two planes alternate.  The slots of a row are dealt by the residue of
+// the neighbour's local index (cheb_fused.hip, get_tiles: slot j of local row i holds a neighbour with index & 3 == (i + j) & 3
+// where it can), so that the four rows a 16-lane LDS access covers hit four different bank quarters; the sum therefore runs in
+// another ORDER than the gather kernel's -- same terms, results equal to rounding (deterministic from run to run).
 // Generic in the graph: rings come from the plan's own pattern; whole graphs only (no halo columns, all rows).
 #include <algorithm>
 

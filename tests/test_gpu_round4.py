@@ -578,8 +578,9 @@ def test_fuzz_input_side_strips_and_pass_chains():
 ])
 def test_tiled_step_on_wide_graphs(nside, k, N, F, K, basis):
     """A symmetrised k-nearest-neighbour graph as the reference's models build it: single steps through dsph_cheb_step with the
-    tiled kernel and with the gather kernel (DSPH_OPT_TSTEP = 0) agree BIT FOR BIT (same summation order), the whole forward
-    agrees with the float64 oracle, and so does the weight gradient (its planes come from the same steps)."""
+    tiled kernel and with the gather kernel (DSPH_OPT_TSTEP = 0) agree to rounding (the tiled kernel deals a row's slots by
+    bank residue: the same terms in another order) and repeat bit for bit, the whole forward agrees with the float64 oracle, and
+    so does the weight gradient (its planes come from the same steps)."""
     L = healpix.healpix_laplacian(nside, n_neighbors=k, mode="knn")
     Lt, _ = orc.prepare_L(L, scale=0.75 if basis == "chebyshev" else 1.0)
     cols, vals = utils.csr_to_ell(Lt)
@@ -592,10 +593,12 @@ def test_tiled_step_on_wide_graphs(nside, k, N, F, K, basis):
     xd, pd = _dev(x), _dev(rng.standard_normal((N, M, F)).astype(np.float32))
     a = _native.cheb_step(plan, xd, None, 1.0, 0.0)
     b = _native.cheb_step(plain, xd, None, 1.0, 0.0)
-    assert torch.equal(a, b)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6 and torch.equal(a, _native.cheb_step(plan, xd, None, 1.0, 0.0))
+    if W_ell <= 12:
+        assert torch.equal(a, b)  # (not a wide graph: both plans run the gather kernel)
     a2 = _native.cheb_step(plan, a, pd, 2.0, 1.0)
-    b2 = _native.cheb_step(plain, b, pd, 2.0, 1.0)
-    assert torch.equal(a2, b2)
+    b2 = _native.cheb_step(plain, a, pd, 2.0, 1.0)
+    assert rel_err(a2.cpu().numpy(), b2.cpu().numpy()) < 1e-6
     ref1 = (Lt.astype(np.float64) @ x.transpose(1, 0, 2).reshape(M, -1)).reshape(M, N, F).transpose(1, 0, 2)
     assert rel_err(a.cpu().numpy(), ref1) < 2e-6
     Fout = 12
@@ -606,7 +609,7 @@ def test_tiled_step_on_wide_graphs(nside, k, N, F, K, basis):
     y, _ = _native.cheb_forward(plan, xd, _dev(Wk), _dev(bias), K, act=_native.ACT_RELU, precision=_native.PREC_BF16X6, basis=B)
     yp, _ = _native.cheb_forward(plain, xd, _dev(Wk), _dev(bias), K, act=_native.ACT_RELU, precision=_native.PREC_BF16X6, basis=B)
     assert rel_err(y.cpu().numpy(), fwd(Lt, x, Wk, K, bias=bias, activation="relu")) < 2e-6
-    assert torch.equal(y, yp)
+    assert rel_err(y.cpu().numpy(), yp.cpu().numpy()) < 2e-6
     if basis == "chebyshev":
         dy = rng.standard_normal((N, M, Fout)).astype(np.float32)
         dw, _ = _native.cheb_backward_weights(plan, xd, _dev(dy), K)

@@ -19,7 +19,10 @@ algo = {"auto": 0, "unfused": 1, "fused": 2}[sys.argv[3] if len(sys.argv) > 3 el
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 nside, K, Fin, Fout, N = bench.CONFIGS[cfg]
 dev = torch.device("cuda", 0)
-cols, vals, lmax = bench.build_laplacian_masked(nside, dev) if cfg in bench.MASKED else bench.build_laplacian(nside, dev)
+if cfg in bench.KNN:
+    cols, vals, lmax = bench.build_laplacian_knn(nside, dev, bench.KNN[cfg])
+else:
+    cols, vals, lmax = bench.build_laplacian_masked(nside, dev) if cfg in bench.MASKED else bench.build_laplacian(nside, dev)
 plan = _native.LaplacianPlan(cols, vals, device=0)
 M = cols.shape[0]
 x = torch.randn((N, M, Fin), device=dev)
