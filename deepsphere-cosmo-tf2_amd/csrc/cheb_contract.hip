@@ -209,8 +209,21 @@ int launch_cheb_contract(const float* const* planes, int64_t plane_rows, const f
                          const float* bias, float* y, int64_t N, int64_t rows, int32_t Fin,
                          int32_t Fout, int32_t K, int32_t act, int32_t precision,
                          hipStream_t stream) {
-  (void)precision;  // the unfused contraction always runs exact fp32 MFMA
   if (rows <= 0 || N <= 0) return DSPH_OK;
+  // channel counts in multiples of four: plane rows straight into the MFMA operand layout, in the arithmetic asked for
+  // (cheb_tcontract.hip); the kernels below -- always exact fp32 -- take what that one does not
+  if (Fin * K > 64 || Fin % 4 == 0) {
+    int rc = DSPH_OK, ncu = 256, dev = 0;
+    static int ncu_of[64] = {0};  // (looked up once per device: hipGetDeviceProperties is slow; a racing second writer stores the same value)
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      if (ncu_of[dev] == 0) {
+        hipDeviceProp_t prop;
+        ncu_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+      }
+      ncu = ncu_of[dev];
+    }
+    if (Fin * K > 64 && launch_cheb_tcontract(planes, plane_rows, w, bias, y, N, rows, Fin, Fout, K, act, precision, ncu, stream, &rc)) return rc;
+  }
   if (K > KMAX) {
     set_error("cheb_contract: K = %d exceeds %d", K, KMAX);
     return DSPH_E_UNSUPPORTED;

@@ -76,6 +76,10 @@ int launch_cheb_contract(const float* const* planes, int64_t plane_rows, const f
                          int32_t Fout, int32_t K, int32_t act, int32_t precision,
                          hipStream_t stream);
 
+bool launch_cheb_tcontract(const float* const* planes, int64_t plane_rows, const float* w, const float* bias, float* y, int64_t N,
+                           int64_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t act, int32_t precision, int num_cu,
+                           hipStream_t stream, int* rc);
+
 size_t wgrad_workspace_bytes(int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K);
 int launch_cheb_wgrad(const float* const* planes, int64_t plane_rows, const float* dy, float* dw,
                       int64_t N, int64_t rows, int32_t Fin, int32_t Fout, int32_t K, void* workspace,
