@@ -22,10 +22,10 @@
 
 namespace dsph {
 
-constexpr int TS_THREADS = 512;   // 128 tile rows x 4 chunks of 4 channels per pass, two passes: a lane owns two rows
-constexpr int TS_RP = 2;
+// TS_RP tile rows per lane: 1 (1,024 threads, sixteen waves: twice the waves to hide the staging loads' latency behind -- the
+// kernel waits on memory, not on LDS or the vector pipe -- within 128 registers) or 2 (512 threads, for the widths whose row
+// tables do not fit 128 registers)
 constexpr int TS_RMAX = 768;      // region rows a plane holds (64 B each): a 27 x 27 pixel region
-constexpr int TS_SQ = TS_RMAX * 4 / TS_THREADS;  // staged 16-byte pieces per lane
 
 struct TStepArgs {
   const float* in;
@@ -42,8 +42,10 @@ struct TStepArgs {
   float alpha, beta;
 };
 
-template <int WT>
-__global__ __launch_bounds__(TS_THREADS, 2) void cheb_tstep_kernel(TStepArgs a) {
+template <int WT, int TS_RP>
+__global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
+  constexpr int TS_THREADS = 1024 / TS_RP, TS_ROWS = TS_THREADS / 4;  // rows per pass
+  constexpr int TS_SQ = TS_RMAX / TS_ROWS;                            // staged 16-byte pieces per lane
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TS_RMAX * 64];
   const int tid = threadIdx.x, row_l = tid >> 2, slot = tid & 3;
   const int nslices = (a.F + 15) / 16;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(TS_THREADS, 2) void cheb_tstep_kernel(TStepArgs a) 
     const int E = a.ring_end[(size_t)t * (FUSED_DMAX + 1)];       // the tile's own rows (the last tile may be ragged)
     const int R = a.ring_end[(size_t)t * (FUSED_DMAX + 1) + 1];   // rows within one hop
     const int64_t r0 = (int64_t)t * FUSED_P;
-    // this lane's rows of the tile-local ELL (row_l and row_l + 128): LDS byte addresses of the neighbours' chunk, and the values
+    // this lane's rows of the tile-local ELL (row_l, and row_l + 128 with two rows per lane): LDS byte addresses of the neighbours' chunk, and the values
     unsigned pre[TS_RP][WT / 2];  // two 16-bit addresses per register
     float val[TS_RP][WT];
     {
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(TS_THREADS, 2) void cheb_tstep_kernel(TStepArgs a) 
       const float* lv = a.lvals + a.ell_off[t] * WT;
 #pragma unroll
       for (int p = 0; p < TS_RP; ++p) {
-        const int row = row_l + 128 * p;
+        const int row = row_l + TS_ROWS * p;
 #pragma unroll
         for (int j = 0; j < WT; ++j) {
           const unsigned c = row < E ? lc[(size_t)j * E + row] : 0u;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(TS_THREADS, 2) void cheb_tstep_kernel(TStepArgs a) 
     int grow[TS_SQ];
 #pragma unroll
     for (int q = 0; q < TS_SQ; ++q) {
-      const int i = row_l + 128 * q;
+      const int i = row_l + TS_ROWS * q;
       grow[q] = i < R ? a.region[base + i] : -1;
     }
     float4 st[TS_SQ];
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(TS_THREADS, 2) void cheb_tstep_kernel(TStepArgs a) 
     auto stage = [&](unsigned char* plane) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < TS_SQ; ++q) {
-        const int i = row_l + 128 * q;
+        const int i = row_l + TS_ROWS * q;
         if (i < R) *reinterpret_cast<float4*>(plane + plane_byte((unsigned)i, (unsigned)slot)) = st[q];
       }
     };
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(TS_THREADS, 2) void cheb_tstep_kernel(TStepArgs a) 
       asm volatile("" : "+v"(po));
 #pragma unroll
       for (int p = 0; p < TS_RP; ++p) {
-        const int row = row_l + 128 * p;
+        const int row = row_l + TS_ROWS * p;
         if (row < E && ch < a.F) {
           float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
           // eight gathers in flight at a time (all WT at once cost WT x 4 registers of landing space).  The packed addresses are
@@ -178,9 +180,9 @@ int launch_cheb_tstep(const TStepTables& tb, const float* in, const float* prev,
   a.beta = beta;
   const int grid = std::max(8, std::min(tb.ntiles, num_cu) / 8 * 8);
   switch (tb.width) {
-    case 16: hipLaunchKernelGGL(cheb_tstep_kernel<16>, dim3(grid), dim3(TS_THREADS), 0, stream, a); break;
-    case 24: hipLaunchKernelGGL(cheb_tstep_kernel<24>, dim3(grid), dim3(TS_THREADS), 0, stream, a); break;
-    case 32: hipLaunchKernelGGL(cheb_tstep_kernel<32>, dim3(grid), dim3(TS_THREADS), 0, stream, a); break;
+    case 16: hipLaunchKernelGGL((cheb_tstep_kernel<16, 1>), dim3(grid), dim3(1024), 0, stream, a); break;
+    case 24: hipLaunchKernelGGL((cheb_tstep_kernel<24, 1>), dim3(grid), dim3(1024), 0, stream, a); break;
+    case 32: hipLaunchKernelGGL((cheb_tstep_kernel<32, 2>), dim3(grid), dim3(512), 0, stream, a); break;
     default: set_error("cheb_tstep: no kernel for table width %d", tb.width); return DSPH_E_UNSUPPORTED;
   }
   DSPH_HIP(hipGetLastError());
