@@ -385,6 +385,13 @@ class Chebyshev(torch.nn.Module):
 
     call = forward
 
+    def invalidate_weights(self):
+        """Forget the packed weight images (and a captured graph): the next forward re-packs.  The layer notices weight updates
+        by the version counter of ``self.kernel`` -- optimiser steps, ``copy_``, ``load_state_dict`` all move it -- but an
+        in-place write through ``kernel.data`` does not; call this after one."""
+        self._wkey = None
+        self._graph = None
+
     def _graph_forward(self, plan, x, bias, act_code, wkey):
         """The prepared forward as one HIP-graph launch (``graph=True``).  Captured after an ordinary forward has packed the
         weight images and sized the workspace; the captured call keeps them (DSPH_FWD_KEEP_WEIGHTS), so the graph holds the
