@@ -296,7 +296,7 @@ def main():
             with torch.no_grad():  # inference forward: bias/activation fused in the kernel epilogue
                 return layer(x)
         fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-        step_name = "cheb_tstep_kernel" if (12 < W_ell <= 32 and args.tstep == "on" and Fin % 4 == 0) else "cheb_step_kernel"
+        step_name = "cheb_tstep_kernel" if (12 < W_ell <= 32 and args.tstep == "on") else "cheb_step_kernel"
         kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N, args.split) if fused else f"{step_name} x{K - 1} + cheb_contract_f32_kernel"
     else:
         from deepsphere import sharding

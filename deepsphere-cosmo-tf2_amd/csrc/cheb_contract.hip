@@ -212,7 +212,7 @@ int launch_cheb_contract(const float* const* planes, int64_t plane_rows, const f
   if (rows <= 0 || N <= 0) return DSPH_OK;
   // channel counts in multiples of four: plane rows straight into the MFMA operand layout, in the arithmetic asked for
   // (cheb_tcontract.hip); the kernels below -- always exact fp32 -- take what that one does not
-  if (Fin * K > 64 || Fin % 4 == 0) {
+  if (Fin * K > 64) {
     int rc = DSPH_OK, ncu = 256, dev = 0;
     static int ncu_of[64] = {0};  // (looked up once per device: hipGetDeviceProperties is slow; a racing second writer stores the same value)
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
@@ -222,7 +222,7 @@ int launch_cheb_contract(const float* const* planes, int64_t plane_rows, const f
       }
       ncu = ncu_of[dev];
     }
-    if (Fin * K > 64 && launch_cheb_tcontract(planes, plane_rows, w, bias, y, N, rows, Fin, Fout, K, act, precision, ncu, stream, &rc)) return rc;
+    if (launch_cheb_tcontract(planes, plane_rows, w, bias, y, N, rows, Fin, Fout, K, act, precision, ncu, stream, &rc)) return rc;
   }
   if (K > KMAX) {
     set_error("cheb_contract: K = %d exceeds %d", K, KMAX);

@@ -92,10 +92,9 @@ int launch_cheb_step(const dsph_plan* plan, const float* in, int64_t in_rows, co
     return DSPH_E_BADARG;
   }
   // graphs wider than the fused kernels' templates (the reference's 20 / 40 neighbours): the step through LDS tiles, every row of
-  // `in` read once per tile region instead of once per neighbour (cheb_tstep.hip) -- whole graphs, whole planes, 16-byte rows
+  // `in` read once per tile region instead of once per neighbour (cheb_tstep.hip) -- whole graphs, whole planes
   if (plan->fused != nullptr && plan->opt.tstep && rows == plan->n_rows && in_rows == plan->n_rows && out_rows == plan->n_rows &&
-      (prev == nullptr || beta == 0.f || prev_rows == plan->n_rows) && F % 4 == 0 &&
-      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(prev)) & 15) == 0) {
+      (prev == nullptr || beta == 0.f || prev_rows == plan->n_rows)) {
     TStepTables tb;
     if (fused_tstep_tables(plan, &tb))
       return launch_cheb_tstep(tb, in, prev, out, rows, N, F, alpha, beta, fused_num_cu(plan), stream);

@@ -6,7 +6,7 @@
 // path used to run exact fp32 whatever the layer asked for, padded to 32 channels per order).  The weights are turned into
 // A-operand fragments in LDS by the workgroup itself (a few KiB), the accumulator tile (32 rows x 32 columns, lane = row) is stored
 // with 16-byte stores.  HBM-bound: K planes in, y out.  Used by the unfused path (graphs the fused kernels do not take) whenever
-// the channel count is a multiple of four and the fragments fit the LDS; cheb_contract.hip otherwise.
+// Fin * K > 64 and the fragments fit the LDS (channel counts that are not multiples of four: scalar loads); cheb_contract.hip otherwise.
 #include <algorithm>
 
 #include "cheb_istrip_kernel.h"
@@ -26,7 +26,7 @@ struct TContractArgs {
   int N, Fin, Fout, K, act;
 };
 
-template <int PREC, int NB>
+template <int PREC, int NB, bool VEC>  // VEC: channel count a multiple of four, planes 16-byte aligned
 __global__ __launch_bounds__(TC_THREADS, 2) void cheb_tcontract_kernel(TContractArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
   constexpr int TERMS = is_terms(PREC), TB = is_term_bytes(PREC), LEVB = TERMS * TB;
@@ -73,10 +73,15 @@ __global__ __launch_bounds__(TC_THREADS, 2) void cheb_tcontract_kernel(TContract
         for (int k = 0; k < a.K; ++k) {
           float row[8];
           const float* src = a.p[k] + ((int64_t)n * a.plane_rows + (row_ok ? m : 0)) * a.Fin + ch;
-          const sp_f32x4 v0 = (row_ok && ch < a.Fin) ? *reinterpret_cast<const sp_f32x4*>(src) : sp_f32x4{0.f, 0.f, 0.f, 0.f};
-          const sp_f32x4 v1 = (row_ok && ch + 4 < a.Fin) ? *reinterpret_cast<const sp_f32x4*>(src + 4) : sp_f32x4{0.f, 0.f, 0.f, 0.f};
+          if (VEC) {
+            const sp_f32x4 v0 = (row_ok && ch < a.Fin) ? *reinterpret_cast<const sp_f32x4*>(src) : sp_f32x4{0.f, 0.f, 0.f, 0.f};
+            const sp_f32x4 v1 = (row_ok && ch + 4 < a.Fin) ? *reinterpret_cast<const sp_f32x4*>(src + 4) : sp_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { row[j] = v0[j]; row[4 + j] = v1[j]; }
+            for (int j = 0; j < 4; ++j) { row[j] = v0[j]; row[4 + j] = v1[j]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) row[j] = (row_ok && ch + j < a.Fin) ? src[j] : 0.f;
+          }
 #pragma unroll
           for (int q = 0; q < NB; ++q)
             if (nb0 + q < NBT)
@@ -110,14 +115,14 @@ bool launch_cheb_tcontract(const float* const* planes, int64_t plane_rows, const
                            int64_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t act, int32_t precision, int num_cu,
                            hipStream_t stream, int* rc) {
   *rc = DSPH_OK;
-  if (Fin % 4 != 0 || K > TC_KMAX || N > (1 << 24)) return false;
+  if (K > TC_KMAX || N > (1 << 24)) return false;
   const int C = (Fin + 15) / 16, NBT = (Fout + 31) / 32;
   const size_t lds = (size_t)C * K * NBT * is_terms(precision) * is_term_bytes(precision);
   if (lds > (size_t)TC_LDS_MAX) return false;
   TContractArgs a;
   for (int k = 0; k < TC_KMAX; ++k) a.p[k] = k < K ? planes[k] : nullptr;
-  for (int k = 0; k < K; ++k)
-    if (reinterpret_cast<uintptr_t>(planes[k]) & 15) return false;
+  bool vec_in = Fin % 4 == 0;
+  for (int k = 0; k < K; ++k) vec_in = vec_in && (reinterpret_cast<uintptr_t>(planes[k]) & 15) == 0;
   if ((reinterpret_cast<uintptr_t>(y) & 15) && Fout % 4 == 0) return false;
   a.w = w; a.bias = bias; a.y = y;
   a.plane_rows = plane_rows; a.rows = rows;
@@ -127,8 +132,10 @@ bool launch_cheb_tcontract(const float* const* planes, int64_t plane_rows, const
   const bool two = NBT >= 2;
 #define DSPH_TC(P)                                                                                                             \
   do {                                                                                                                         \
-    if (two) hipLaunchKernelGGL((cheb_tcontract_kernel<P, 2>), dim3(grid), dim3(TC_THREADS), lds, stream, a);                   \
-    else hipLaunchKernelGGL((cheb_tcontract_kernel<P, 1>), dim3(grid), dim3(TC_THREADS), lds, stream, a);                       \
+    if (two && vec_in) hipLaunchKernelGGL((cheb_tcontract_kernel<P, 2, true>), dim3(grid), dim3(TC_THREADS), lds, stream, a);   \
+    else if (two) hipLaunchKernelGGL((cheb_tcontract_kernel<P, 2, false>), dim3(grid), dim3(TC_THREADS), lds, stream, a);       \
+    else if (vec_in) hipLaunchKernelGGL((cheb_tcontract_kernel<P, 1, true>), dim3(grid), dim3(TC_THREADS), lds, stream, a);     \
+    else hipLaunchKernelGGL((cheb_tcontract_kernel<P, 1, false>), dim3(grid), dim3(TC_THREADS), lds, stream, a);                \
   } while (0)
   if (precision == DSPH_PREC_FP32) DSPH_TC(DSPH_PREC_FP32);
   else if (precision == DSPH_PREC_BF16X6) DSPH_TC(DSPH_PREC_BF16X6);

@@ -42,7 +42,9 @@ struct TStepArgs {
   float alpha, beta;
 };
 
-template <int WT, int TS_RP>
+// VEC: the channel count is a multiple of four and the planes are 16-byte aligned (16-byte loads and stores); otherwise a lane
+// moves its four channels one by one (the reference's own models have 5 or 2 channels: examples/quick_start.ipynb:118-127)
+template <int WT, int TS_RP, bool VEC>
 __global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
   constexpr int TS_THREADS = 1024 / TS_RP, TS_ROWS = TS_THREADS / 4;  // rows per pass
   constexpr int TS_SQ = TS_RMAX / TS_ROWS;                            // staged 16-byte pieces per lane
@@ -89,7 +91,16 @@ __global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
 #pragma unroll
       for (int q = 0; q < TS_SQ; ++q) {
         st[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grow[q] >= 0 && ch < a.F) st[q] = *reinterpret_cast<const float4*>(a.in + ((int64_t)n * a.rows + (int64_t)grow[q]) * a.F + ch);
+        if (grow[q] >= 0 && ch < a.F) {
+          const float* src = a.in + ((int64_t)n * a.rows + (int64_t)grow[q]) * a.F + ch;
+          if (VEC) st[q] = *reinterpret_cast<const float4*>(src);
+          else {
+            st[q].x = src[0];
+            if (ch + 1 < a.F) st[q].y = src[1];
+            if (ch + 2 < a.F) st[q].z = src[2];
+            if (ch + 3 < a.F) st[q].w = src[3];
+          }
+        }
       }
     };
     auto stage = [&](unsigned char* plane) __attribute__((always_inline)) {
@@ -140,12 +151,25 @@ __global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
           const int64_t o = ((int64_t)n * a.rows + r0 + row) * a.F + ch;
           float4 r;
           if (a.prev != nullptr) {
-            const float4 q = *reinterpret_cast<const float4*>(a.prev + o);
+            float4 q;
+            if (VEC) q = *reinterpret_cast<const float4*>(a.prev + o);
+            else {
+              q.x = a.prev[o];
+              q.y = ch + 1 < a.F ? a.prev[o + 1] : 0.f;
+              q.z = ch + 2 < a.F ? a.prev[o + 2] : 0.f;
+              q.w = ch + 3 < a.F ? a.prev[o + 3] : 0.f;
+            }
             r = make_float4(a.alpha * s.x - a.beta * q.x, a.alpha * s.y - a.beta * q.y, a.alpha * s.z - a.beta * q.z, a.alpha * s.w - a.beta * q.w);
           } else {
             r = make_float4(a.alpha * s.x, a.alpha * s.y, a.alpha * s.z, a.alpha * s.w);
           }
-          *reinterpret_cast<float4*>(a.out + o) = r;
+          if (VEC) *reinterpret_cast<float4*>(a.out + o) = r;
+          else {
+            a.out[o] = r.x;
+            if (ch + 1 < a.F) a.out[o + 1] = r.y;
+            if (ch + 2 < a.F) a.out[o + 2] = r.z;
+            if (ch + 3 < a.F) a.out[o + 3] = r.w;
+          }
         }
       }
       if (it + 1 < iters) stage(smem + ((it + 1) & 1) * (TS_RMAX * 64));
@@ -179,12 +203,19 @@ int launch_cheb_tstep(const TStepTables& tb, const float* in, const float* prev,
   a.alpha = alpha;
   a.beta = beta;
   const int grid = std::max(8, std::min(tb.ntiles, num_cu) / 8 * 8);
+  const bool vec = F % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(a.prev)) & 15) == 0;
+#define DSPH_TS(WT, RP)                                                                                                     \
+  do {                                                                                                                      \
+    if (vec) hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, true>), dim3(grid), dim3(1024 / RP), 0, stream, a);               \
+    else hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, false>), dim3(grid), dim3(1024 / RP), 0, stream, a);                  \
+  } while (0)
   switch (tb.width) {
-    case 16: hipLaunchKernelGGL((cheb_tstep_kernel<16, 1>), dim3(grid), dim3(1024), 0, stream, a); break;
-    case 24: hipLaunchKernelGGL((cheb_tstep_kernel<24, 1>), dim3(grid), dim3(1024), 0, stream, a); break;
-    case 32: hipLaunchKernelGGL((cheb_tstep_kernel<32, 2>), dim3(grid), dim3(512), 0, stream, a); break;
+    case 16: DSPH_TS(16, 1); break;
+    case 24: DSPH_TS(24, 1); break;
+    case 32: DSPH_TS(32, 2); break;
     default: set_error("cheb_tstep: no kernel for table width %d", tb.width); return DSPH_E_UNSUPPORTED;
   }
+#undef DSPH_TS
   DSPH_HIP(hipGetLastError());
   return DSPH_OK;
 }

@@ -574,6 +574,8 @@ def test_fuzz_input_side_strips_and_pass_chains():
     (32, 20, 3, 16, 5, "chebyshev"),   # ELL width 23 -> the 24-wide instantiation; one 16-channel slice
     (32, 20, 2, 40, 4, "chebyshev"),   # three slices, the last one partial
     (16, 20, 2, 4, 3, "monomial"),     # one 4-channel chunk, the other basis, 12 tiles
+    (32, 20, 2, 5, 6, "chebyshev"),    # five channels (the quick-start model's width): scalar loads and stores; K = 6
+    (16, 20, 3, 1, 10, "chebyshev"),   # one channel, the tutorials' K = 10
     (32, 8, 2, 8, 5, "chebyshev"),     # width 11: the fused kernels' territory -- the tiled step is not used, same answer
 ])
 def test_tiled_step_on_wide_graphs(nside, k, N, F, K, basis):
@@ -615,3 +617,46 @@ def test_tiled_step_on_wide_graphs(nside, k, N, F, K, basis):
         dw, _ = _native.cheb_backward_weights(plan, xd, _dev(dy), K)
         _, dW_ref = orc.chebyshev_backward(Lt, x, Wk, K, dy)
         assert rel_err(dw.cpu().numpy(), dW_ref) < 1e-5
+
+
+def test_quick_start_model_values():
+    """The reference's quick-start network (examples/quick_start.ipynb:118-127, 142-147): HealpyGCNN(n_neighbors=20) of four
+    HealpyChebyshev(K=10, Fout=5 | 2, use_bias, use_bn, relu) layers with HealpyPool(p=1) between them, one input channel --
+    20-neighbour graphs (ELL width 23), K = 10, channel counts that are no multiple of four: every step on the tiled kernel's
+    scalar path, every contraction on the direct-operand kernel.  Values against the same walk with the float64 oracle layers
+    (batch norm in inference mode at its initial statistics)."""
+    from deepsphere import healpy_layers, healpy_networks
+
+    nside = 16
+    indices = np.arange(12 * nside * nside)
+    layers = [healpy_layers.HealpyChebyshev(K=10, Fout=5, use_bias=True, use_bn=True, activation="relu"),
+              healpy_layers.HealpyPool(p=1),
+              healpy_layers.HealpyChebyshev(K=10, Fout=5, use_bias=True, use_bn=True, activation="relu"),
+              healpy_layers.HealpyPool(p=1),
+              healpy_layers.HealpyChebyshev(K=10, Fout=2)]
+    torch.manual_seed(11)
+    model = healpy_networks.HealpyGCNN(nside=nside, indices=indices, layers=layers, n_neighbors=20).cuda()
+    model.eval()
+    rng = np.random.default_rng(18)
+    x = rng.standard_normal((4, len(indices), 1)).astype(np.float32)
+    with torch.no_grad():
+        y = model(_dev(x)).cpu().numpy()
+    cur, cur_nside, cur_idx = x.astype(np.float64), nside, np.asarray(indices)
+    for spec, mod in zip(layers, model):
+        if isinstance(spec, healpy_layers.HealpyPool):
+            cur = orc.healpy_pool(cur, spec.p, spec.pool_type)
+            cur_idx = np.unique(cur_idx // 4 ** spec.p)
+            cur_nside //= 2 ** spec.p
+            continue
+        L = healpix.healpix_laplacian(cur_nside, indices=cur_idx, n_neighbors=20, mode="knn")
+        assert utils.csr_to_ell(L)[0].shape[1] > 12, "a 20-neighbour graph is wider than the fused kernels' templates"
+        Lt, _ = orc.prepare_L(L)
+        Wk = mod.kernel.detach().cpu().numpy().astype(np.float64)
+        b = mod.bias.detach().cpu().numpy().reshape(-1).astype(np.float64) if mod.use_bias else None
+        Fo = Wk.shape[1]
+        cur = orc.chebyshev_forward(Lt, cur, Wk, spec.K, bias=b, activation=spec.activation,
+                                    bn=(np.zeros(Fo), np.ones(Fo)) if spec.use_bn else None)
+    assert y.shape == cur.shape == (4, len(indices) // 16, 2)
+    err = rel_err(y, cur)
+    print(f"quick-start model vs oracle composition: rel err {err:.2e}")
+    assert err < 1e-5
