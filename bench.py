@@ -52,9 +52,10 @@ CONFIGS = {
     # a layer of the reference's quick-start model (examples/quick_start.ipynb:118-127,142-147): K = 10, five channels,
     # 20 neighbours, batch 16 -- at nside 256
     "qs": (256, 10, 5, 5, 16),
+    "qs1": (256, 10, 1, 5, 16),  # its first layer: one input channel
 }
 MASKED = {"c5"}
-KNN = {"knn8": 8, "knn20": 20, "qs": 20}
+KNN = {"knn8": 8, "knn20": 20, "qs": 20, "qs1": 20}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 
