@@ -50,7 +50,12 @@ __global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
   constexpr int TS_SQ = TS_RMAX / TS_ROWS;                            // staged 16-byte pieces per lane
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TS_RMAX * 64];
   const int tid = threadIdx.x, row_l = tid >> 2, slot = tid & 3;
-  const int nslices = (a.F + 15) / 16;
+  // A plane row holds 16 channels.  Layers with up to eight channels (the reference's quick-start model: 1 and 5) would leave most
+  // of it empty, so several MAPS share a row: with cpm = ceil(F / 4) chunks per map, 4 / cpm maps per iteration (four maps of up
+  // to 4 channels, two of up to 8); wider layers: one map, 16 channels of it, per iteration.
+  const int cpm = (a.F + 3) / 4, mpi = cpm <= 2 ? 4 / cpm : 1;
+  const int nslices = mpi > 1 ? 1 : (a.F + 15) / 16;
+  const int ngroups = (a.N + mpi - 1) / mpi;
   const unsigned nblk = gridDim.x;
   for (unsigned tb = xcd_remap(blockIdx.x, nblk); tb < (unsigned)a.ntiles; tb += nblk) {
     const int t = (int)tb;
@@ -86,12 +91,13 @@ __global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
     }
     float4 st[TS_SQ];
     auto fetch = [&](int it) __attribute__((always_inline)) {
-      const int n = it / nslices, c = it - n * nslices;
-      const int ch = 16 * c + 4 * slot;
+      const int grp = it / nslices, c = it - grp * nslices;
+      const int n = mpi > 1 ? grp * mpi + slot / cpm : grp;
+      const int ch = mpi > 1 ? 4 * (slot % cpm) : 16 * c + 4 * slot;
 #pragma unroll
       for (int q = 0; q < TS_SQ; ++q) {
         st[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grow[q] >= 0 && ch < a.F) {
+        if (grow[q] >= 0 && ch < a.F && n < a.N) {
           const float* src = a.in + ((int64_t)n * a.rows + (int64_t)grow[q]) * a.F + ch;
           if (VEC) st[q] = *reinterpret_cast<const float4*>(src);
           else {
@@ -110,21 +116,22 @@ __global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
         if (i < R) *reinterpret_cast<float4*>(plane + plane_byte((unsigned)i, (unsigned)slot)) = st[q];
       }
     };
-    const int iters = a.N * nslices;
+    const int iters = ngroups * nslices;
     fetch(0);
     __syncthreads();  // (the previous tile's last reads of plane 0)
     stage(smem);
     for (int it = 0; it < iters; ++it) {
       if (it + 1 < iters) fetch(it + 1);
       __syncthreads();  // plane `it & 1` is staged; the other one's readers of iteration it - 1 are done
-      const int n = it / nslices, c = it - n * nslices;
-      const int ch = 16 * c + 4 * slot;
+      const int grp = it / nslices, c = it - grp * nslices;
+      const int n = mpi > 1 ? grp * mpi + slot / cpm : grp;
+      const int ch = mpi > 1 ? 4 * (slot % cpm) : 16 * c + 4 * slot;
       unsigned po = (unsigned)(it & 1) * (TS_RMAX * 64);
       asm volatile("" : "+v"(po));
 #pragma unroll
       for (int p = 0; p < TS_RP; ++p) {
         const int row = row_l + TS_ROWS * p;
-        if (row < E && ch < a.F) {
+        if (row < E && ch < a.F && n < a.N) {
           float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
           // eight gathers in flight at a time (all WT at once cost WT x 4 registers of landing space).  The packed addresses are
           // unpacked from a copy hipcc cannot see through: it would otherwise hoist the unpacked, plane-relative addresses of
