@@ -210,9 +210,9 @@ int launch_cheb_contract(const float* const* planes, int64_t plane_rows, const f
                          int32_t Fout, int32_t K, int32_t act, int32_t precision,
                          hipStream_t stream) {
   if (rows <= 0 || N <= 0) return DSPH_OK;
-  // channel counts in multiples of four: plane rows straight into the MFMA operand layout, in the arithmetic asked for
-  // (cheb_tcontract.hip); the kernels below -- always exact fp32 -- take what that one does not
-  if (Fin * K > 64) {
+  // plane rows straight into the MFMA operand layout, in the arithmetic asked for (cheb_tcontract.hip: four input channels and
+  // more); the kernels below -- always exact fp32 -- take what that one does not (fewer channels: the plain-FMA kernel)
+  if (Fin * K > 64 || Fin >= 4) {
     int rc = DSPH_OK, ncu = 256, dev = 0;
     static int ncu_of[64] = {0};  // (looked up once per device: hipGetDeviceProperties is slow; a racing second writer stores the same value)
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
