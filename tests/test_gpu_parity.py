@@ -447,7 +447,10 @@ def test_layer_gradients_match_oracle(graph, use_bias, activation):
     else:
         dz = dy_np
     dx_ref, dW_ref = orc.chebyshev_backward(Lt, x_np, W_np, K, dz)
-    assert rel_err(y.detach().cpu().numpy(), orc.chebyshev_forward(Lt, x_np, W_np, K, bias=b, activation=activation)) < 2e-5
+    # (behind tanh the reference scale shrinks to <= 1 while the pre-activation's error passes through with slope <= 1: five times
+    # the tolerance, as tools/fuzz_gpu.py holds it -- since round 4 the unfused contraction runs the layer's own arithmetic, the
+    # three-term split here, where it used to be exact fp32 whatever the layer asked for)
+    assert rel_err(y.detach().cpu().numpy(), orc.chebyshev_forward(Lt, x_np, W_np, K, bias=b, activation=activation)) < (1e-4 if activation == "tanh" else 2e-5)
     assert rel_err(x.grad.cpu().numpy(), dx_ref) < 2e-5
     assert rel_err(layer.kernel.grad.cpu().numpy(), dW_ref) < 2e-5
     if use_bias:
