@@ -56,7 +56,7 @@ for it in range(cases):
         K, Fin, Fout = 5, 64, 64 * int(rng.integers(1, 4))
     if ISTRIPS:
         K = int(rng.integers(2, 6)) if it % 3 else int(rng.integers(6, 14))
-        Fin = int(rng.integers(1, 17))
+        Fin = int(rng.integers(1, 17)) if rng.random() < 0.7 else int(rng.integers(1, 3))  # (1, 2: the level-packed kernel)
         Fout = 4 * int(rng.integers(1, 26)) if rng.random() < 0.8 else int(rng.integers(1, 100))
     if not plan.fused_ok(Fin, Fout, K):
         continue
