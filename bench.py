@@ -202,7 +202,7 @@ def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1, split="auto"):
     n_strip = plan.strip_tiles(Fin, Fout, K, prec_code, N=N)
     parts = []
     if n_strip:
-        parts.append(f"{'cheb_istrip_kernel' if Fin <= 16 else 'cheb_strip5_kernel'} ({n_strip} tiles)")
+        parts.append(f"{'cheb_istrip1_kernel' if Fin <= 2 else ('cheb_istrip_kernel' if Fin <= 16 else 'cheb_strip5_kernel')} ({n_strip} tiles)")
     if n_struct - n_strip:
         parts.append(f"cheb_struct_kernel ({n_struct - n_strip} tiles)")
     if n_bfs:
@@ -238,6 +238,8 @@ def main():
                     help="K > 5: the product-identity chain of K <= 5 passes (csrc/cheb_split.hip) -- plan option DSPH_OPT_SPLIT")
     ap.add_argument("--strips", default="auto", choices=["auto", "always", "never"], help="plan option DSPH_OPT_STRIPS")
     ap.add_argument("--tstep", default="on", choices=["on", "off"], help="plan option DSPH_OPT_TSTEP (wide graphs: tiled step)")
+    ap.add_argument("--fork", default="on", choices=["on", "off"],
+                    help="plan option DSPH_OPT_FORK (the BFS-tile launch beside the structured ones, on the plan's side stream)")
     ap.add_argument("--quick", action="store_true", help="the headline leg only: no side legs in the other arithmetics, no CPU baseline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = halo rows "
@@ -273,7 +275,8 @@ def main():
 
     plan_options = {_native.OPT_SPLIT: {"auto": 0, "always": 1, "never": 2}[args.split],
                     _native.OPT_STRIPS: {"auto": 0, "always": 1, "never": 2}[args.strips],
-                    _native.OPT_TSTEP: 1 if args.tstep == "on" else 0}
+                    _native.OPT_TSTEP: 1 if args.tstep == "on" else 0,
+                    _native.OPT_FORK: 1 if args.fork == "on" else 0}
     nside, K, Fin, Fout, N = CONFIGS[args.config]
     # what is timed is what a user of the layer gets: the layer's default arithmetic unless --precision says otherwise
     layer_default = args.precision is None

@@ -83,7 +83,7 @@ struct FusedTiles {
   int n_ipairs = 0;
   std::vector<int32_t> ipair_h;             // rows of every pair
   std::vector<unsigned char> ipair_second;  // whether its second strip exists
-  mutable std::map<int64_t, int> iseg;      // batch N -> row segments per strip (under FusedPlan::mu)
+  mutable std::map<int64_t, int> iseg;      // 2 * batch N + narrow -> row segments per strip (under FusedPlan::mu)
   // every tile of the plan, the interior ones first (d_all[0 .. n_all_interior)): what a two-part launch with a deferred
   // activation finishes per part (launch_struct_act_tiles)
   int32_t* d_all = nullptr;
@@ -950,11 +950,12 @@ static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fi
 static bool istrips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t K, int32_t Fout, int32_t ld) {
   return ft.n_ipairs > 0 && plan->opt.strips != 2 && istrip_shape_ok(Fin, K) && Fout % 4 == 0 && ld % 4 == 0;
 }
-static int istrip_nseg(const dsph_plan* plan, const FusedTiles& ft, int64_t N, int D) {
+static int istrip_nseg(const dsph_plan* plan, const FusedTiles& ft, int64_t N, int D, bool narrow) {
   FusedPlan* fp = plan->fused;
   std::lock_guard<std::mutex> lock(fp->mu);
-  auto it = ft.iseg.find(N);
-  if (it == ft.iseg.end()) it = ft.iseg.emplace(N, istrip_segments(ft.ipair_h, ft.ipair_second, N, fp->num_cu, D)).first;
+  const int64_t key = 2 * N + (narrow ? 1 : 0);
+  auto it = ft.iseg.find(key);
+  if (it == ft.iseg.end()) it = ft.iseg.emplace(key, istrip_segments(ft.ipair_h, ft.ipair_second, N, fp->num_cu, D, narrow)).first;
   return it->second;
 }
 
@@ -1300,7 +1301,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       is.x_rows = sl.x_rows; is.y_rows = sl.y_rows; is.N = N;
       is.npairs = ft.n_ipairs; is.Fin = Fin; is.Fin_w = Fin_w; is.Fout = Fout; is.K = K; is.act = act; is.precision = precision; is.ld = ld;
       is.num_cu = plan->fused->num_cu;
-      is.nseg = istrip_nseg(plan, ft, N, K - 1);
+      is.nseg = istrip_nseg(plan, ft, N, K - 1, istrip_narrow(Fin_w));
       is.cheb = sl.cheb;
       is.prep_weights = !keep_weights;
       const int rc = launch_cheb_istrip(is, stream);

@@ -9,6 +9,7 @@ namespace dsph {
 // A-operand fragments of one 32-column block: [level k][term][64 lanes][16 B] (bf16 arithmetics) or [k][step][64 lanes][4 B]
 // (exact fp32).  Lane (m = lane & 31 -> column 32 nb + m, kg = lane >> 5), slot j <- channel CH kg + j (zero for j >= CH and
 // for channels the layer does not have); w is the layer's kernel [Fin_w * K, ld], row f K + k.
+// CH == 1 (cheb_istrip1_kernel): ONE image, slot j <- level j of channel kg.
 __global__ __launch_bounds__(256) void istrip_wprep_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Fin_w,
                                                            int Fout, int K, int CH, int prec, int ld) {
   const int k = blockIdx.x;
@@ -17,7 +18,9 @@ __global__ __launch_bounds__(256) void istrip_wprep_kernel(const float* __restri
   for (int e = threadIdx.x; e < 512; e += 256) {
     const int l = e >> 3, j = e & 7;
     const int ch = CH * (l >> 5) + j, col = l & 31;
-    const float v = (j < CH && ch < Fin_w && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
+    float v;
+    if (CH == 1) v = (j < K && (l >> 5) < Fin_w && col < Fout) ? w[((int64_t)(l >> 5) * K + j) * ld + col] : 0.f;
+    else v = (j < CH && ch < Fin_w && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
     if (prec == DSPH_PREC_FP32) {
       reinterpret_cast<float*>(base)[j * 64 + l] = v;  // step j, lane l
     } else if (prec == DSPH_PREC_BF16X3) {
@@ -37,6 +40,7 @@ __global__ __launch_bounds__(256) void istrip_wprep_kernel(const float* __restri
   }
 }
 
+bool istrip_narrow(int32_t Fin_w) { return Fin_w <= 2; }  // real input channels: the level-packed kernel's layers
 bool istrip_shape_ok(int32_t Fin, int32_t K) { return K >= 2 && K <= 5 && Fin >= 4 && Fin <= 16 && Fin % 4 == 0; }
 
 size_t istrip_wimg_bytes(int32_t K, int32_t precision) { return (size_t)K * is_terms(precision) * is_term_bytes(precision); }
@@ -48,7 +52,10 @@ void (*istrip_kernel_k5(int ch, int prec))(IStripArgs);
 
 // Row segments per strip for a batch of N maps: the count whose busiest worker has the fewest steps when the kernel deals its
 // items (a contiguous eighth per XCD, in turn to the XCD's waves).  heights: rows of every pair's strips; D: run-in rows.
-int istrip_segments(const std::vector<int32_t>& heights, const std::vector<unsigned char>& second, int64_t N, int num_cu, int D) {
+int istrip_segments(const std::vector<int32_t>& heights, const std::vector<unsigned char>& second, int64_t N, int num_cu, int D,
+                    bool narrow) {
+  const int IS_WAVES = narrow ? IS1_WAVES : dsph::IS_WAVES;  // workers per workgroup
+  if (narrow) num_cu *= IS1_WG_PER_CU;
   static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
   int best = 1;
   int64_t best_span = -1;
@@ -83,7 +90,9 @@ int istrip_segments(const std::vector<int32_t>& heights, const std::vector<unsig
 
 // one launch per 32-column block of the (at most 64-column) block the caller handles
 int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream) {
-  const int CH = s.Fin <= 8 ? 4 : 8;
+  const bool narrow = istrip_narrow(s.Fin_w);
+  const int CH = narrow ? 1 : (s.Fin <= 8 ? 4 : 8);
+  const int waves = narrow ? IS1_WAVES : IS_WAVES, ncu = narrow ? IS1_WG_PER_CU * s.num_cu : s.num_cu;
   void (*kern)(IStripArgs) = nullptr;
   switch (s.K) {
     case 2: kern = istrip_kernel_k2(CH, s.precision); break;
@@ -95,12 +104,12 @@ int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream) {
   const size_t wb = istrip_wimg_bytes(s.K, s.precision);
   const int64_t items = (int64_t)s.npairs * 2 * s.nseg * s.N;
   // eight workers per workgroup, one workgroup per CU; fewer when there are fewer items
-  const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(s.num_cu, ((items + IS_WAVES - 1) / IS_WAVES + 7) / 8 * 8));
+  const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(ncu, ((items + waves - 1) / waves + 7) / 8 * 8));
   for (int32_t cb = 0; cb < s.Fout; cb += 32) {
     unsigned char* img = s.wimg + (size_t)(cb / 32) * wb;
     const int32_t fo = std::min<int32_t>(32, s.Fout - cb);
     if (s.prep_weights) {
-      hipLaunchKernelGGL(istrip_wprep_kernel, dim3(s.K), dim3(256), 0, stream, s.w + cb, img, (int)s.Fin_w, (int)fo, (int)s.K, CH,
+      hipLaunchKernelGGL(istrip_wprep_kernel, dim3(narrow ? 1 : s.K), dim3(256), 0, stream, s.w + cb, img, (int)s.Fin_w, (int)fo, (int)s.K, CH,
                          (int)s.precision, (int)s.ld);
       DSPH_HIP(hipGetLastError());
     }
@@ -122,7 +131,7 @@ int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream) {
     a.act = s.act;
     a.nseg = s.nseg;
     a.cheb = s.cheb ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(IS_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(narrow ? IS1_THREADS : IS_THREADS), 0, stream, a);
     DSPH_HIP(hipGetLastError());
   }
   return DSPH_OK;

@@ -378,4 +378,234 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
   }
 }
 
+// ---- one or two input channels: the levels go into the MFMA's inner index ---------------------------------------------------
+// The first layer of every reference model has ONE input channel (tests/test_healpy_networks.py:96; BASELINE configs[0]), and
+// zero-padded to the four-channel form above it spends three quarters of its recurrence and four of its five contractions on
+// zeros.  Here a lane is (pixel column, channel g = lane >> 5) with ONE value per plane row, and the contraction's inner index
+// carries the LEVELS: slot j of half g <- T_j[r] of channel g, so  y[r] = sum_k T_k[r] W_k  is one MFMA group per row instead
+// of one per level.  That needs T_0[r] .. T_{K-1}[r] at the same time: level k keeps its last max(3, K - k) rows (one register
+// each; shifted, not rotated -- no phase unrolling), T_k[r] made in step r + k and used in step r + K - 1.  One accumulator
+// row, 16 registers.  With so little plane state the rows of L~ live in registers too (K rows of nine values, shifted like
+// the planes; each half of the wave fetches four of a pixel's eight directions and v_permlane32_swap hands both halves both
+// quads), and so does the ONE weight image: the LDS holds the y block only, which a step fills and the NEXT step turns and
+// stores (no LDS round trip inside a step).  Strips, segments and item dealing are the kernel above's.  Two steps are in
+// flight on the load side (rows ytop + 1 and ytop + 2), two phases unrolled for that.  Workgroups of four waves, three per
+// CU (140 registers).
+constexpr int IS1_WAVES = 4;
+constexpr int IS1_THREADS = 64 * IS1_WAVES;
+constexpr int IS1_WG_PER_CU = 3;  // workgroups of four waves per CU: three waves per SIMD at up to 168 registers
+
+template <int K, int PREC>
+__global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs a) {
+  constexpr int D = K - 1;
+  constexpr int NP = K - 1;            // planes with rows kept: T_0 .. T_{K-2}
+  constexpr int WAVEB = IS_YSTB;       // LDS per wave: the y block (the rows of L~ live in registers here)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[IS1_WAVES * WAVEB + 128];
+  float* const sBias = reinterpret_cast<float*>(smem + IS1_WAVES * WAVEB);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 31, g = lane >> 5;
+  unsigned char* const yst = smem + wave * WAVEB;
+
+  // the ONE weight image stays in registers: this lane's A-operand fragments (12 registers; K under the exact arithmetic)
+  sp_bf16x8 wf[3];
+  float wx[K];
+  if (PREC == DSPH_PREC_FP32) {
+#pragma unroll
+    for (int s_ = 0; s_ < K; ++s_) wx[s_] = *reinterpret_cast<const float*>(a.wimg + s_ * 256 + lane * 4);
+  } else {
+#pragma unroll
+    for (int t_ = 0; t_ < is_terms(PREC); ++t_) wf[t_] = *reinterpret_cast<const sp_bf16x8*>(a.wimg + t_ * 1024 + lane * 16);
+  }
+  if (tid < 32) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
+  __syncthreads();
+
+  const int G_ = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+  const int nslots = (G_ + 7 - xcd) / 8;
+  const int64_t n_items = (int64_t)a.npairs * 2 * a.nseg * a.N;
+  const int64_t q_begin = n_items * xcd / 8, q_end = n_items * (xcd + 1) / 8;
+  const unsigned xrowb = (unsigned)a.Fin * 4u, yrowb = (unsigned)a.ld * 4u;
+  const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
+  const bool cheb = __builtin_amdgcn_readfirstlane(a.cheb) != 0;
+
+  for (int64_t q = q_begin + slot0 * IS1_WAVES + wave; q < q_end; q += (int64_t)nslots * IS1_WAVES) {
+    const int n = (int)(q % a.N);
+    const int sg = (int)((q / a.N) % a.nseg);
+    const int e = (int)((q / ((int64_t)a.N * a.nseg)) & 1);
+    const int p = (int)(q / (2 * (int64_t)a.N * a.nseg));
+    StripPair pr = a.pairs[p];
+    {
+      const int H = pr.y1 - pr.y0, ya = pr.y0 + (int)((int64_t)H * sg / a.nseg), yb = pr.y0 + (int)((int64_t)H * (sg + 1) / a.nseg);
+      pr.y0 = ya;
+      pr.y1 = yb;
+      if (yb <= ya) continue;
+    }
+    const int x0 = e ? pr.x0[1] : pr.x0[0], wuse = e ? pr.w[1] : pr.w[0], xs = e ? pr.xs[1] : pr.xs[0];
+    if (wuse <= 0) continue;
+    const unsigned sX = st_spread((unsigned)min(max(xs + px, pr.xlo), pr.xhi));
+    const unsigned sXs = st_spread((unsigned)(xs + (lane >> 3)));
+    const int pfirst = x0 - xs, plast = x0 - xs + wuse;
+    // (x arrives zero-padded to four channels: channel g of a one-channel layer reads the padding)
+    const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)n * a.x_rows * xrowb + (unsigned)g * 4u;
+    char* __restrict__ ymap = reinterpret_cast<char*>(a.y) + (size_t)n * a.y_rows * yrowb;
+    auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
+      return st_spread((unsigned)min(max(yrow, pr.ylo), pr.yhi)) << 1;
+    };
+
+    // R[k][d]: row (newest - d) of T_k; level k keeps max(3, K - k) rows
+    float R[NP][K < 3 ? 3 : K];
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+      for (int d = 0; d < (K < 3 ? 3 : K); ++d) R[k][d] = 0.f;
+
+    float xin[2];
+    sp_f32x4 cv[2];
+    float cd[2];
+    auto fetch = [&](auto b_c, int yrow) __attribute__((always_inline)) {
+      constexpr int B = decltype(b_c)::value;
+      const unsigned rid = sX | spread_y(yrow);
+      xin[B] = *reinterpret_cast<const float*>(xmap + (size_t)rid * xrowb);
+      cv[B] = *reinterpret_cast<const sp_f32x4*>(reinterpret_cast<const char*>(a.gvals8) + (size_t)rid * 32u + (unsigned)g * 16u);
+      cd[B] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.gdiag) + (size_t)rid * 4u);
+    };
+    // CF[j]: the nine values of L~ of this lane's pixel in row ytop - j (level k uses CF[k]); shifted like the planes' rows
+    SpCoef CF[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      CF[j].a = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+      CF[j].b = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+      CF[j].d = 0.f;
+    }
+
+    const int ybase = pr.y0 - D;
+    const int T2 = ((pr.y1 - pr.y0) + 2 * D + 2) / 2;  // steps, in twos: output row yr is made in step yr - y0 + 2 D, stored in the next
+    fetch(std::integral_constant<int, 0>{}, ybase);
+    fetch(std::integral_constant<int, 1>{}, ybase + 1);
+    auto step = [&](auto ph_c, int t) __attribute__((always_inline)) {
+      constexpr int PH = decltype(ph_c)::value;  // t mod 2: which fetch buffer holds this step's rows
+      const int ytop = ybase + t;
+      // every plane's rows age by one; this step's rows land; the rows of step t + 2 go out
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        constexpr int dummy = 0; (void)dummy;
+        const int dep = (K - k) < 3 ? 3 : (K - k);
+#pragma unroll
+        for (int d = (K < 3 ? 3 : K) - 1; d >= 1; --d)
+          if (d < dep) R[k][d] = R[k][d - 1];
+      }
+      R[0][0] = xin[PH];
+      // (the rows are read through DPP below, by instructions the compiler's hazard recogniser cannot see: two wait states
+      // behind the moves above)
+#pragma unroll
+      for (int k = 0; k < NP; ++k) asm volatile("s_nop 1" : "+v"(R[k][0]), "+v"(R[k][1]), "+v"(R[k][2]));
+#pragma unroll
+      for (int j = K - 1; j >= 1; --j) CF[j] = CF[j - 1];
+      // the row of L~ that arrived: half g of the wave fetched directions 4 g .. 4 g + 3 of its pixel; v_permlane32_swap gives both
+      // halves both quads (the lower half's register to every lane, and the upper half's)
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        // (as asm: the compiler folded the four builtin calls of this loop into one; the no-ops are the wait states a VALU result
+        // needs before the swap reads it and the swap's results before a VALU reads them)
+        float lo = cv[PH][e4], hi = cv[PH][e4];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+        CF[0].a[e4] = lo;
+        CF[0].b[e4] = hi;
+      }
+      CF[0].d = cd[PH];
+      fetch(ph_c, ytop + 2);
+      __builtin_amdgcn_wave_barrier();  // (the LDS executes a wave's instructions in order: the previous step's block is complete)
+      // the y row the PREVIOUS step left in the block
+      auto run_base = [](unsigned run) -> unsigned { return run * 256u; };
+      const int och = 4 * (lane & 7);
+      sp_f32x4 yo4[4];
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const unsigned pk = 8u * k4 + ((unsigned)lane >> 3), run = pk >> 1;
+        yo4[k4] = *reinterpret_cast<const sp_f32x4*>(yst + run_base(run) + (pk & 1u) * 128u + ((((unsigned)lane & 7u)) ^ (run & 7u)) * 16u);
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int yr = ytop - D - 1;  // finished by the previous step
+        if (yr >= pr.y0 && yr < pr.y1) {  // (wave-uniform)
+          const unsigned sY = st_spread((unsigned)yr) << 1;
+          const sp_f32x4 bv = *reinterpret_cast<const sp_f32x4*>(sBias + och);
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const int pk = 8 * k4 + (lane >> 3);
+            const unsigned rid = (((sXs | 0xAAAAAAAAu) + st_spread(8u * k4)) & 0x55555555u) | sY;
+            float* dst = reinterpret_cast<float*>(ymap + (size_t)rid * yrowb) + och;
+            sp_f32x4 o;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) o[e4] = fmaxf(yo4[k4][e4] + bv[e4], floor_v);
+            if (pk >= pfirst && pk < plast && och < a.Fout) *reinterpret_cast<sp_f32x4*>(dst) = o;
+          }
+        }
+      }
+
+      // levels 1 .. K-1: T_k[ytop - k] from T_{k-1}'s three newest rows (ytop-k+1, ytop-k, ytop-k-1) and T_{k-2}[ytop - k]
+      float row[8];  // the contraction's operand: slot j <- T_j[ytop - (K-1)]
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row[j] = 0.f;
+#pragma unroll
+      for (int k = 1; k <= K - 1; ++k) {
+        float acc[1] = {0.f};
+        const float s_old[1] = {R[k - 1][2]}, s_mid[1] = {R[k - 1][1]}, s_new[1] = {R[k - 1][0]};
+        is_row<1>(acc, s_old, CF[k].b[3], CF[k].b[2], CF[k].b[1]);  // y-1: directions 7, 6, 5
+        is_row<1>(acc, s_mid, CF[k].a[0], CF[k].d, CF[k].b[0]);     // y  : 0, diagonal, 4
+        is_row<1>(acc, s_new, CF[k].a[1], CF[k].a[2], CF[k].a[3]);  // y+1: 1, 2, 3
+        float v = acc[0];
+        if (k >= 2 && cheb) v = fmaf(2.f, v, -R[k - 2][2]);
+        if (k <= K - 2) {
+          R[k][0] = v;
+          asm volatile("s_nop 1" : "+v"(R[k][0]));  // (read through DPP by the next level)
+        } else {
+          row[K - 1] = v;
+          asm volatile("s_nop 1" : "+v"(row[K - 1]));  // (an MFMA operand as it is under the exact arithmetic)
+        }
+      }
+#pragma unroll
+      for (int j = 0; j <= K - 2; ++j) row[j] = R[j][K - 1 - j];
+
+      sp_f32x16 Yd;
+      if (PREC == DSPH_PREC_FP32) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Yd[c] = 0.f;
+#pragma unroll
+        for (int s = 0; s < K; ++s) Yd = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[s], row[s], Yd, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Yd[c] = 0.f;
+        const IsFrag f = is_split<8, PREC>(row);
+        if (PREC == DSPH_PREC_BF16X3) {
+          Yd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], f.t[1], Yd, 0, 0, 0);  // small terms first (is_contract)
+          Yd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], f.t[0], Yd, 0, 0, 0);
+          Yd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], f.t[0], Yd, 0, 0, 0);
+        } else {
+          Yd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], f.t[2], Yd, 0, 0, 0);
+          Yd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2], f.t[0], Yd, 0, 0, 0);
+          Yd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], f.t[1], Yd, 0, 0, 0);
+          Yd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], f.t[1], Yd, 0, 0, 0);
+          Yd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], f.t[0], Yd, 0, 0, 0);
+          Yd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], f.t[0], Yd, 0, 0, 0);
+        }
+      }
+      // y of row ytop - (K-1) into the staging block; the NEXT step turns it so that eight lanes store 128 contiguous bytes
+      {
+        const unsigned run = (unsigned)px >> 1;
+        unsigned char* wp = yst + run_base(run) + ((unsigned)px & 1u) * 128u;
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq)
+          *reinterpret_cast<sp_f32x4*>(wp + (((unsigned)(2 * tq + g)) ^ (run & 7u)) * 16u) =
+              sp_f32x4{Yd[4 * tq], Yd[4 * tq + 1], Yd[4 * tq + 2], Yd[4 * tq + 3]};
+      }
+    };
+    for (int t2 = 0; t2 < T2; ++t2) {
+      step(std::integral_constant<int, 0>{}, 2 * t2);
+      step(std::integral_constant<int, 1>{}, 2 * t2 + 1);
+    }
+  }
+}
+
 }  // namespace dsph

@@ -498,6 +498,46 @@ def test_input_side_strip_kernel_whole_map(nside, N, Fin, Fout, K, basis, act, p
     assert rel_err(y.cpu().numpy(), y3.cpu().numpy()) < 2 * tol
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("nside,N,Fin,Fout,K,basis,act", [
+    (128, 2, 1, 32, 5, "chebyshev", "relu"),    # a first layer: one channel, five levels in the inner index
+    (128, 3, 2, 16, 5, "chebyshev", None),      # two channels: one per lane half
+    (128, 1, 1, 64, 4, "chebyshev", "elu"),     # K = 4, two 32-column blocks, deferred activation
+    (128, 2, 2, 40, 3, "monomial", "relu"),     # K = 3, the other basis, a ragged second block
+    (128, 5, 1, 8, 2, "chebyshev", None),       # K = 2 (T_0 keeps three rows all the same), an odd batch
+    (256, 2, 1, 96, 5, "monomial", "tanh"),     # larger map, three blocks over two 64-column launches
+])
+def test_level_packed_strip_kernel_for_one_and_two_channels(nside, N, Fin, Fout, K, basis, act, prec):
+    """cheb_istrip1_kernel (layers with one or two input channels: the Chebyshev levels in the MFMA's inner index, one
+    contraction per row) against the float64 oracle, deterministic, and equal to the tile kernels alone to rounding."""
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    assert plan.strip_tiles(Fin, Fout, K, N=N) > 0
+    rng = np.random.default_rng(7 * nside + Fin + Fout + K)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    fwd = orc.chebyshev_forward if basis == "chebyshev" else orc.monomial_forward
+    ref = fwd(_csr(cols, vals), x, W, K, bias=b, activation=act)
+    P = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}[prec]
+    B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
+    A = {None: _native.ACT_NONE, "relu": _native.ACT_RELU, "elu": _native.ACT_ELU, "tanh": _native.ACT_TANH}[act]
+    y, ws = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
+    err = rel_err(y.cpu().numpy(), ref)
+    tol = (2e-6 if prec != "bf16x3" else 2 * TOL) * (5 if act == "tanh" else 1)
+    print(f"istrip1 nside={nside} {Fin}->{Fout} K={K} {basis} {act} {prec}: err {err:.2e}")
+    assert err < tol
+    y2, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B, workspace=ws)
+    assert torch.equal(y, y2)
+    plain = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_STRIPS: _native.STRIPS_NEVER})
+    y3, _ = _native.cheb_forward(plain, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
+    assert rel_err(y.cpu().numpy(), y3.cpu().numpy()) < 2 * tol
+    # a map's result does not depend on the batch it came in (other row segments: same sums)
+    y1, _ = _native.cheb_forward(plan, _dev(x[:1]), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
+    assert torch.equal(y1, y[:1])
+
+
 def test_input_side_strip_kernel_partial_sky_and_batches():
     """A cap of the sphere at nside 256 (ragged rectangles), 16 -> 32, at batch sizes that change the row-segment count the
     kernel is launched with (1, 2, 5, 16 maps): every batch equals the oracle, and a map's result does not depend on the batch
