@@ -357,6 +357,7 @@ static int64_t strip_makespan(const std::vector<int32_t>& steps, int64_t N, int 
   return worst;
 }
 
+constexpr int SMALL_MAP_TILES = 512;  // structured tiles up to which a plan without strips runs them in ONE launch (class-R tiles with tables)
 // Strip kernel: which class-R tiles it takes, and in what pieces.  The interior class-R tiles are covered by rectangles (in
 // the virtual Morton plane of the tile indices: tile t sits at (compress(t), compress(t >> 1))) of 3 to 5 tile columns and at
 // least 4 tile rows; a rectangle is cut into 32-column strips with 24 output columns each, two strips per workgroup item,
@@ -736,6 +737,37 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
   };
   if (lcols.empty()) { lcols.push_back(0); lvals.push_back(0.f); }
+  // Small maps (BASELINE configs[0]: nside 64, 192 tiles -- 48 class R, 120 class T, 24 class G) are bound by launches, not by
+  // work: every structured tile fits the device at once, and two launches (class R, then class T) take twice as long as one.
+  // Where the strips take nothing anyway, the class-R tiles get tables too and join the class-T launch.
+  if (try_tables && D <= SP_DMAX && !(r_interior.empty() && r_boundary.empty()) &&
+      r_interior.size() + r_boundary.size() + t_interior.size() + t_boundary.size() <= (size_t)SMALL_MAP_TILES) {
+    int64_t taken = 0;
+    if (plan->opt.strips != 2) {
+      std::vector<StripPair> p0, ip0;
+      std::vector<int32_t> rest0, steps0;
+      build_strips(r_interior, D, fp->num_cu, plan->opt, p0, rest0, &taken, steps0, ip0);
+    }
+    if (taken == 0) {
+      std::vector<int32_t> keep_i, keep_b;
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int32_t t : pass == 0 ? r_interior : r_boundary) {
+          bool inner = false;
+          if (embed_tile(plan, cols, vals, W, t, D, out_rows, e_row.data(), e_val.data(), &inner, h_key, h_slot)) {
+            (pass == 0 ? t_interior : t_boundary).push_back(t);
+            std::vector<int32_t>& rw = pass == 0 ? trow_i : trow_b;
+            std::vector<float>& vl = pass == 0 ? tval_i : tval_b;
+            rw.insert(rw.end(), e_row.begin(), e_row.end());
+            vl.insert(vl.end(), e_val.begin(), e_val.end());
+          } else {
+            (pass == 0 ? keep_i : keep_b).push_back(t);
+          }
+        }
+      }
+      r_interior.swap(keep_i);
+      r_boundary.swap(keep_b);
+    }
+  }
   std::vector<int32_t> all_tiles;  // every tile, whatever its class: interior ones first
   all_tiles.insert(all_tiles.end(), r_interior.begin(), r_interior.end());
   all_tiles.insert(all_tiles.end(), t_interior.begin(), t_interior.end());
