@@ -35,7 +35,7 @@ namespace dsph {
 constexpr int IS_THREADS = 512;
 constexpr int IS_WAVES = 8;
 constexpr int IS_CRING = 6;                    // rows of L~ held per wave: ytop - 4 .. ytop + 1
-constexpr int IS_CROWB = 32 * 32 + 32 * 4;     // one ring row: [px][8 directions] + [px] diagonal
+constexpr int IS_CROWB = 32 * 32 + 32 * 4;     // one ring row: [directions 0-3][px] | [directions 4-7][px] | [px] diagonal
 constexpr int IS_YSTB = 4096;                  // y staging block: 32 pixels x 32 channels
 constexpr int IS_WAVEB = IS_CRING * IS_CROWB + IS_YSTB;
 
@@ -244,14 +244,14 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
     };
     auto cstore = [&](int slot) __attribute__((always_inline)) {
       unsigned char* pr_ = cring + (unsigned)slot * IS_CROWB;
-      *reinterpret_cast<sp_f32x4*>(pr_ + (unsigned)px * 32u + (unsigned)g * 16u) = cv;
+      *reinterpret_cast<sp_f32x4*>(pr_ + (unsigned)g * 512u + (unsigned)px * 16u) = cv;  // (16-byte stride: no bank conflicts)
       if (g == 0) *reinterpret_cast<float*>(pr_ + 1024 + (unsigned)px * 4u) = cd;
     };
     auto c9 = [&](int slot) __attribute__((always_inline)) -> SpCoef {
       const unsigned char* pr_ = cring + (unsigned)slot * IS_CROWB;
       SpCoef c;
-      c.a = *reinterpret_cast<const sp_f32x4*>(pr_ + (unsigned)px * 32u);
-      c.b = *reinterpret_cast<const sp_f32x4*>(pr_ + (unsigned)px * 32u + 16u);
+      c.a = *reinterpret_cast<const sp_f32x4*>(pr_ + (unsigned)px * 16u);
+      c.b = *reinterpret_cast<const sp_f32x4*>(pr_ + 512u + (unsigned)px * 16u);
       c.d = *reinterpret_cast<const float*>(pr_ + 1024 + (unsigned)px * 4u);
       return c;
     };
