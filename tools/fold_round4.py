@@ -14,7 +14,7 @@ SRC = os.path.join(ROOT, "gpurun_out", "measure4")
 PRO = os.path.join(ROOT, "profiles")
 KEYS = {"c3": "c3:bf16x3:fused:1", "c2": "c2:bf16x3:fused:1", "c1": "c1:bf16x6:fused:1", "k10": "k10:bf16x6:fused:1",
         "in1": "in1:bf16x6:fused:1"}
-FORWARD = ("cheb_strip5_kernel", "cheb_strip_kernel", "cheb_istrip_kernel", "cheb_struct_kernel", "cheb_fused_kernel")
+FORWARD = ("cheb_strip5_kernel", "cheb_strip_kernel", "cheb_istrip_kernel", "cheb_istrip1_kernel", "cheb_struct_kernel", "cheb_fused_kernel", "fused_pad_kernel")
 
 for name in os.listdir(SRC):
     if name.startswith("bench_") and name.endswith(".json") and os.path.getsize(os.path.join(SRC, name)) > 10:

@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/measure4; mkdir -p $O
 python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_c3.json
-for c in c1 c2 k10 in1 knn8 knn20 qs qs1; do python3 bench.py --config $c --steps 50 --warmup 10 --cpu-budget 0 2>/dev/null | tail -1 > $O/bench_$c.json; done
+for c in c1 c2 k10 in1 knn8 knn20 qs qs1; do python3 bench.py --config $c --steps 100 --warmup 20 --cpu-budget 0 2>/dev/null | tail -1 > $O/bench_$c.json; done
 for c in knn20 qs qs1; do python3 bench.py --config $c --tstep off --steps 10 --warmup 3 --cpu-budget 0 --quick 2>/dev/null | tail -1 > $O/bench_${c}_gather.json; done
 python3 bench.py --config knn8 --algo unfused --steps 20 --warmup 5 --cpu-budget 0 --quick 2>/dev/null | tail -1 > $O/bench_knn8_unfused.json
 for c in c4 c5; do python3 bench.py --config $c --steps 10 --warmup 3 --cpu-budget 0 2>/dev/null | tail -1 > $O/bench_$c.json; done
