@@ -878,8 +878,9 @@ static bool supported_impl(const dsph_plan* plan, int32_t Fin, int32_t Fout, int
   if (ft.n_part == 0) return true;  // every tile is class R
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   if (pr == 0) return false;
-  const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wfrag_bytes(Fin, std::min(Fout, 64), K) + FUSED_BIAS_BYTES;
-  return lds <= (size_t)LDS_BYTES;
+  // (the weight fragments need not fit beside the planes: the forward then reads them from global memory, cheb_fused_kernel's
+  // WG variant; the planes and weight-gradient modes hold no weights)
+  return (size_t)2 * pr * FUSED_CH * 4 + FUSED_BIAS_BYTES <= (size_t)LDS_BYTES;
 }
 
 // The forward takes any Fin >= 1: channel counts that are not a multiple of four are zero-padded into the workspace first

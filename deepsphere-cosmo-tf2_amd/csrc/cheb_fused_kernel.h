@@ -283,7 +283,10 @@ __device__ __forceinline__ void wgrad_plane_bf16(unsigned char* __restrict__ til
 // MODE 2 ("weight gradient"): the recurrence, and every plane contracted over the tile's pixels against dy
 // (wgrad_batch); the partial sums stay in registers over all tiles of the workgroup and are written once,
 // to a.slabs, for a fixed-order second stage.  No plane ever leaves the LDS.
-template <int PR, int WT, int RP, int NB, int PREC, int MODE = 0>
+// WG: the weight fragments of all slices do not fit the LDS beside the planes (more than 64 input channels at K = 5): every
+// level's fragments are then read from the packed image in global memory (L2-resident, at most a few hundred KB) as they are
+// needed, instead of from an LDS copy made once per workgroup.
+template <int PR, int WT, int RP, int NB, int PREC, int MODE = 0, bool WG = false>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs a) {
   constexpr int PLANE_BYTES = PR * FUSED_CH * 4;
   constexpr int NS = (PR * 4 + FUSED_THREADS - 1) / FUSED_THREADS;  // staging float4 per lane
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     for (int i = tid * 16; i < 2 * PLANE_BYTES; i += FUSED_THREADS * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
   }
   if (MODE == 0 && tid < FUSED_BIAS_BYTES / 4) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
-  if (MODE == 0) {
+  if (MODE == 0 && !WG) {
     for (int i = tid * 16; i < a.wfrag_bytes; i += FUSED_THREADS * 16)
       *reinterpret_cast<uint4*>(sW + i) = *reinterpret_cast<const uint4*>(a.wfrag + i);
   }
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
           for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
       }
       DSPH_STAMP(5);
-      const unsigned char* __restrict__ wblk = sW + (size_t)c * NB * 2048;
+      const unsigned char* __restrict__ wblk = (WG ? a.wfrag : sW) + (size_t)c * NB * 2048;
       WFrag<NB, PREC> wf;
       load_wfrag<NB, PREC>(wblk, lane, wf);
       __builtin_amdgcn_sched_barrier(0);
@@ -671,8 +674,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
 
 template <int PR, int WT, int RPL, int NB, int PREC>
 static int launch_variant(const FusedArgs& args, int grid, size_t lds, hipStream_t stream) {
-  auto kern = cheb_fused_kernel<PR, WT, RPL, NB, PREC>;
-  (void)lds;  // the kernel declares the whole LDS statically
+  // (the kernel declares the whole LDS statically; what does not fit it are the weight fragments of many slices: WG)
+  auto kern = lds + FUSED_BIAS_BYTES > (size_t)LDS_BYTES ? cheb_fused_kernel<PR, WT, RPL, NB, PREC, 0, true>
+                                                         : cheb_fused_kernel<PR, WT, RPL, NB, PREC, 0, false>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), 0, stream, args);
   DSPH_HIP(hipGetLastError());
   return DSPH_OK;

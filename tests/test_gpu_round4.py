@@ -561,12 +561,14 @@ def test_input_side_strip_kernel_partial_sky_and_batches():
         assert torch.equal(yN, y16[:N]), f"batch {N}"
 
 
-def test_input_side_strips_in_a_two_part_launch():
+@pytest.mark.parametrize("Fin", [16, 1])
+def test_input_side_strips_in_a_two_part_launch(Fin):
     """A rank's plan at nside 128 (two ranks): the interior part runs the strips, the boundary part the tile kernels; the two
-    parts together equal the single launch bit for bit, with a deferred activation."""
+    parts together equal the single launch bit for bit, with a deferred activation.  Fin = 1: a sharded first layer, the
+    level-packed kernel."""
     from deepsphere import sharding
 
-    nside, K, Fin, Fout, N = 128, 5, 16, 32, 2
+    nside, K, Fout, N = 128, 5, 32, 2
     cols, vals = _grid_ell(nside)
     lay = sharding.ShardLayout(cols, vals, K, 1, 2)
     plan = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols, device=0, levels=lay.levels)
@@ -575,7 +577,7 @@ def test_input_side_strips_in_a_two_part_launch():
     x = _dev(rng.standard_normal((N, lay.n_cols, Fin)).astype(np.float32))
     W = _dev((rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32))
     b = _dev(rng.standard_normal(Fout).astype(np.float32))
-    kw = dict(act=_native.ACT_ELU, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    kw = dict(act=_native.ACT_ELU, precision=_native.PREC_BF16X3 if Fin >= 16 else _native.PREC_BF16X6, algo=_native.ALGO_FUSED)
     whole, ws = _native.cheb_forward(plan, x, W, b, K, **kw)
     out = torch.full_like(whole, float("nan"))
     _native.cheb_forward(plan, x, W, b, K, part=_native.PART_INTERIOR, out=out, workspace=ws, **kw)
@@ -700,3 +702,40 @@ def test_quick_start_model_values():
     err = rel_err(y, cur)
     print(f"quick-start model vs oracle composition: rel err {err:.2e}")
     assert err < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Layers with more than 64 input channels: fused too (the BFS-tile kernel reads its weight fragments from global memory
+# when those of all slices do not fit the LDS beside the planes)
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-6), ("bf16x6", 2e-6), ("bf16x3", TOL)])
+@pytest.mark.parametrize("graph,nside,N,Fin,Fout,K", [
+    ("grid", 64, 2, 128, 128, 5),   # a wide layer of the networks: structured tiles + class-G tiles, two 64-column blocks
+    ("grid", 32, 1, 96, 40, 5),     # six slices, a ragged block
+    ("knn", 32, 2, 128, 64, 4),     # every tile on the BFS-tile kernel
+    ("grid", 32, 1, 256, 32, 3),    # sixteen slices
+])
+def test_wide_input_layers_run_fused(graph, nside, N, Fin, Fout, K, prec, tol):
+    import bench
+
+    if graph == "grid":
+        cols, vals = _grid_ell(nside)
+    else:
+        cols, vals, _ = bench.build_laplacian_knn(nside, torch.device("cuda", 0), 8)
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    assert plan.fused_ok(Fin, Fout, K), "more than 64 input channels no longer fall back to the unfused path"
+    rng = np.random.default_rng(Fin + Fout)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    ref = orc.chebyshev_forward(_csr(cols, vals), x, W, K, bias=b, activation="relu")
+    P = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}[prec]
+    y, ws = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=P, algo=_native.ALGO_FUSED)
+    err = rel_err(y.cpu().numpy(), ref)
+    print(f"wide {graph} nside={nside} {Fin}->{Fout} K={K} {prec}: err {err:.2e}, tiles {plan.tile_counts(K)}")
+    assert err < tol
+    yu, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=P, algo=_native.ALGO_UNFUSED)
+    assert rel_err(y.cpu().numpy(), yu.cpu().numpy()) < 2 * tol
