@@ -910,6 +910,17 @@ bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K
   return Fin >= 1 && supported_impl(plan, pad4(Fin), Fout, K, false);
 }
 
+// ... and with the BFS-tile kernel's weight fragments resident in the LDS (its fast variant: what "supported" meant before the
+// WG variant existed; the K > 5 routing of dsphere_api.hip prefers the chain of passes to the WG variant)
+bool fused_weights_resident(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K) {
+  if (!fused_supported(plan, Fin, Fout, K)) return false;
+  const int32_t Fp = pad4(Fin);
+  const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fp, false));
+  if (ft.n_part == 0) return true;
+  const int pr = plane_rows_for(ft.rmax, ft.emax);
+  return (size_t)2 * pr * FUSED_CH * 4 + wfrag_bytes(Fp, std::min(Fout, 64), K) + FUSED_BIAS_BYTES <= (size_t)LDS_BYTES;
+}
+
 int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags) {
   if (plan->fused && plan->fused->wide) {  // the tiled step's tables, so that the first forward does not build them
     TStepTables tb;

@@ -224,7 +224,7 @@ int dsph_plan_strip_tiles(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fo
 // alternative is the unfused path's K planes through HBM) and for 6 <= K <= 9 where the measured rule says so (use_split).
 static bool use_split(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo, int32_t part) {
   if (K <= 5 || algo == DSPH_ALGO_UNFUSED || part != DSPH_PART_ALL || p->opt.split_order == 2) return false;
-  if (p->opt.split_order == 0 && K - 1 <= fused_dmax() && fused_supported(p, Fin, Fout, K)) return false;
+  if (p->opt.split_order == 0 && K - 1 <= fused_dmax() && fused_weights_resident(p, Fin, Fout, K)) return false;
   return split_applicable(p, Fin, Fout, K);
 }
 

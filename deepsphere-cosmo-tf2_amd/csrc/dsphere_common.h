@@ -95,6 +95,7 @@ void fused_plan_invalidate(FusedPlan* fp);
 bool fused_host_released(FusedPlan* fp);
 int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
 bool fused_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
+bool fused_weights_resident(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
 int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision);
 int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_t cap);

@@ -21,7 +21,9 @@ for nside, K, Fin, Fout, N in shapes:
     if nside not in cache:
         cache[nside] = bench.build_laplacian(nside, dev)
     cols, vals, lmax = cache[nside]
-    layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, lmax=lmax, Fout=Fout, device=dev, precision="bf16x3")
+    from deepsphere import _native
+    layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, lmax=lmax, Fout=Fout, device=dev, precision=os.environ.get("BS_PREC", "bf16x3"),
+                                                   plan_options={_native.OPT_STRIPS: int(os.environ.get("BS_STRIPS", "0"))})
     x = torch.randn((N, cols.shape[0], Fin), device=dev)
     with torch.no_grad():
         for _ in range(3):
