@@ -17,6 +17,11 @@ head -1 $f > $O/kernel_stats_c3.csv; grep -E "dsph" $f | cut -c1-300 >> $O/kerne
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench2 -- python3 bench.py --config c2 --steps 50 --warmup 5 --cpu-budget 0 --quick > $O/bench_c2_under_rocprof.log 2>&1
 f=$(find /tmp/prof_bench2 -name "*kernel_stats.csv" | head -1)
 head -1 $f > $O/kernel_stats_c2.csv; grep -E "dsph" $f | cut -c1-300 >> $O/kernel_stats_c2.csv
+for c in in1 knn20 qs1 c1; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$c -- python3 bench.py --config $c --steps 50 --warmup 5 --cpu-budget 0 --quick > $O/bench_${c}_under_rocprof.log 2>&1
+  f=$(find /tmp/prof_$c -name "*kernel_stats.csv" | head -1)
+  head -1 $f > $O/kernel_stats_$c.csv; grep -E "dsph" $f | cut -c1-300 >> $O/kernel_stats_$c.csv
+done
 tools/pmc3.sh r4_c3 c3 bf16x3 > $O/pmc_c3_bf16x3.txt 2>&1
 PMC_ONLY="2 3 4 6" tools/pmc3.sh r4_c2 c2 bf16x3 > $O/pmc_c2_bf16x3.txt 2>&1
 PMC_ONLY="2 3 4" tools/pmc3.sh r4_in1 in1 bf16x6 > $O/pmc_in1_bf16x6.txt 2>&1
