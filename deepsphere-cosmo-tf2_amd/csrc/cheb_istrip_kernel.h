@@ -428,6 +428,9 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
   const unsigned xrowb = (unsigned)a.Fin * 4u, yrowb = (unsigned)a.ld * 4u;
   const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
   const bool cheb = __builtin_amdgcn_readfirstlane(a.cheb) != 0;
+  // at most 16 output columns (a first layer: 1 -> 16): a y row is 64 bytes, FOUR lanes store it, and two store instructions with
+  // every lane at work cover the strip row -- instead of four with half of their lanes masked
+  const bool nout = __builtin_amdgcn_readfirstlane(a.Fout) <= 16;
 
   for (int64_t q = q_begin + slot0 * IS1_WAVES + wave; q < q_end; q += (int64_t)nslots * IS1_WAVES) {
     const int n = (int)(q % a.N);
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
     const int x0 = e ? pr.x0[1] : pr.x0[0], wuse = e ? pr.w[1] : pr.w[0], xs = e ? pr.xs[1] : pr.xs[0];
     if (wuse <= 0) continue;
     const unsigned sX = st_spread((unsigned)min(max(xs + px, pr.xlo), pr.xhi));
-    const unsigned sXs = st_spread((unsigned)(xs + (lane >> 3)));
+    const unsigned sXs = st_spread((unsigned)(xs + (nout ? lane >> 2 : lane >> 3)));
     const int pfirst = x0 - xs, plast = x0 - xs + wuse;
     // (x arrives zero-padded to four channels: channel g of a one-channel layer reads the padding)
     const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)n * a.x_rows * xrowb + (unsigned)g * 4u;
@@ -518,12 +521,15 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
       __builtin_amdgcn_wave_barrier();  // (the LDS executes a wave's instructions in order: the previous step's block is complete)
       // the y row the PREVIOUS step left in the block
       auto run_base = [](unsigned run) -> unsigned { return run * 256u; };
-      const int och = 4 * (lane & 7);
+      // (pixels per store instruction PPI = 8 with eight 16-byte chunks each, or 16 with four; wave-uniform)
+      const unsigned ppi = nout ? 16u : 8u, cpl = nout ? (unsigned)lane & 3u : (unsigned)lane & 7u, pl = nout ? (unsigned)lane >> 2 : (unsigned)lane >> 3;
+      const int och = 4 * (int)cpl;
       sp_f32x4 yo4[4];
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
-        const unsigned pk = 8u * k4 + ((unsigned)lane >> 3), run = pk >> 1;
-        yo4[k4] = *reinterpret_cast<const sp_f32x4*>(yst + run_base(run) + (pk & 1u) * 128u + ((((unsigned)lane & 7u)) ^ (run & 7u)) * 16u);
+        if (nout && k4 >= 2) break;
+        const unsigned pk = ppi * k4 + pl, run = pk >> 1;
+        yo4[k4] = *reinterpret_cast<const sp_f32x4*>(yst + run_base(run) + (pk & 1u) * 128u + ((cpl ^ (run & 7u))) * 16u);
       }
       __builtin_amdgcn_wave_barrier();
       {
@@ -533,8 +539,9 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
           const sp_f32x4 bv = *reinterpret_cast<const sp_f32x4*>(sBias + och);
 #pragma unroll
           for (int k4 = 0; k4 < 4; ++k4) {
-            const int pk = 8 * k4 + (lane >> 3);
-            const unsigned rid = (((sXs | 0xAAAAAAAAu) + st_spread(8u * k4)) & 0x55555555u) | sY;
+            if (nout && k4 >= 2) break;
+            const int pk = (int)(ppi * k4 + pl);
+            const unsigned rid = (((sXs | 0xAAAAAAAAu) + st_spread(ppi * k4)) & 0x55555555u) | sY;
             float* dst = reinterpret_cast<float*>(ymap + (size_t)rid * yrowb) + och;
             sp_f32x4 o;
 #pragma unroll
@@ -596,9 +603,11 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
         const unsigned run = (unsigned)px >> 1;
         unsigned char* wp = yst + run_base(run) + ((unsigned)px & 1u) * 128u;
 #pragma unroll
-        for (int tq = 0; tq < 4; ++tq)
+        for (int tq = 0; tq < 4; ++tq) {
+          if (nout && tq >= 2) break;  // (columns 16 .. 31 do not exist)
           *reinterpret_cast<sp_f32x4*>(wp + (((unsigned)(2 * tq + g)) ^ (run & 7u)) * 16u) =
               sp_f32x4{Yd[4 * tq], Yd[4 * tq + 1], Yd[4 * tq + 2], Yd[4 * tq + 3]};
+        }
       }
     };
     for (int t2 = 0; t2 < T2; ++t2) {
