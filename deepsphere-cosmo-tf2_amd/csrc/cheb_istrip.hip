@@ -10,8 +10,9 @@ namespace dsph {
 // (exact fp32).  Lane (m = lane & 31 -> column 32 nb + m, kg = lane >> 5), slot j <- channel CH kg + j (zero for j >= CH and
 // for channels the layer does not have); w is the layer's kernel [Fin_w * K, ld], row f K + k.
 // CH == 1 (cheb_istrip1_kernel): ONE image, slot j <- level j of channel kg.
+// pair (cheb_istrip1_kernel, two maps per wave): rows 0 .. 15 carry W in the slots of half 0, rows 16 .. 31 in those of half 1.
 __global__ __launch_bounds__(256) void istrip_wprep_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Fin_w,
-                                                           int Fout, int K, int CH, int prec, int ld) {
+                                                           int Fout, int K, int CH, int prec, int ld, int pair) {
   const int k = blockIdx.x;
   const int terms = is_terms(prec), tb = is_term_bytes(prec);
   unsigned char* base = out + (size_t)k * terms * tb;
@@ -19,7 +20,8 @@ __global__ __launch_bounds__(256) void istrip_wprep_kernel(const float* __restri
     const int l = e >> 3, j = e & 7;
     const int ch = CH * (l >> 5) + j, col = l & 31;
     float v;
-    if (CH == 1) v = (j < K && (l >> 5) < Fin_w && col < Fout) ? w[((int64_t)(l >> 5) * K + j) * ld + col] : 0.f;
+    if (CH == 1 && pair) v = (j < K && (l >> 5) == (col >> 4) && (col & 15) < Fout) ? w[(int64_t)j * ld + (col & 15)] : 0.f;
+    else if (CH == 1) v = (j < K && (l >> 5) < Fin_w && col < Fout) ? w[((int64_t)(l >> 5) * K + j) * ld + col] : 0.f;
     else v = (j < CH && ch < Fin_w && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
     if (prec == DSPH_PREC_FP32) {
       reinterpret_cast<float*>(base)[j * 64 + l] = v;  // step j, lane l
@@ -41,6 +43,8 @@ __global__ __launch_bounds__(256) void istrip_wprep_kernel(const float* __restri
 }
 
 bool istrip_narrow(int32_t Fin_w) { return Fin_w <= 2; }  // real input channels: the level-packed kernel's layers
+// ... and among them the ones that run two maps per wave: one input channel, at most 16 output columns (1 -> 16)
+bool istrip_pairs(int32_t Fin_w, int32_t Fout) { return Fin_w == 1 && Fout <= 16; }
 bool istrip_shape_ok(int32_t Fin, int32_t K) { return K >= 2 && K <= 5 && Fin >= 4 && Fin <= 16 && Fin % 4 == 0; }
 
 size_t istrip_wimg_bytes(int32_t K, int32_t precision) { return (size_t)K * is_terms(precision) * is_term_bytes(precision); }
@@ -102,7 +106,8 @@ int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream) {
     default: set_error("cheb_istrip: K = %d", s.K); return DSPH_E_UNSUPPORTED;
   }
   const size_t wb = istrip_wimg_bytes(s.K, s.precision);
-  const int64_t items = (int64_t)s.npairs * 2 * s.nseg * s.N;
+  const bool pair = narrow && istrip_pairs(s.Fin_w, s.Fout);
+  const int64_t items = (int64_t)s.npairs * 2 * s.nseg * (pair ? (s.N + 1) / 2 : s.N);
   // eight workers per workgroup, one workgroup per CU; fewer when there are fewer items
   const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(ncu, ((items + waves - 1) / waves + 7) / 8 * 8));
   for (int32_t cb = 0; cb < s.Fout; cb += 32) {
@@ -110,7 +115,7 @@ int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream) {
     const int32_t fo = std::min<int32_t>(32, s.Fout - cb);
     if (s.prep_weights) {
       hipLaunchKernelGGL(istrip_wprep_kernel, dim3(narrow ? 1 : s.K), dim3(256), 0, stream, s.w + cb, img, (int)s.Fin_w, (int)fo, (int)s.K, CH,
-                         (int)s.precision, (int)s.ld);
+                         (int)s.precision, (int)s.ld, pair ? 1 : 0);
       DSPH_HIP(hipGetLastError());
     }
     IStripArgs a;
@@ -131,6 +136,7 @@ int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream) {
     a.act = s.act;
     a.nseg = s.nseg;
     a.cheb = s.cheb ? 1 : 0;
+    a.pair = pair ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(narrow ? IS1_THREADS : IS_THREADS), 0, stream, a);
     DSPH_HIP(hipGetLastError());
   }

@@ -50,6 +50,7 @@ struct IStripArgs {
   int64_t x_rows, y_rows;
   int npairs, N, Fin, Fout, ld, act;  // Fout: columns of this block (<= 32)
   int nseg;                           // every strip is cut into nseg row segments (chosen per call: istrip_segments)
+  int pair;                           // cheb_istrip1_kernel: two maps per wave (one input channel, at most 16 output columns)
   int cheb;                           // T_k = 2 L~ T_{k-1} - T_{k-2} (1, Chebyshev) or L~ T_{k-1} (0, monomial), k >= 2
 };
 
@@ -423,20 +424,27 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
 
   const int G_ = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
   const int nslots = (G_ + 7 - xcd) / 8;
-  const int64_t n_items = (int64_t)a.npairs * 2 * a.nseg * a.N;
+  // Two maps per wave (a.pair: ONE input channel and at most 16 output columns, the first layer of a network): half g of the
+  // wave runs the recurrence of map 2 n + g -- its lanes would carry a channel that does not exist --, the rows of L~ fetched once
+  // serve both, and ONE MFMA group contracts both: rows 0 .. 15 of the weight image hold W in the inner slots of half 0, rows
+  // 16 .. 31 hold it in the slots of half 1, so accumulator rows 0 .. 15 are map 2 n's 16 columns and rows 16 .. 31 map 2 n + 1's.
+  // The y block then holds [map 2 n | map 2 n + 1] per pixel and the eight lanes of a pixel store 64 bytes into each.
+  const bool pairm = __builtin_amdgcn_readfirstlane(a.pair) != 0;
+  const int NI = pairm ? (a.N + 1) / 2 : a.N;  // maps, or pairs of maps, per strip segment
+  const int64_t n_items = (int64_t)a.npairs * 2 * a.nseg * NI;
   const int64_t q_begin = n_items * xcd / 8, q_end = n_items * (xcd + 1) / 8;
   const unsigned xrowb = (unsigned)a.Fin * 4u, yrowb = (unsigned)a.ld * 4u;
   const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
   const bool cheb = __builtin_amdgcn_readfirstlane(a.cheb) != 0;
   // at most 16 output columns (a first layer: 1 -> 16): a y row is 64 bytes, FOUR lanes store it, and two store instructions with
   // every lane at work cover the strip row -- instead of four with half of their lanes masked
-  const bool nout = __builtin_amdgcn_readfirstlane(a.Fout) <= 16;
+  const bool nout = __builtin_amdgcn_readfirstlane(a.Fout) <= 16 && !pairm;
 
   for (int64_t q = q_begin + slot0 * IS1_WAVES + wave; q < q_end; q += (int64_t)nslots * IS1_WAVES) {
-    const int n = (int)(q % a.N);
-    const int sg = (int)((q / a.N) % a.nseg);
-    const int e = (int)((q / ((int64_t)a.N * a.nseg)) & 1);
-    const int p = (int)(q / (2 * (int64_t)a.N * a.nseg));
+    const int n = (int)(q % NI);
+    const int sg = (int)((q / NI) % a.nseg);
+    const int e = (int)((q / ((int64_t)NI * a.nseg)) & 1);
+    const int p = (int)(q / (2 * (int64_t)NI * a.nseg));
     StripPair pr = a.pairs[p];
     {
       const int H = pr.y1 - pr.y0, ya = pr.y0 + (int)((int64_t)H * sg / a.nseg), yb = pr.y0 + (int)((int64_t)H * (sg + 1) / a.nseg);
@@ -450,8 +458,12 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
     const unsigned sXs = st_spread((unsigned)(xs + (nout ? lane >> 2 : lane >> 3)));
     const int pfirst = x0 - xs, plast = x0 - xs + wuse;
     // (x arrives zero-padded to four channels: channel g of a one-channel layer reads the padding)
-    const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)n * a.x_rows * xrowb + (unsigned)g * 4u;
-    char* __restrict__ ymap = reinterpret_cast<char*>(a.y) + (size_t)n * a.y_rows * yrowb;
+    // (pairs: this half's own map, the last map again where an odd batch has no partner -- its stores are masked)
+    const int n_x = pairm ? min(2 * n + g, a.N - 1) : n;
+    const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)n_x * a.x_rows * xrowb + (pairm ? 0u : (unsigned)g * 4u);
+    const int n_y = pairm ? 2 * n + ((lane >> 2) & 1) : n;  // (pairs: chunks 0 .. 3 of a pixel are map 2 n's, 4 .. 7 map 2 n + 1's)
+    const bool y_live = n_y < a.N;
+    char* __restrict__ ymap = reinterpret_cast<char*>(a.y) + (size_t)(y_live ? n_y : 0) * a.y_rows * yrowb;
     auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
       return st_spread((unsigned)min(max(yrow, pr.ylo), pr.yhi)) << 1;
     };
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
       auto run_base = [](unsigned run) -> unsigned { return run * 256u; };
       // (pixels per store instruction PPI = 8 with eight 16-byte chunks each, or 16 with four; wave-uniform)
       const unsigned ppi = nout ? 16u : 8u, cpl = nout ? (unsigned)lane & 3u : (unsigned)lane & 7u, pl = nout ? (unsigned)lane >> 2 : (unsigned)lane >> 3;
-      const int och = 4 * (int)cpl;
+      const int och = 4 * (int)(pairm ? cpl & 3u : cpl);
       sp_f32x4 yo4[4];
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
             sp_f32x4 o;
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) o[e4] = fmaxf(yo4[k4][e4] + bv[e4], floor_v);
-            if (pk >= pfirst && pk < plast && och < a.Fout) *reinterpret_cast<sp_f32x4*>(dst) = o;
+            if (pk >= pfirst && pk < plast && och < a.Fout && y_live) *reinterpret_cast<sp_f32x4*>(dst) = o;
           }
         }
       }

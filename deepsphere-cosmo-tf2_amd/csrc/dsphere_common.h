@@ -197,6 +197,7 @@ struct IStripLaunch {
 int istrip_segments(const std::vector<int32_t>& heights, const std::vector<unsigned char>& second, int64_t N, int num_cu, int D,
                     bool narrow);
 bool istrip_narrow(int32_t Fin_w);
+bool istrip_pairs(int32_t Fin_w, int32_t Fout);
 bool istrip_shape_ok(int32_t Fin, int32_t K);
 size_t istrip_wimg_bytes(int32_t K, int32_t precision);
 int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream);

@@ -504,7 +504,9 @@ def test_input_side_strip_kernel_whole_map(nside, N, Fin, Fout, K, basis, act, p
     (128, 3, 2, 16, 5, "chebyshev", None),      # two channels: one per lane half
     (128, 1, 1, 64, 4, "chebyshev", "elu"),     # K = 4, two 32-column blocks, deferred activation
     (128, 2, 2, 40, 3, "monomial", "relu"),     # K = 3, the other basis, a ragged second block
-    (128, 5, 1, 8, 2, "chebyshev", None),       # K = 2 (T_0 keeps three rows all the same), an odd batch
+    (128, 5, 1, 8, 2, "chebyshev", None),       # K = 2 (T_0 keeps three rows all the same), an odd batch: two maps per wave, one left over
+    (128, 4, 1, 16, 5, "chebyshev", "relu"),    # 1 -> 16, the first layer of the networks: pairs of maps share a wave
+    (128, 3, 1, 12, 4, "monomial", "elu"),      # pairs with a ragged width and the other basis
     (256, 2, 1, 96, 5, "monomial", "tanh"),     # larger map, three blocks over two 64-column launches
 ])
 def test_level_packed_strip_kernel_for_one_and_two_channels(nside, N, Fin, Fout, K, basis, act, prec):
