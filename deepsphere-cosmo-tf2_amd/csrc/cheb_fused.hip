@@ -1362,7 +1362,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       is.npairs = ft.n_ipairs; is.Fin = Fin; is.Fin_w = Fin_w; is.Fout = Fout; is.K = K; is.act = act; is.precision = precision; is.ld = ld;
       is.num_cu = plan->fused->num_cu;
       // (row segments for the items the kernel will deal: maps, or pairs of maps in the one-channel kernel's pair mode)
-      is.nseg = istrip_nseg(plan, ft, istrip_narrow(Fin_w) && istrip_pairs(Fin_w, Fout) ? (N + 1) / 2 : N, K - 1, istrip_narrow(Fin_w));
+      is.nseg = istrip_nseg(plan, ft, istrip_pairs(Fin_w, Fout) ? (N + 1) / 2 : N, K - 1, istrip_narrow(Fin_w));
       is.cheb = sl.cheb;
       is.prep_weights = !keep_weights;
       const int rc = launch_cheb_istrip(is, stream);

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void istrip_wprep_kernel(const float* __restri
     float v;
     if (CH == 1 && pair) v = (j < K && (l >> 5) == (col >> 4) && (col & 15) < Fout) ? w[(int64_t)j * ld + (col & 15)] : 0.f;
     else if (CH == 1) v = (j < K && (l >> 5) < Fin_w && col < Fout) ? w[((int64_t)(l >> 5) * K + j) * ld + col] : 0.f;
+    else if (pair) v = (j < CH && j < Fin_w && (l >> 5) == (col >> 4) && (col & 15) < Fout) ? w[((int64_t)j * K + k) * ld + (col & 15)] : 0.f;
     else v = (j < CH && ch < Fin_w && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
     if (prec == DSPH_PREC_FP32) {
       reinterpret_cast<float*>(base)[j * 64 + l] = v;  // step j, lane l
@@ -43,8 +44,9 @@ __global__ __launch_bounds__(256) void istrip_wprep_kernel(const float* __restri
 }
 
 bool istrip_narrow(int32_t Fin_w) { return Fin_w <= 2; }  // real input channels: the level-packed kernel's layers
-// ... and among them the ones that run two maps per wave: one input channel, at most 16 output columns (1 -> 16)
-bool istrip_pairs(int32_t Fin_w, int32_t Fout) { return Fin_w == 1 && Fout <= 16; }
+// layers that run two maps per wave (at most 16 output columns): one input channel on the level-packed kernel (1 -> 16), three
+// or four on the four-channel form (4 -> 8, the layers behind a pseudo-convolution) -- half of each wave would idle otherwise
+bool istrip_pairs(int32_t Fin_w, int32_t Fout) { return (Fin_w == 1 || (Fin_w >= 3 && Fin_w <= 4)) && Fout <= 16; }
 bool istrip_shape_ok(int32_t Fin, int32_t K) { return K >= 2 && K <= 5 && Fin >= 4 && Fin <= 16 && Fin % 4 == 0; }
 
 size_t istrip_wimg_bytes(int32_t K, int32_t precision) { return (size_t)K * is_terms(precision) * is_term_bytes(precision); }
@@ -106,7 +108,9 @@ int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream) {
     default: set_error("cheb_istrip: K = %d", s.K); return DSPH_E_UNSUPPORTED;
   }
   const size_t wb = istrip_wimg_bytes(s.K, s.precision);
-  const bool pair = narrow && istrip_pairs(s.Fin_w, s.Fout);
+  // (one input channel: the level-packed kernel; three or four: the four-channel form -- two channels fill both halves of
+  // the level-packed kernel already)
+  const bool pair = istrip_pairs(s.Fin_w, s.Fout) && (narrow || (s.Fin == 4 && CH == 4));
   const int64_t items = (int64_t)s.npairs * 2 * s.nseg * (pair ? (s.N + 1) / 2 : s.N);
   // eight workers per workgroup, one workgroup per CU; fewer when there are fewer items
   const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(ncu, ((items + waves - 1) / waves + 7) / 8 * 8));

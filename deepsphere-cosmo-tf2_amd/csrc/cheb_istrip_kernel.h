@@ -178,19 +178,25 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
   const int G_ = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
   const int nslots = (G_ + 7 - xcd) / 8;
   // work items: (pair, strip of the pair, row segment, map); a contiguous eighth of them per XCD, dealt to the XCD's waves in turn
-  const int64_t n_items = (int64_t)a.npairs * 2 * a.nseg * a.N;
+  // Two maps per wave (a.pair; CH = 4 only: at most four input channels and at most 16 output columns, e.g. the 4 -> 8 layers behind
+  // a pseudo-convolution, reference tests/test_healpy_networks.py:96-107): half g of the wave carries map 2 n + g instead of
+  // channels 4 .. 7 that do not exist; rows 0 .. 15 of every level's weight image hold W in the inner slots of half 0, rows
+  // 16 .. 31 in those of half 1, so an accumulator row is [map 2 n's 16 columns | map 2 n + 1's] (see cheb_istrip1_kernel below).
+  const bool pairm = CH == 4 && __builtin_amdgcn_readfirstlane(a.pair) != 0;
+  const int NI = pairm ? (a.N + 1) / 2 : a.N;
+  const int64_t n_items = (int64_t)a.npairs * 2 * a.nseg * NI;
   const int64_t q_begin = n_items * xcd / 8, q_end = n_items * (xcd + 1) / 8;
   const unsigned xrowb = (unsigned)a.Fin * 4u, yrowb = (unsigned)a.ld * 4u;
   const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
   const int nch = a.Fin;  // real channels (multiple of four); this lane's are CH * g .. CH * g + CH - 1
   const bool cheb = __builtin_amdgcn_readfirstlane(a.cheb) != 0;
-  const bool all_ch = nch == 2 * CH;                      // every lane's CH channels exist: no masking of the loads
+  const bool all_ch = nch == 2 * CH || pairm;             // every lane's CH channels exist: no masking of the loads
 
   for (int64_t q = q_begin + slot0 * IS_WAVES + wave; q < q_end; q += (int64_t)nslots * IS_WAVES) {
-    const int n = (int)(q % a.N);
-    const int sg = (int)((q / a.N) % a.nseg);
-    const int e = (int)((q / ((int64_t)a.N * a.nseg)) & 1);
-    const int p = (int)(q / (2 * (int64_t)a.N * a.nseg));
+    const int n = (int)(q % NI);
+    const int sg = (int)((q / NI) % a.nseg);
+    const int e = (int)((q / ((int64_t)NI * a.nseg)) & 1);
+    const int p = (int)(q / (2 * (int64_t)NI * a.nseg));
     StripPair pr = a.pairs[p];
     {
       const int H = pr.y1 - pr.y0, ya = pr.y0 + (int)((int64_t)H * sg / a.nseg), yb = pr.y0 + (int)((int64_t)H * (sg + 1) / a.nseg);
@@ -203,8 +209,13 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
     const unsigned sX = st_spread((unsigned)min(max(xs + px, pr.xlo), pr.xhi));
     const unsigned sXs = st_spread((unsigned)(xs + (lane >> 3)));  // the pixel whose y chunk this lane stores (instruction 0)
     const int pfirst = x0 - xs, plast = x0 - xs + wuse;
-    const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)n * a.x_rows * xrowb;
-    char* __restrict__ ymap = reinterpret_cast<char*>(a.y) + (size_t)n * a.y_rows * yrowb;
+    // (pairs: this half's own map -- the last map again where an odd batch has no partner, its stores masked; chunks 0 .. 3 of a
+    // pixel's y are map 2 n's, 4 .. 7 map 2 n + 1's)
+    const int n_x = pairm ? min(2 * n + g, a.N - 1) : n;
+    const int n_y = pairm ? 2 * n + ((lane >> 2) & 1) : n;
+    const bool y_live = n_y < a.N;
+    const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)n_x * a.x_rows * xrowb;
+    char* __restrict__ ymap = reinterpret_cast<char*>(a.y) + (size_t)(y_live ? n_y : 0) * a.y_rows * yrowb;
     auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
       return st_spread((unsigned)min(max(yrow, pr.ylo), pr.yhi)) << 1;
     };
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
 #pragma unroll
       for (int c4 = 0; c4 < CH / 4; ++c4) {
         // (branch-free: a lane whose channels the layer does not have reads the row's first quad and drops it)
-        const int ch = CH * g + 4 * c4;
+        const int ch = (pairm ? 0 : CH * g) + 4 * c4;
         const bool have = all_ch || ch < nch;
         const sp_f32x4 v = *reinterpret_cast<const sp_f32x4*>(row + (have ? ch : 0) * 4);
 #pragma unroll
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (yr >= pr.y0 && yr < pr.y1) {  // (wave-uniform)
           const unsigned sY = st_spread((unsigned)yr) << 1;
-          const int och = 4 * (lane & 7);
+          const int och = 4 * (pairm ? lane & 3 : lane & 7);
           const sp_f32x4 bv = *reinterpret_cast<const sp_f32x4*>(sBias + och);
           sp_f32x4 yo4[4];
 #pragma unroll
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) o[e4] = fmaxf(yo4[k4][e4] + bv[e4], floor_v);
             // (the launch guarantees 16-byte stores: the block's width and the row stride of y are multiples of four)
-            if (pk >= pfirst && pk < plast && och < a.Fout) *reinterpret_cast<sp_f32x4*>(dst) = o;
+            if (pk >= pfirst && pk < plast && och < a.Fout && y_live) *reinterpret_cast<sp_f32x4*>(dst) = o;
           }
         }
         __builtin_amdgcn_wave_barrier();  // (the block is rewritten in the next step)

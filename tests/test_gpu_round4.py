@@ -466,6 +466,9 @@ def test_pseudo_convolutions_against_the_oracle():
     (128, 2, 4, 20, 2, "chebyshev", None),      # K = 2, a narrow block
     (128, 1, 16, 96, 5, "monomial", "relu"),    # the other basis, three column blocks over two 64-column launches
     (256, 2, 5, 24, 5, "chebyshev", "tanh"),    # padded channel count, larger map
+    (128, 4, 4, 8, 5, "chebyshev", "relu"),     # the reference's own test network (4 -> 8 behind a pseudo-convolution): two maps per wave
+    (128, 3, 3, 16, 4, "monomial", "elu"),      # pairs with a padded channel count, an odd batch, the other basis
+    (128, 1, 4, 12, 5, "chebyshev", None),      # a single map in pair mode (its partner masked)
 ])
 def test_input_side_strip_kernel_whole_map(nside, N, Fin, Fout, K, basis, act, prec):
     """Whole maps against the float64 oracle: the rectangles on cheb_istrip_kernel, the rest on the tile kernels; the kernel
