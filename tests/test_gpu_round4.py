@@ -566,14 +566,14 @@ def test_input_side_strip_kernel_partial_sky_and_batches():
         assert torch.equal(yN, y16[:N]), f"batch {N}"
 
 
-@pytest.mark.parametrize("Fin", [16, 1])
-def test_input_side_strips_in_a_two_part_launch(Fin):
+@pytest.mark.parametrize("Fin,Fout", [(16, 32), (1, 32), (1, 16), (4, 8)])
+def test_input_side_strips_in_a_two_part_launch(Fin, Fout):
     """A rank's plan at nside 128 (two ranks): the interior part runs the strips, the boundary part the tile kernels; the two
     parts together equal the single launch bit for bit, with a deferred activation.  Fin = 1: a sharded first layer, the
-    level-packed kernel."""
+    level-packed kernel; with at most 16 columns two maps per wave (an odd batch of three: one wave carries a single map)."""
     from deepsphere import sharding
 
-    nside, K, Fout, N = 128, 5, 32, 2
+    nside, K, N = 128, 5, 3
     cols, vals = _grid_ell(nside)
     lay = sharding.ShardLayout(cols, vals, K, 1, 2)
     plan = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols, device=0, levels=lay.levels)
