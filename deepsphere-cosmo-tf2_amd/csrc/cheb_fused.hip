@@ -851,8 +851,11 @@ static int plane_rows_for(int rmax, int emax) {
   return (rmax <= 1024 && emax <= 1024) ? 1024 : 0;
 }
 
+// Layers the BFS-tile kernel runs with four maps per item (FusedArgs::pack): at most four input channels (padded to four),
+// at most 16 output columns.  Its weight image then has two column blocks whatever the layer's width.
+static bool bfs_packs(int32_t Fin, int32_t Fout) { return Fin == 4 && Fout <= 16; }
 static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
-  const int C = (Fin + FUSED_CH - 1) / FUSED_CH, NB = (Fout + 31) / 32;
+  const int C = (Fin + FUSED_CH - 1) / FUSED_CH, NB = bfs_packs(Fin, Fout) ? 2 : (Fout + 31) / 32;
   return (size_t)K * C * NB * 2048;
 }
 
@@ -1063,15 +1066,19 @@ __global__ __launch_bounds__(256) void fused_pad_kernel(const float* __restrict_
 // Weight fragments in MFMA operand order, one 2 KiB block per (order k, slice c, column block nb):
 //   bf16x3: lane l, element j  <- w[(c*16 + 8*(l>>5) + j)*K + k][32*nb + (l&31)], hi at +0, lo at +1024
 //   fp32  : step t, lane l     <- w[(c*16 + 8*(l>>5) + t)*K + k][32*nb + (l&31)] at t*256 + l*4
+// pack (four maps per item, FusedArgs::pack): one slice, two column blocks, block diagonal -- inner index 4 q + c against columns
+// 16 q + o holds w[c*K + k][o].
 __global__ __launch_bounds__(256) void fused_wprep_kernel(const float* __restrict__ w,
                                                           unsigned char* __restrict__ out, int Fin,
-                                                          int Fout, int K, int C, int NB, int prec, int ld) {
+                                                          int Fout, int K, int C, int NB, int prec, int ld, int pack) {
   const int blk = blockIdx.x;  // (k*C + c)*NB + nb
   const int nb = blk % NB, c = (blk / NB) % C, k = blk / (NB * C);
   for (int e = threadIdx.x; e < 512; e += 256) {
     const int l = e >> 3, j = e & 7;
     const int ch = c * FUSED_CH + 8 * (l >> 5) + j, col = 32 * nb + (l & 31);
-    const float v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
+    float v;
+    if (pack) v = ((ch >> 2) == (col >> 4) && (ch & 3) < Fin && (col & 15) < Fout) ? w[((int64_t)(ch & 3) * K + k) * ld + (col & 15)] : 0.f;
+    else v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
     unsigned char* base = out + (size_t)blk * 2048;
     if (prec == DSPH_PREC_BF16X3) {
       const __bf16 hi = (__bf16)v;
@@ -1332,6 +1339,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     sl.num_cu = plan->fused->num_cu;
     sl.cheb = beta_rest != 0.f;
     sl.prep_weights = !keep_weights;  // the first of the two launches packs the fragments
+    sl.allow_pack = plan->opt.pack;
     // rectangles of interior class-R tiles: the strip kernel, when it has this shape; the class-R list shrinks to the rest
     const bool strips = strips_apply(plan, ft, Fin, Fout, K, precision, N, ld) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     if (strips && part != 2 && !dbg_only('b')) {
@@ -1397,10 +1405,13 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   if (only == 1) return DSPH_OK;
   // the BFS-tile kernel has two contraction arithmetics; the six-term split of the structured kernel is fp32-equivalent
   if (precision == DSPH_PREC_BF16X6) precision = DSPH_PREC_FP32;
+  // four maps per item where the layer has at most four input channels and 16 output columns (FusedArgs::pack)
+  const bool pack = plan->opt.pack && !planes_mode && !wgrad_mode && bfs_packs(Fin, Fout) && N >= 2;  // (a single map gains nothing from two column blocks)
+  const int NBb = pack ? 2 : NB;
   if (!planes_mode && !keep_weights) {
-    hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NB), dim3(256), 0, stream, w,
-                       static_cast<unsigned char*>(workspace), (int)Fin_w, (int)Fout, (int)K, C, NB,
-                       (int)precision, (int)ld);
+    hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NBb), dim3(256), 0, stream, w,
+                       static_cast<unsigned char*>(workspace), (int)Fin_w, (int)Fout, (int)K, C, NBb,
+                       (int)precision, (int)ld, pack ? 1 : 0);
     DSPH_HIP(hipGetLastError());
   }
 
@@ -1424,7 +1435,9 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   args.lvals = ft.d_lvals;
   args.x_rows = plan->n_cols;
   args.y_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
-  args.N = (int)N;
+  args.N = pack ? (int)((N + 3) / 4) : (int)N;  // (packed: groups of four maps)
+  args.n_maps = (int)N;
+  args.pack = pack ? 1 : 0;
   args.Fin = Fin;
   args.Fout = Fout;
   args.ld = ld;
@@ -1501,10 +1514,10 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     return rc;
   };
 #define DSPH_FUSED_CASE(PR, WT) \
-  if (pr == PR && ft.width == WT) return dump_stamps(launch_fused_##PR##_##WT(args, NB, precision, grid, lds, stream));
+  if (pr == PR && ft.width == WT) return dump_stamps(launch_fused_##PR##_##WT(args, NBb, precision, grid, lds, stream));
 #else
 #define DSPH_FUSED_CASE(PR, WT) \
-  if (pr == PR && ft.width == WT) return launch_fused_##PR##_##WT(args, NB, precision, grid, lds, stream);
+  if (pr == PR && ft.width == WT) return launch_fused_##PR##_##WT(args, NBb, precision, grid, lds, stream);
 #endif
   DSPH_FUSED_CASE(576, 9)
   DSPH_FUSED_CASE(768, 9)

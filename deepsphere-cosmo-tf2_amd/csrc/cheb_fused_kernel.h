@@ -47,6 +47,12 @@ struct FusedArgs {
 #ifdef DSPH_STAMPS
   unsigned long long* stamps;  // diagnostic build only: [8 waves][8 items][32 points] s_memtime values
 #endif
+  // Forward of a layer with at most FOUR input channels and at most 16 output columns (a network's first layers): FOUR MAPS per
+  // item.  The 16-channel slice the recurrence works on is [map 4 n | 4 n + 1 | 4 n + 2 | 4 n + 3] x 4 channels instead of
+  // 4 channels + 12 zeros (the recurrence is per channel: nothing changes), the weight image is block diagonal -- inner
+  // index 4 q + c against columns 16 q .. 16 q + 15 -- so the 64-column contraction leaves map 4 n + q's 16 columns in columns
+  // 16 q ..; the store sends each 16-column group to its own map.  N is then the number of GROUPS, n_maps the batch.
+  int pack, n_maps;
   int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no contraction, 8 no y store
 };
 
@@ -304,7 +310,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   if (MODE == 2) {  // rows of a ragged tile that no step writes are multiplied by dy = 0: they must be finite
     for (int i = tid * 16; i < 2 * PLANE_BYTES; i += FUSED_THREADS * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
   }
-  if (MODE == 0 && tid < FUSED_BIAS_BYTES / 4) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
+  if (MODE == 0 && tid < FUSED_BIAS_BYTES / 4) {
+    const int bc = a.pack ? tid & 15 : tid;  // (packed maps: every 16-column group carries the layer's columns)
+    sBias[tid] = (a.bias != nullptr && bc < a.Fout) ? a.bias[bc] : 0.f;
+  }
   if (MODE == 0 && !WG) {
     for (int i = tid * 16; i < a.wfrag_bytes; i += FUSED_THREADS * 16)
       *reinterpret_cast<uint4*>(sW + i) = *reinterpret_cast<const uint4*>(a.wfrag + i);
@@ -345,8 +354,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   auto issue_loads = [&](int item, int slot) {
     const int n = item / a.c_count, c = a.c_begin + item - n * a.c_count;
     const int ch0 = c * FUSED_CH + 4 * (tid & 3);
-    const int ch = ch0 < a.Fin ? ch0 : a.Fin - 4;
-    const float* __restrict__ xb = a.x + (int64_t)n * a.x_rows * a.Fin + ch;
+    const int ch = a.pack ? 0 : (ch0 < a.Fin ? ch0 : a.Fin - 4);
+    // (packed maps: this lane's 16-byte slot is map 4 n + slot -- the last map again where the batch ends inside the group)
+    const int nx = a.pack ? min(4 * n + (tid & 3), a.n_maps - 1) : n;
+    const float* __restrict__ xb = a.x + (int64_t)nx * a.x_rows * a.Fin + ch;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if (slot >= 0 && (s < a.K ? s : 0) != slot) continue;
@@ -381,7 +392,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       lds_wave_sync();
       const int cq = 32 * b + cq0;
       const float4 bv = *reinterpret_cast<const float4*>(sBias + cq);
-      float* __restrict__ yp0 = a.y + ((int64_t)pend_n * a.y_rows + pend_row0 + wave * 32 + rsub) * a.ld + cq;
+      const int ymap = a.pack ? 4 * pend_n + (cq >> 4) : pend_n, ycol = a.pack ? cq & 15 : cq;
+      const bool ylive = !a.pack || ymap < a.n_maps;
+      float* __restrict__ yp0 = a.y + ((int64_t)(ylive ? ymap : 0) * a.y_rows + pend_row0 + wave * 32 + rsub) * a.ld + ycol;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = i * 8 + rsub;
@@ -391,14 +404,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
         v.z = apply_act(v.z + bv.z, act);
         v.w = apply_act(v.w + bv.w, act);
         float* __restrict__ yp = yp0 + (int64_t)(i * 8) * a.ld;
-        if (wave * 32 + row < pend_Pt) {
+        if (wave * 32 + row < pend_Pt && ylive) {
           if (VEC) {
-            if (cq < a.Fout) *reinterpret_cast<float4*>(yp) = v;
+            if (ycol < a.Fout) *reinterpret_cast<float4*>(yp) = v;
           } else {
-            if (cq + 0 < a.Fout) yp[0] = v.x;
-            if (cq + 1 < a.Fout) yp[1] = v.y;
-            if (cq + 2 < a.Fout) yp[2] = v.z;
-            if (cq + 3 < a.Fout) yp[3] = v.w;
+            if (ycol + 0 < a.Fout) yp[0] = v.x;
+            if (ycol + 1 < a.Fout) yp[1] = v.y;
+            if (ycol + 2 < a.Fout) yp[2] = v.z;
+            if (ycol + 3 < a.Fout) yp[3] = v.w;
           }
         }
       }
@@ -491,7 +504,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       __syncthreads();  // the previous slice's last plane is still being read
       DSPH_STAMP(1);
       // ---- T_0: the prefetched x slice goes to plane X; fetch the next slice meanwhile -------
-      const bool ch_ok = c * FUSED_CH + 4 * (tid & 3) < a.Fin;
+      const bool ch_ok = a.pack || c * FUSED_CH + 4 * (tid & 3) < a.Fin;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const unsigned idx = tid + s * FUSED_THREADS;

@@ -83,15 +83,18 @@ __global__ __launch_bounds__(256) void struct_tiles_kernel(const unsigned char* 
 // contiguous (it is streamed into LDS as one piece):
 //   bf16x3: lane l, element j <- w[(c*16 + 8*(l>>5) + j)*K + k][32*nb + (l&31)], hi at +0, lo at +1024
 //   fp32  : lane l, half e, i <- w[(c*16 + 8*(l>>5) + 4e + i)*K + k][32*nb + (l&31)] at e*1024 + l*16 + 4i
+// pack (StructArgs::pack): one slice, two column blocks, block diagonal -- inner index 4 q + c against columns 16 q + o.
 __global__ __launch_bounds__(256) void struct_wprep_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
-                                                           int Fin, int Fout, int K, int C, int NB, int prec, int ld) {
+                                                           int Fin, int Fout, int K, int C, int NB, int prec, int ld, int pack) {
   const int blk = blockIdx.x;  // (c*K + k)*NB + nb
   const int nb = blk % NB, k = (blk / NB) % K, c = blk / (NB * K);
   unsigned char* base = out + (size_t)blk * (prec == DSPH_PREC_BF16X6 ? ST_WBLK3 : 2048);
   for (int e = threadIdx.x; e < 512; e += 256) {
     const int l = e >> 3, j = e & 7;
     const int ch = c * 16 + 8 * (l >> 5) + j, col = 32 * nb + (l & 31);
-    const float v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
+    float v;
+    if (pack) v = ((ch >> 2) == (col >> 4) && (ch & 3) < Fin && (col & 15) < Fout) ? w[((int64_t)(ch & 3) * K + k) * ld + (col & 15)] : 0.f;
+    else v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
     if (prec == DSPH_PREC_BF16X6) {  // exact three-way split by truncation (st_contract): hi | mid | lo, 1 KiB each
       const unsigned u = __float_as_uint(v);
       const float r = v - __uint_as_float(u & 0xffff0000u);
@@ -226,20 +229,26 @@ bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K) {
          K * NB * 2048 <= ST_WSLICE_BYTES;
 }
 
+// layers the kernel runs with four maps per item (StructArgs::pack): two column blocks whatever the layer's width
+bool struct_packs(int32_t Fin, int32_t Fout) { return Fin == 4 && Fout <= 16; }
+
 size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {  // (sized for the largest block form, DSPH_PREC_BF16X6)
-  const int C = (Fin + 15) / 16, NB = (Fout + 31) / 32;
+  const int C = (Fin + 15) / 16, NB = struct_packs(Fin, Fout) ? 2 : (Fout + 31) / 32;
   return (size_t)C * K * NB * ST_WBLK3;
 }
 
 int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
-  const int C = (s.Fin + 15) / 16, NB = (s.Fout + 31) / 32;
+  // (packed: the per-lane offset of a map inside its group is 32 bits wide)
+  // (not for a single map: the two column blocks would be pure overhead -- BASELINE configs[0])
+  const bool pack = s.allow_pack && struct_packs(s.Fin, s.Fout) && s.N >= 2 && s.x_rows * (int64_t)s.Fin * 4 * 3 < (1ll << 32);
+  const int C = (s.Fin + 15) / 16, NB = pack ? 2 : (s.Fout + 31) / 32;
   // the six-term split needs 3 KiB weight blocks: double-buffered while a slice has at most six of them, replaced in place
   // for K = 5 with 64 columns (cheb_struct_kernel.h); the one shape in between (K = 4, 64 columns) runs exact fp32
   int prec = s.precision;
   if (prec == DSPH_PREC_BF16X6 && !(s.K * NB <= 6 || (s.K == 5 && NB == 2))) prec = DSPH_PREC_FP32;
   if (s.prep_weights) {
     hipLaunchKernelGGL(struct_wprep_kernel, dim3(C * s.K * NB), dim3(256), 0, stream, s.w, s.wfrag, (int)s.Fin_w, (int)s.Fout,
-                       (int)s.K, C, NB, prec, (int)s.ld);
+                       (int)s.K, C, NB, prec, (int)s.ld, pack ? 1 : 0);
     DSPH_HIP(hipGetLastError());
   }
   StructArgs a;
@@ -255,7 +264,9 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   a.x_rows = s.x_rows;
   a.y_rows = s.y_rows;
   a.ntiles = s.ntiles;
-  a.N = (int)s.N;
+  a.N = pack ? (int)((s.N + 3) / 4) : (int)s.N;  // (packed: groups of four maps)
+  a.n_maps = (int)s.N;
+  a.pack = pack ? 1 : 0;
   a.Fin = s.Fin;
   a.Fout = s.Fout;
   a.K = s.K;

@@ -101,6 +101,11 @@ struct StructArgs {
   const float* tabvals;        //   [ntiles][ST_CELLS][ST_TABV] diagonal + eight directions of every cell's row of L~
   int64_t x_rows, y_rows;
   int ntiles, N, Fin, Fout, K, C, act, ld;
+  // Four maps per item (layers with at most four input channels and at most 16 output columns, a network's first layers): the
+  // four 16-byte slots of a plane cell carry maps 4 n .. 4 n + 3 instead of channels 4 .. 15 that do not exist, the weight image is
+  // block diagonal (slot q against columns 16 q .. 16 q + 15: struct_wprep_kernel), the store sends every 16-column group to its
+  // own map.  N is then the number of groups, n_maps the batch.  (The same form as FusedArgs::pack, cheb_fused_kernel.h.)
+  int pack, n_maps;
 #ifdef DSPH_STAMPS
   unsigned long long* stamps;  // diagnostic build only: [8 waves][8 items][32 points] s_memtime values
 #endif
@@ -363,7 +368,8 @@ __device__ __forceinline__ void st_contract(const unsigned char* __restrict__ sm
 template <int NB>
 __device__ __forceinline__ void st_store(const st_f32x16 (&acc)[2][NB], unsigned char* __restrict__ smem, unsigned plane,
                                          int cw, float* __restrict__ ytile, int ld, const float* __restrict__ sBias,
-                                         int lane, int Fout, float floor_v, bool vec) {
+                                         int lane, int Fout, float floor_v, bool vec, bool pack = false, int64_t map_stride = 0,
+                                         int maps_left = 4) {  // pack: ytile is map 4 n's, maps_left = n_maps - 4 n
   if (ST_ABL_SKIP & 8) return;
   const unsigned r = lane & 31, h = lane >> 5, j = lane & 7, pq = lane >> 3;
   // byte a of the 4 KiB block lives in chunk a >> 9 (512 B = the 8 cells of one column parity of one tile pixel row)
@@ -380,8 +386,11 @@ __device__ __forceinline__ void st_store(const st_f32x16 (&acc)[2][NB], unsigned
       for (int tq = 0; tq < 4; ++tq)
         *reinterpret_cast<float4*>(smem + scr(r * 128u + 16u * ((2u * tq + h) ^ (r & 7u)))) =
             make_float4(acc[pb][b][4 * tq + 0], acc[pb][b][4 * tq + 1], acc[pb][b][4 * tq + 2], acc[pb][b][4 * tq + 3]);
-      const int ch = 32 * b + 4 * (int)j;
-      const float4 bv = *reinterpret_cast<const float4*>(sBias + ch);
+      const int ch0 = 32 * b + 4 * (int)j;
+      const float4 bv = *reinterpret_cast<const float4*>(sBias + ch0);
+      const int ch = pack ? ch0 & 15 : ch0;                     // column of y
+      const bool live = !pack || (ch0 >> 4) < maps_left;        // (a batch that ends inside the group)
+      float* __restrict__ ymap = ytile + (pack && live ? (int64_t)(ch0 >> 4) * map_stride : 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const unsigned p = pq + 8 * i;  // pixel (p & 15, 4 cw + 2 pb + (p >> 4)) of the tile
@@ -390,10 +399,10 @@ __device__ __forceinline__ void st_store(const st_f32x16 (&acc)[2][NB], unsigned
         o.y = fmaxf(o.y + bv.y, floor_v);
         o.z = fmaxf(o.z + bv.z, floor_v);
         o.w = fmaxf(o.w + bv.w, floor_v);
-        float* __restrict__ yp = ytile + (int64_t)st_morton(p & 15u, 4u * cw + 2u * pb + (p >> 4)) * ld + ch;
+        float* __restrict__ yp = ymap + (int64_t)st_morton(p & 15u, 4u * cw + 2u * pb + (p >> 4)) * ld + ch;
         if (vec) {
-          if (ch < Fout) *reinterpret_cast<float4*>(yp) = o;
-        } else {
+          if (ch < Fout && live) *reinterpret_cast<float4*>(yp) = o;
+        } else if (live) {
           if (ch + 0 < Fout) yp[0] = o.x;
           if (ch + 1 < Fout) yp[1] = o.y;
           if (ch + 2 < Fout) yp[2] = o.z;
@@ -440,7 +449,11 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   const bool gather = wave < ST_GATHER_WAVES;
   const int cw = wave - ST_GATHER_WAVES;  // contraction wave 0..3
   const int D = a.K - 1;
-  if (tid < 64) sBias[tid] = (a.bias != nullptr && tid < a.Fout) ? a.bias[tid] : 0.f;
+  if (tid < 64) {
+    const int bc = a.pack ? tid & 15 : tid;  // (packed maps: every 16-column group carries the layer's columns)
+    sBias[tid] = (a.bias != nullptr && bc < a.Fout) ? a.bias[bc] : 0.f;
+  }
+  const unsigned map_bytes = (unsigned)(a.x_rows * a.Fin * 4);  // (pack only: the launch makes sure three of them fit 32 bits)
 
   // tiles are dealt to XCDs in contiguous ranges (blocks b and b+8 share an XCD and its L2)
   const int G = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
@@ -507,12 +520,14 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
                         __builtin_amdgcn_readfirstlane((unsigned)ST_LDS_W + slot0 * ST_WBLK3 + 1024u * (unsigned)p));
     };
     const unsigned* const sRowG = reinterpret_cast<const unsigned*>(smem + ST_LDS_ROWS);
-    const bool raggedG = (a.Fin & 15) != 0;
+    const bool raggedG = (a.Fin & 15) != 0 && !a.pack;
     auto gdma = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
       constexpr int s = decltype(s_c)::value;
       const int piece = wave + 8 * s;
-      const float* __restrict__ base = a.x + ((int64_t)n * a.x_rows * a.Fin + c * 16);
-      unsigned off = sRowG[16 * piece + (lane >> 2)] + 16u * ((ginfo >> (3 * s)) & 3u);
+      const float* __restrict__ base = a.x + ((int64_t)(a.pack ? 4 * n : n) * a.x_rows * a.Fin + c * 16);
+      unsigned off = sRowG[16 * piece + (lane >> 2)];
+      if (a.pack) off += (unsigned)min((int)((ginfo >> (3 * s)) & 3u), a.n_maps - 1 - 4 * n) * map_bytes;  // slot q: map 4 n + q
+      else off += 16u * ((ginfo >> (3 * s)) & 3u);
       if (raggedG) {
         const int ch0 = c * 16 + 4 * (int)((ginfo >> (3 * s)) & 3u);
         if (ch0 >= a.Fin) off -= (unsigned)(ch0 - (a.Fin - 4)) * 4u;
@@ -675,7 +690,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   unsigned itC = 0;  // this workgroup's item counter
   const int wpieces = wslice / 1024;
   const bool vec_ok = (a.Fout % 4 == 0) && (a.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
-  const bool ragged = (a.Fin & 15) != 0;  // the last slice has channels past Fin: they are read from valid channels
+  const bool ragged = (a.Fin & 15) != 0 && !a.pack;  // the last slice has channels past Fin: they are read from valid channels
   // Byte offsets (from the map's first element) of the x rows of the region cells of the tile being PREFETCHED, in LDS:
   // ten offsets per lane in registers (and what hipcc hoists around them) cost the contraction role 40 spilled registers.
   // Rebuilt by the four contraction waves in the first interval of a tile's last item, used from the second interval on
@@ -697,9 +712,11 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   // piece s (compile-time) of the x slice of item (n, c) -> plane at pdst
   auto dma_x = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
     constexpr int s = decltype(s_c)::value;
-    const float* __restrict__ base = a.x + ((int64_t)n * a.x_rows * a.Fin + c * 16);
+    const float* __restrict__ base = a.x + ((int64_t)(a.pack ? 4 * n : n) * a.x_rows * a.Fin + c * 16);
     constexpr int piece_base = GX + ST_CONTRACT_WAVES * s;
-    unsigned off = sRow[16 * (piece_base + cw) + (lane >> 2)] + 16u * ((dinfo >> (3 * s)) & 3u);
+    unsigned off = sRow[16 * (piece_base + cw) + (lane >> 2)];
+    if (a.pack) off += (unsigned)min((int)((dinfo >> (3 * s)) & 3u), a.n_maps - 1 - 4 * n) * map_bytes;
+    else off += 16u * ((dinfo >> (3 * s)) & 3u);
     if (ragged) {
       const int ch0 = c * 16 + 4 * (int)((dinfo >> (3 * s)) & 3u);
       if (ch0 >= a.Fin) off -= (unsigned)(ch0 - (a.Fin - 4)) * 4u;  // meets zero weights
@@ -773,9 +790,10 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     if (!pend) return;
     st_contract<NB, PREC>(smem, pend_plane, pend_w, mb, lane, acc);
     if (pend_store) {  // that completed a map: y, then fresh accumulators
-      float* __restrict__ yt = a.y + ((int64_t)pend_n * a.y_rows + pend_row0) * a.ld;
+      float* __restrict__ yt = a.y + ((int64_t)(a.pack ? 4 * pend_n : pend_n) * a.y_rows + pend_row0) * a.ld;
       st_store<NB>(acc, smem, pend_plane, cw, yt, a.ld, sBias, lane, a.Fout,
-                   a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf(), vec_ok);
+                   a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf(), vec_ok, a.pack != 0, a.y_rows * (int64_t)a.ld,
+                   a.n_maps - 4 * pend_n);
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
 #pragma unroll

@@ -152,6 +152,7 @@ int dsph_plan_set_option(dsph_plan* p, int32_t option, int64_t value) {
       tables = false;
       break;
     case DSPH_OPT_TSTEP: o.tstep = value != 0; tables = false; break;
+    case DSPH_OPT_PACK: o.pack = value != 0; tables = false; break;
     default: set_error("plan_set_option: unknown option %d", (int)option); return DSPH_E_BADARG;
   }
   if (tables && p->fused) {

@@ -47,6 +47,7 @@ struct PlanOptions {
   bool strip_generic = false;  // DSPH_OPT_STRIP_GENERIC: compiler-scheduled strip kernel instead of the hand-ordered one
   int split_order = 0;       // DSPH_OPT_SPLIT: K > 5 by the product identity (0 auto, 1 always when possible, 2 never)
   bool tstep = true;         // DSPH_OPT_TSTEP: wide graphs step through LDS tiles (cheb_tstep.hip) instead of the gather kernel
+  bool pack = true;          // DSPH_OPT_PACK: narrow layers run several maps per item / wave when the batch has more than one
 };
 
 }  // namespace dsph
@@ -148,6 +149,7 @@ struct StructLaunch {
   const int32_t* tabrow = nullptr;  // class-T tiles: [ntiles][ST_CELLS] rows and [ntiles][ST_CELLS][ST_TABV] values
   const float* tabvals = nullptr;   // (null: class-R tiles, rows by Morton arithmetic, values from gvals8 / gdiag)
   bool prep_weights = true;         // pack the weight fragments first (false: an earlier launch of this forward did)
+  bool allow_pack = true;           // DSPH_OPT_PACK of the plan
 };
 int struct_build_rows(const dsph_plan* plan, float** gvals8, float** gdiag, unsigned char** flag);
 int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, int ntiles, int D, int64_t out_rows,

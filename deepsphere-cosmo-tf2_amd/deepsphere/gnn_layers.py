@@ -359,7 +359,8 @@ class Chebyshev(torch.nn.Module):
         # Inference steady state: the packed weight images of the previous forward are still in the workspace -- same kernel
         # tensor at the same version (torch bumps it on every in-place write: optimiser step, copy_, load_state_dict), same
         # arithmetic, same workspace -- so the call launches no weight-preparation kernel (DSPH_FWD_KEEP_WEIGHTS).
-        wkey = (self.kernel.data_ptr(), self.kernel._version, self._prec_code(), self.algo,
+        # (and same batch class: the tile kernels pack four maps of a narrow layer into one item when there is more than one map)
+        wkey = (self.kernel.data_ptr(), self.kernel._version, self._prec_code(), (self.algo, N > 1),
                 None if self._workspace is None else self._workspace.data_ptr())
         if getattr(self, "_use_graph", False):
             y = self._graph_forward(plan, x, bias if fuse_epilogue else None, act_code, wkey[:4])

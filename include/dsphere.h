@@ -129,7 +129,13 @@ int dsph_plan_prepare(dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
  *                           T_{4+j} = 2 T_4 T_j - T_{|4-j|} (passes of K <= 5 on the fast kernels), 2 never
  *   DSPH_OPT_TSTEP          1 (default) / 0: graphs wider than the fused kernels take (ELL width 13 .. 32: the reference's 20
  *                           neighbours) run every recurrence step through LDS tiles (csrc/cheb_tstep.hip); 0: the gather kernel.
- *                           Same bits either way. */
+ *                           Same bits either way.
+ *   DSPH_OPT_PACK           1 (default) / 0: a layer with at most four input channels and at most 16 output columns (the first
+ *                           layers of a network) runs its batch four maps to an item on the tile kernels when the batch has more
+ *                           than one map (the input-side strips put two maps on a wave whatever the batch: map n always rides
+ *                           half n & 1, its bits do not depend on the batch).  A map then equals its single-map result
+ *                           to rounding, not bit for bit (another order of exact-zero products, and at K = 4 the fp32-equivalent
+ *                           arithmetic in its exact-fp32 form); 0 keeps every map's bits independent of the batch. */
 #define DSPH_OPT_STRIPS 1
 #define DSPH_OPT_STRUCT 2
 #define DSPH_OPT_TABLES 3
@@ -139,6 +145,7 @@ int dsph_plan_prepare(dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
 #define DSPH_OPT_STRIP_GENERIC 7
 #define DSPH_OPT_SPLIT 8
 #define DSPH_OPT_TSTEP 9
+#define DSPH_OPT_PACK 10
 int dsph_plan_set_option(dsph_plan* plan, int32_t option, int64_t value);
 
 int64_t dsph_plan_rows(const dsph_plan* plan);
@@ -221,7 +228,9 @@ int dsph_poly_forward_part(const dsph_plan* plan, const float* x, const float* w
 
 /* The same with flags:
  *   DSPH_FWD_KEEP_WEIGHTS  `workspace` still holds the weight images that the previous call on this workspace packed from the
- *                          same w (values, not only pointer), Fin, Fout, K, basis and precision: the fused kernels use them as
+ *                          same w (values, not only pointer), Fin, Fout, K, basis, precision and batch class (N == 1 or N > 1:
+ *                          layers with at most four input channels and 16 output columns pack four maps into one item of the
+ *                          tile kernels when there is more than one, with a block-diagonal image): the fused kernels use them as
  *                          they are and the call launches no weight-preparation kernel (three small launches per forward
  *                          otherwise; on a small map they are a third of the forward).  The caller vouches for it -- a layer
  *                          in inference does, by the version counter of its kernel tensor (deepsphere/gnn_layers.py).  The

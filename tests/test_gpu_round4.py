@@ -538,9 +538,16 @@ def test_level_packed_strip_kernel_for_one_and_two_channels(nside, N, Fin, Fout,
     plain = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_STRIPS: _native.STRIPS_NEVER})
     y3, _ = _native.cheb_forward(plain, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
     assert rel_err(y.cpu().numpy(), y3.cpu().numpy()) < 2 * tol
-    # a map's result does not depend on the batch it came in (other row segments: same sums)
+    # a map's result does not depend on the batch it came in (other row segments: same sums) -- bit for bit with
+    # DSPH_OPT_PACK = 0; by default the tile kernels next to the strips pack four maps of so narrow a layer into one item when
+    # the batch has more than one: equal to rounding
     y1, _ = _native.cheb_forward(plan, _dev(x[:1]), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
-    assert torch.equal(y1, y[:1])
+    assert rel_err(y1.cpu().numpy(), y[:1].cpu().numpy()) < tol
+    nopack = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_PACK: 0})
+    yn, _ = _native.cheb_forward(nopack, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
+    yn1, _ = _native.cheb_forward(nopack, _dev(x[:1]), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
+    assert torch.equal(yn1, yn[:1])
+    assert rel_err(yn.cpu().numpy(), ref) < tol
 
 
 def test_input_side_strip_kernel_partial_sky_and_batches():
@@ -744,3 +751,73 @@ def test_wide_input_layers_run_fused(graph, nside, N, Fin, Fout, K, prec, tol):
     assert err < tol
     yu, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=P, algo=_native.ALGO_UNFUSED)
     assert rel_err(y.cpu().numpy(), yu.cpu().numpy()) < 2 * tol
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# First layers on the reference's own graphs (k-NN: a third of the tiles are class G): four maps per item in the BFS-tile kernel
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-6), ("bf16x6", 2e-6), ("bf16x3", 2 * TOL)])
+@pytest.mark.parametrize("graph,nside,N,Fin,Fout,K,act", [
+    ("knn", 64, 5, 1, 16, 5, "relu"),     # 1 -> 16 on the k-NN graph, a batch that ends inside a group of four
+    ("knn", 32, 3, 4, 8, 5, None),        # the reference's test network shape
+    ("knn", 32, 1, 3, 12, 4, "elu"),      # a single map, padded channels, deferred activation
+    ("bfs", 32, 8, 2, 16, 3, "tanh"),     # the grid with the structured kernels switched off: every tile packed
+    ("knn", 32, 6, 4, 20, 5, None),       # 20 columns: NOT packed (the ordinary path, for contrast)
+])
+def test_bfs_tiles_pack_four_maps_for_narrow_layers(graph, nside, N, Fin, Fout, K, act, prec, tol):
+    import bench
+
+    opts = None
+    if graph == "knn":
+        cols, vals, _ = bench.build_laplacian_knn(nside, torch.device("cuda", 0), 8)
+    else:
+        cols, vals = _grid_ell(nside)
+        opts = {_native.OPT_STRUCT: 0}
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0, options=opts)
+    n_struct, n_bfs = plan.tile_counts(K)
+    assert n_bfs > 0
+    rng = np.random.default_rng(N + Fin + Fout)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    ref = orc.chebyshev_forward(_csr(cols, vals), x, W, K, bias=b, activation=act)
+    P = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}[prec]
+    A = {None: _native.ACT_NONE, "relu": _native.ACT_RELU, "elu": _native.ACT_ELU, "tanh": _native.ACT_TANH}[act]
+    y, ws = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED)
+    err = rel_err(y.cpu().numpy(), ref)
+    print(f"packed {graph} nside={nside} {Fin}->{Fout} K={K} N={N} {prec}: err {err:.2e}, tiles ({n_struct}, {n_bfs})")
+    assert err < tol * (5 if act == "tanh" else 1)
+    y2, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, workspace=ws)
+    assert torch.equal(y, y2)
+    # a map's result does not depend on the group it shared a slice with (two maps: still a packed group; a single map runs
+    # the plain form, equal to rounding)
+    if N >= 2:
+        y2m, _ = _native.cheb_forward(plan, _dev(x[N - 2:]), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED)
+        assert torch.equal(y2m, y[N - 2:])
+    y1, _ = _native.cheb_forward(plan, _dev(x[N - 1:]), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED)
+    assert rel_err(y1[0].cpu().numpy(), y[N - 1].cpu().numpy()) < 2 * tol
+
+
+def test_kept_weight_images_across_batch_classes():
+    """A 1 -> 16 layer called with one map, then four, then one again: the tile kernels pack four maps into an item only when
+    there is more than one, with another weight image -- the layer keys its kept images on the batch class."""
+    nside, K = 64, 5
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=16, device=torch.device("cuda", 0), use_bias=True, activation="relu")
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((4, M, 1)).astype(np.float32)
+    with torch.no_grad():
+        y1 = layer(_dev(x[:1])).clone()
+        y4 = layer(_dev(x)).clone()
+        y4b = layer(_dev(x)).clone()      # kept images, packed
+        y1b = layer(_dev(x[:1])).clone()  # back to one map: re-packed for the plain form
+        y1c = layer(_dev(x[:1])).clone()  # kept images, plain
+    ref = orc.chebyshev_forward(_csr(cols, vals), x, layer.kernel.detach().cpu().numpy(), K,
+                                bias=layer.bias.detach().cpu().numpy().reshape(-1), activation="relu")
+    for y, r in ((y1, ref[:1]), (y4, ref), (y4b, ref), (y1b, ref[:1]), (y1c, ref[:1])):
+        assert rel_err(y.cpu().numpy(), r) < 2e-6
+    assert torch.equal(y4, y4b) and torch.equal(y1, y1b) and torch.equal(y1, y1c)

@@ -19,7 +19,8 @@ shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(1024, 
 cache = {}
 for nside, K, Fin, Fout, N in shapes:
     if nside not in cache:
-        cache[nside] = bench.build_laplacian(nside, dev)
+        kk = int(os.environ.get("BS_KNN", "0"))  # 0: the grid stencil; 8 / 20: the reference's k-nearest-neighbour graphs
+        cache[nside] = bench.build_laplacian_knn(nside, dev, kk) if kk else bench.build_laplacian(nside, dev)
     cols, vals, lmax = cache[nside]
     from deepsphere import _native
     layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, lmax=lmax, Fout=Fout, device=dev, precision=os.environ.get("BS_PREC", "bf16x3"),
