@@ -853,7 +853,7 @@ static int plane_rows_for(int rmax, int emax) {
 
 // Layers the BFS-tile kernel runs with four maps per item (FusedArgs::pack): at most four input channels (padded to four),
 // at most 16 output columns.  Its weight image then has two column blocks whatever the layer's width.
-static bool bfs_packs(int32_t Fin, int32_t Fout) { return Fin == 4 && Fout <= 16; }
+static int bfs_packs(int32_t Fin, int32_t Fout) { return Fin == 4 && Fout <= 16 ? 4 : (Fin == 8 && Fout <= 32 ? 2 : 0); }
 static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
   const int C = (Fin + FUSED_CH - 1) / FUSED_CH, NB = bfs_packs(Fin, Fout) ? 2 : (Fout + 31) / 32;
   return (size_t)K * C * NB * 2048;
@@ -1077,7 +1077,10 @@ __global__ __launch_bounds__(256) void fused_wprep_kernel(const float* __restric
     const int l = e >> 3, j = e & 7;
     const int ch = c * FUSED_CH + 8 * (l >> 5) + j, col = 32 * nb + (l & 31);
     float v;
-    if (pack) v = ((ch >> 2) == (col >> 4) && (ch & 3) < Fin && (col & 15) < Fout) ? w[((int64_t)(ch & 3) * K + k) * ld + (col & 15)] : 0.f;
+    if (pack) {  // pack = P maps: 16 / P inner indices and 64 / P columns each
+      const int ci = 16 / pack, cm = 64 / pack;
+      v = (ch / ci == col / cm && ch % ci < Fin && col % cm < Fout) ? w[((int64_t)(ch % ci) * K + k) * ld + col % cm] : 0.f;
+    }
     else v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
     unsigned char* base = out + (size_t)blk * 2048;
     if (prec == DSPH_PREC_BF16X3) {
@@ -1406,12 +1409,12 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   // the BFS-tile kernel has two contraction arithmetics; the six-term split of the structured kernel is fp32-equivalent
   if (precision == DSPH_PREC_BF16X6) precision = DSPH_PREC_FP32;
   // four maps per item where the layer has at most four input channels and 16 output columns (FusedArgs::pack)
-  const bool pack = plan->opt.pack && !planes_mode && !wgrad_mode && bfs_packs(Fin, Fout) && N >= 2;  // (a single map gains nothing from two column blocks)
+  const int pack = (plan->opt.pack && !planes_mode && !wgrad_mode && N >= 2) ? bfs_packs(Fin, Fout) : 0;  // (a single map gains nothing from two column blocks)
   const int NBb = pack ? 2 : NB;
   if (!planes_mode && !keep_weights) {
     hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NBb), dim3(256), 0, stream, w,
                        static_cast<unsigned char*>(workspace), (int)Fin_w, (int)Fout, (int)K, C, NBb,
-                       (int)precision, (int)ld, pack ? 1 : 0);
+                       (int)precision, (int)ld, pack);
     DSPH_HIP(hipGetLastError());
   }
 
@@ -1435,9 +1438,9 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   args.lvals = ft.d_lvals;
   args.x_rows = plan->n_cols;
   args.y_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
-  args.N = pack ? (int)((N + 3) / 4) : (int)N;  // (packed: groups of four maps)
+  args.N = pack ? (int)((N + pack - 1) / pack) : (int)N;  // (packed: groups of P maps)
   args.n_maps = (int)N;
-  args.pack = pack ? 1 : 0;
+  args.pack = pack;
   args.Fin = Fin;
   args.Fout = Fout;
   args.ld = ld;

@@ -48,10 +48,11 @@ struct FusedArgs {
   unsigned long long* stamps;  // diagnostic build only: [8 waves][8 items][32 points] s_memtime values
 #endif
   // Forward of a layer with at most FOUR input channels and at most 16 output columns (a network's first layers): FOUR MAPS per
-  // item.  The 16-channel slice the recurrence works on is [map 4 n | 4 n + 1 | 4 n + 2 | 4 n + 3] x 4 channels instead of
-  // 4 channels + 12 zeros (the recurrence is per channel: nothing changes), the weight image is block diagonal -- inner
+  // item (pack = 4).  The 16-channel slice the recurrence works on is [map 4 n | 4 n + 1 | 4 n + 2 | 4 n + 3] x 4 channels instead
+  // of 4 channels + 12 zeros (the recurrence is per channel: nothing changes), the weight image is block diagonal -- inner
   // index 4 q + c against columns 16 q .. 16 q + 15 -- so the 64-column contraction leaves map 4 n + q's 16 columns in columns
   // 16 q ..; the store sends each 16-column group to its own map.  N is then the number of GROUPS, n_maps the batch.
+  // pack = 2: eight input channels, at most 32 columns, two maps of two slots and 32 columns each.
   int pack, n_maps;
   int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no contraction, 8 no y store
 };
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     for (int i = tid * 16; i < 2 * PLANE_BYTES; i += FUSED_THREADS * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
   }
   if (MODE == 0 && tid < FUSED_BIAS_BYTES / 4) {
-    const int bc = a.pack ? tid & 15 : tid;  // (packed maps: every 16-column group carries the layer's columns)
+    const int bc = a.pack == 4 ? tid & 15 : (a.pack == 2 ? tid & 31 : tid);  // (packed maps: every column group carries the layer's columns)
     sBias[tid] = (a.bias != nullptr && bc < a.Fout) ? a.bias[bc] : 0.f;
   }
   if (MODE == 0 && !WG) {
@@ -354,9 +355,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   auto issue_loads = [&](int item, int slot) {
     const int n = item / a.c_count, c = a.c_begin + item - n * a.c_count;
     const int ch0 = c * FUSED_CH + 4 * (tid & 3);
-    const int ch = a.pack ? 0 : (ch0 < a.Fin ? ch0 : a.Fin - 4);
-    // (packed maps: this lane's 16-byte slot is map 4 n + slot -- the last map again where the batch ends inside the group)
-    const int nx = a.pack ? min(4 * n + (tid & 3), a.n_maps - 1) : n;
+    const int ch = a.pack == 4 ? 0 : (a.pack == 2 ? 4 * (tid & 1) : (ch0 < a.Fin ? ch0 : a.Fin - 4));
+    // (packed maps: this lane's 16-byte slot belongs to map P n + slot / (4 / P) -- the last map again where the batch ends
+    // inside the group)
+    const int nx = a.pack ? min(a.pack * n + (a.pack == 4 ? tid & 3 : (tid & 3) >> 1), a.n_maps - 1) : n;
     const float* __restrict__ xb = a.x + (int64_t)nx * a.x_rows * a.Fin + ch;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -392,7 +394,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       lds_wave_sync();
       const int cq = 32 * b + cq0;
       const float4 bv = *reinterpret_cast<const float4*>(sBias + cq);
-      const int ymap = a.pack ? 4 * pend_n + (cq >> 4) : pend_n, ycol = a.pack ? cq & 15 : cq;
+      const int gsh = a.pack == 4 ? 4 : 5;  // log2 of the columns per map
+      const int ymap = a.pack ? a.pack * pend_n + (cq >> gsh) : pend_n, ycol = a.pack ? cq & ((1 << gsh) - 1) : cq;
       const bool ylive = !a.pack || ymap < a.n_maps;
       float* __restrict__ yp0 = a.y + ((int64_t)(ylive ? ymap : 0) * a.y_rows + pend_row0 + wave * 32 + rsub) * a.ld + ycol;
 #pragma unroll

@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256) void struct_wprep_kernel(const float* __restri
     const int l = e >> 3, j = e & 7;
     const int ch = c * 16 + 8 * (l >> 5) + j, col = 32 * nb + (l & 31);
     float v;
-    if (pack) v = ((ch >> 2) == (col >> 4) && (ch & 3) < Fin && (col & 15) < Fout) ? w[((int64_t)(ch & 3) * K + k) * ld + (col & 15)] : 0.f;
+    if (pack) {  // pack = P maps: 16 / P inner indices and 64 / P columns each
+      const int ci = 16 / pack, cm = 64 / pack;
+      v = (ch / ci == col / cm && ch % ci < Fin && col % cm < Fout) ? w[((int64_t)(ch % ci) * K + k) * ld + col % cm] : 0.f;
+    }
     else v = (ch < Fin && col < Fout) ? w[((int64_t)ch * K + k) * ld + col] : 0.f;
     if (prec == DSPH_PREC_BF16X6) {  // exact three-way split by truncation (st_contract): hi | mid | lo, 1 KiB each
       const unsigned u = __float_as_uint(v);
@@ -230,7 +233,7 @@ bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K) {
 }
 
 // layers the kernel runs with four maps per item (StructArgs::pack): two column blocks whatever the layer's width
-bool struct_packs(int32_t Fin, int32_t Fout) { return Fin == 4 && Fout <= 16; }
+int struct_packs(int32_t Fin, int32_t Fout) { return Fin == 4 && Fout <= 16 ? 4 : (Fin == 8 && Fout <= 32 ? 2 : 0); }
 
 size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {  // (sized for the largest block form, DSPH_PREC_BF16X6)
   const int C = (Fin + 15) / 16, NB = struct_packs(Fin, Fout) ? 2 : (Fout + 31) / 32;
@@ -240,7 +243,7 @@ size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {  // (sized for
 int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   // (packed: the per-lane offset of a map inside its group is 32 bits wide)
   // (not for a single map: the two column blocks would be pure overhead -- BASELINE configs[0])
-  const bool pack = s.allow_pack && struct_packs(s.Fin, s.Fout) && s.N >= 2 && s.x_rows * (int64_t)s.Fin * 4 * 3 < (1ll << 32);
+  const int pack = (s.allow_pack && s.N >= 2 && s.x_rows * (int64_t)s.Fin * 4 * 3 < (1ll << 32)) ? struct_packs(s.Fin, s.Fout) : 0;
   const int C = (s.Fin + 15) / 16, NB = pack ? 2 : (s.Fout + 31) / 32;
   // the six-term split needs 3 KiB weight blocks: double-buffered while a slice has at most six of them, replaced in place
   // for K = 5 with 64 columns (cheb_struct_kernel.h); the one shape in between (K = 4, 64 columns) runs exact fp32
@@ -248,7 +251,7 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   if (prec == DSPH_PREC_BF16X6 && !(s.K * NB <= 6 || (s.K == 5 && NB == 2))) prec = DSPH_PREC_FP32;
   if (s.prep_weights) {
     hipLaunchKernelGGL(struct_wprep_kernel, dim3(C * s.K * NB), dim3(256), 0, stream, s.w, s.wfrag, (int)s.Fin_w, (int)s.Fout,
-                       (int)s.K, C, NB, prec, (int)s.ld, pack ? 1 : 0);
+                       (int)s.K, C, NB, prec, (int)s.ld, pack);
     DSPH_HIP(hipGetLastError());
   }
   StructArgs a;
@@ -264,9 +267,9 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   a.x_rows = s.x_rows;
   a.y_rows = s.y_rows;
   a.ntiles = s.ntiles;
-  a.N = pack ? (int)((s.N + 3) / 4) : (int)s.N;  // (packed: groups of four maps)
+  a.N = pack ? (int)((s.N + pack - 1) / pack) : (int)s.N;  // (packed: groups of P maps)
   a.n_maps = (int)s.N;
-  a.pack = pack ? 1 : 0;
+  a.pack = pack;
   a.Fin = s.Fin;
   a.Fout = s.Fout;
   a.K = s.K;

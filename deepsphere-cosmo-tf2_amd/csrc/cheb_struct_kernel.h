@@ -101,10 +101,11 @@ struct StructArgs {
   const float* tabvals;        //   [ntiles][ST_CELLS][ST_TABV] diagonal + eight directions of every cell's row of L~
   int64_t x_rows, y_rows;
   int ntiles, N, Fin, Fout, K, C, act, ld;
-  // Four maps per item (layers with at most four input channels and at most 16 output columns, a network's first layers): the
-  // four 16-byte slots of a plane cell carry maps 4 n .. 4 n + 3 instead of channels 4 .. 15 that do not exist, the weight image is
-  // block diagonal (slot q against columns 16 q .. 16 q + 15: struct_wprep_kernel), the store sends every 16-column group to its
-  // own map.  N is then the number of groups, n_maps the batch.  (The same form as FusedArgs::pack, cheb_fused_kernel.h.)
+  // Several maps per item (pack = P = 4: layers with at most four input channels and at most 16 output columns, a network's first
+  // layers; P = 2: eight input channels, at most 32 columns): the four 16-byte slots of a plane cell carry maps P n .. P n + P - 1
+  // (4 / P slots each) instead of channels that do not exist, the weight image is block diagonal (the slots of map q against
+  // columns (64 / P) q ..: struct_wprep_kernel), the store sends every column group to its own map.  N is then the number of
+  // groups, n_maps the batch.  (The same form as FusedArgs::pack, cheb_fused_kernel.h.)
   int pack, n_maps;
 #ifdef DSPH_STAMPS
   unsigned long long* stamps;  // diagnostic build only: [8 waves][8 items][32 points] s_memtime values
@@ -368,8 +369,8 @@ __device__ __forceinline__ void st_contract(const unsigned char* __restrict__ sm
 template <int NB>
 __device__ __forceinline__ void st_store(const st_f32x16 (&acc)[2][NB], unsigned char* __restrict__ smem, unsigned plane,
                                          int cw, float* __restrict__ ytile, int ld, const float* __restrict__ sBias,
-                                         int lane, int Fout, float floor_v, bool vec, bool pack = false, int64_t map_stride = 0,
-                                         int maps_left = 4) {  // pack: ytile is map 4 n's, maps_left = n_maps - 4 n
+                                         int lane, int Fout, float floor_v, bool vec, int pack = 0, int64_t map_stride = 0,
+                                         int maps_left = 4) {  // pack = P: ytile is map P n's, maps_left = n_maps - P n
   if (ST_ABL_SKIP & 8) return;
   const unsigned r = lane & 31, h = lane >> 5, j = lane & 7, pq = lane >> 3;
   // byte a of the 4 KiB block lives in chunk a >> 9 (512 B = the 8 cells of one column parity of one tile pixel row)
@@ -388,9 +389,10 @@ __device__ __forceinline__ void st_store(const st_f32x16 (&acc)[2][NB], unsigned
             make_float4(acc[pb][b][4 * tq + 0], acc[pb][b][4 * tq + 1], acc[pb][b][4 * tq + 2], acc[pb][b][4 * tq + 3]);
       const int ch0 = 32 * b + 4 * (int)j;
       const float4 bv = *reinterpret_cast<const float4*>(sBias + ch0);
-      const int ch = pack ? ch0 & 15 : ch0;                     // column of y
-      const bool live = !pack || (ch0 >> 4) < maps_left;        // (a batch that ends inside the group)
-      float* __restrict__ ymap = ytile + (pack && live ? (int64_t)(ch0 >> 4) * map_stride : 0);
+      const int gsh = pack == 4 ? 4 : 5;                        // log2 of the columns per map
+      const int ch = pack ? ch0 & ((1 << gsh) - 1) : ch0;       // column of y
+      const bool live = !pack || (ch0 >> gsh) < maps_left;      // (a batch that ends inside the group)
+      float* __restrict__ ymap = ytile + (pack && live ? (int64_t)(ch0 >> gsh) * map_stride : 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const unsigned p = pq + 8 * i;  // pixel (p & 15, 4 cw + 2 pb + (p >> 4)) of the tile
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   const int cw = wave - ST_GATHER_WAVES;  // contraction wave 0..3
   const int D = a.K - 1;
   if (tid < 64) {
-    const int bc = a.pack ? tid & 15 : tid;  // (packed maps: every 16-column group carries the layer's columns)
+    const int bc = a.pack == 4 ? tid & 15 : (a.pack == 2 ? tid & 31 : tid);  // (packed maps: every column group carries the layer's columns)
     sBias[tid] = (a.bias != nullptr && bc < a.Fout) ? a.bias[bc] : 0.f;
   }
   const unsigned map_bytes = (unsigned)(a.x_rows * a.Fin * 4);  // (pack only: the launch makes sure three of them fit 32 bits)
@@ -524,10 +526,14 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     auto gdma = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
       constexpr int s = decltype(s_c)::value;
       const int piece = wave + 8 * s;
-      const float* __restrict__ base = a.x + ((int64_t)(a.pack ? 4 * n : n) * a.x_rows * a.Fin + c * 16);
+      const float* __restrict__ base = a.x + ((int64_t)(a.pack ? a.pack * n : n) * a.x_rows * a.Fin + c * 16);
       unsigned off = sRowG[16 * piece + (lane >> 2)];
-      if (a.pack) off += (unsigned)min((int)((ginfo >> (3 * s)) & 3u), a.n_maps - 1 - 4 * n) * map_bytes;  // slot q: map 4 n + q
-      else off += 16u * ((ginfo >> (3 * s)) & 3u);
+      if (a.pack) {  // slot q: map P n + q / (4 / P), its 16-byte piece q % (4 / P)
+        const unsigned q = (ginfo >> (3 * s)) & 3u, mq = a.pack == 4 ? q : q >> 1;
+        off += (unsigned)min((int)mq, a.n_maps - 1 - a.pack * n) * map_bytes + (a.pack == 4 ? 0u : 16u * (q & 1u));
+      } else {
+        off += 16u * ((ginfo >> (3 * s)) & 3u);
+      }
       if (raggedG) {
         const int ch0 = c * 16 + 4 * (int)((ginfo >> (3 * s)) & 3u);
         if (ch0 >= a.Fin) off -= (unsigned)(ch0 - (a.Fin - 4)) * 4u;
@@ -712,11 +718,15 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   // piece s (compile-time) of the x slice of item (n, c) -> plane at pdst
   auto dma_x = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
     constexpr int s = decltype(s_c)::value;
-    const float* __restrict__ base = a.x + ((int64_t)(a.pack ? 4 * n : n) * a.x_rows * a.Fin + c * 16);
+    const float* __restrict__ base = a.x + ((int64_t)(a.pack ? a.pack * n : n) * a.x_rows * a.Fin + c * 16);
     constexpr int piece_base = GX + ST_CONTRACT_WAVES * s;
     unsigned off = sRow[16 * (piece_base + cw) + (lane >> 2)];
-    if (a.pack) off += (unsigned)min((int)((dinfo >> (3 * s)) & 3u), a.n_maps - 1 - 4 * n) * map_bytes;
-    else off += 16u * ((dinfo >> (3 * s)) & 3u);
+    if (a.pack) {
+      const unsigned q = (dinfo >> (3 * s)) & 3u, mq = a.pack == 4 ? q : q >> 1;
+      off += (unsigned)min((int)mq, a.n_maps - 1 - a.pack * n) * map_bytes + (a.pack == 4 ? 0u : 16u * (q & 1u));
+    } else {
+      off += 16u * ((dinfo >> (3 * s)) & 3u);
+    }
     if (ragged) {
       const int ch0 = c * 16 + 4 * (int)((dinfo >> (3 * s)) & 3u);
       if (ch0 >= a.Fin) off -= (unsigned)(ch0 - (a.Fin - 4)) * 4u;  // meets zero weights
@@ -790,10 +800,10 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     if (!pend) return;
     st_contract<NB, PREC>(smem, pend_plane, pend_w, mb, lane, acc);
     if (pend_store) {  // that completed a map: y, then fresh accumulators
-      float* __restrict__ yt = a.y + ((int64_t)(a.pack ? 4 * pend_n : pend_n) * a.y_rows + pend_row0) * a.ld;
+      float* __restrict__ yt = a.y + ((int64_t)(a.pack ? a.pack * pend_n : pend_n) * a.y_rows + pend_row0) * a.ld;
       st_store<NB>(acc, smem, pend_plane, cw, yt, a.ld, sBias, lane, a.Fout,
-                   a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf(), vec_ok, a.pack != 0, a.y_rows * (int64_t)a.ld,
-                   a.n_maps - 4 * pend_n);
+                   a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf(), vec_ok, a.pack, a.y_rows * (int64_t)a.ld,
+                   a.n_maps - a.pack * pend_n);
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
 #pragma unroll

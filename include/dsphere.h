@@ -131,7 +131,8 @@ int dsph_plan_prepare(dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
  *                           neighbours) run every recurrence step through LDS tiles (csrc/cheb_tstep.hip); 0: the gather kernel.
  *                           Same bits either way.
  *   DSPH_OPT_PACK           1 (default) / 0: a layer with at most four input channels and at most 16 output columns (the first
- *                           layers of a network) runs its batch four maps to an item on the tile kernels when the batch has more
+ *                           layers of a network; likewise eight channels and 32 columns, two maps) runs its batch four maps to
+ *                           an item on the tile kernels when the batch has more
  *                           than one map (the input-side strips put two maps on a wave whatever the batch: map n always rides
  *                           half n & 1, its bits do not depend on the batch).  A map then equals its single-map result
  *                           to rounding, not bit for bit (another order of exact-zero products, and at K = 4 the fp32-equivalent

@@ -469,6 +469,8 @@ def test_pseudo_convolutions_against_the_oracle():
     (128, 4, 4, 8, 5, "chebyshev", "relu"),     # the reference's own test network (4 -> 8 behind a pseudo-convolution): two maps per wave
     (128, 3, 3, 16, 4, "monomial", "elu"),      # pairs with a padded channel count, an odd batch, the other basis
     (128, 1, 4, 12, 5, "chebyshev", None),      # a single map in pair mode (its partner masked)
+    (128, 3, 8, 8, 5, "chebyshev", "relu"),     # 8 -> 8: the class-T tiles beside the strips run two maps per item
+    (128, 4, 7, 32, 4, "monomial", None),       # padded to eight channels, 32 columns
 ])
 def test_input_side_strip_kernel_whole_map(nside, N, Fin, Fout, K, basis, act, prec):
     """Whole maps against the float64 oracle: the rectangles on cheb_istrip_kernel, the rest on the tile kernels; the kernel
@@ -765,6 +767,9 @@ def test_wide_input_layers_run_fused(graph, nside, N, Fin, Fout, K, prec, tol):
     ("knn", 32, 1, 3, 12, 4, "elu"),      # a single map, padded channels, deferred activation
     ("bfs", 32, 8, 2, 16, 3, "tanh"),     # the grid with the structured kernels switched off: every tile packed
     ("knn", 32, 6, 4, 20, 5, None),       # 20 columns: NOT packed (the ordinary path, for contrast)
+    ("knn", 32, 3, 8, 8, 5, "relu"),      # 8 -> 8 (the reference's test network): two maps per item, one left over
+    ("bfs", 32, 5, 6, 32, 4, None),       # six channels padded to eight, 32 columns, K = 4
+    ("knn", 64, 4, 8, 24, 3, "elu"),      # two full groups
 ])
 def test_bfs_tiles_pack_four_maps_for_narrow_layers(graph, nside, N, Fin, Fout, K, act, prec, tol):
     import bench
