@@ -770,6 +770,9 @@ def test_wide_input_layers_run_fused(graph, nside, N, Fin, Fout, K, prec, tol):
     ("knn", 32, 3, 8, 8, 5, "relu"),      # 8 -> 8 (the reference's test network): two maps per item, one left over
     ("bfs", 32, 5, 6, 32, 4, None),       # six channels padded to eight, 32 columns, K = 4
     ("knn", 64, 4, 8, 24, 3, "elu"),      # two full groups
+    ("knn", 32, 3, 5, 5, 5, "relu"),      # the quick-start model's 5 -> 5: padded to eight channels, a width that is no multiple of four
+    ("bfs", 32, 6, 1, 5, 3, None),        # 1 -> 5 (its first layer): four maps per item, scalar stores, six maps = a group and a half
+    ("grid", 32, 5, 2, 7, 4, "tanh"),     # the structured tiles of the grid with scalar stores
 ])
 def test_bfs_tiles_pack_four_maps_for_narrow_layers(graph, nside, N, Fin, Fout, K, act, prec, tol):
     import bench
@@ -779,7 +782,7 @@ def test_bfs_tiles_pack_four_maps_for_narrow_layers(graph, nside, N, Fin, Fout, 
         cols, vals, _ = bench.build_laplacian_knn(nside, torch.device("cuda", 0), 8)
     else:
         cols, vals = _grid_ell(nside)
-        opts = {_native.OPT_STRUCT: 0}
+        opts = {_native.OPT_STRUCT: 0} if graph == "bfs" else None
     M = cols.shape[0]
     plan = _native.LaplacianPlan(cols, vals, device=0, options=opts)
     n_struct, n_bfs = plan.tile_counts(K)
