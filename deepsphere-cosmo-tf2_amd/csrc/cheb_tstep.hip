@@ -116,11 +116,15 @@ __global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
         if (i < R) *reinterpret_cast<float4*>(plane + plane_byte((unsigned)i, (unsigned)slot)) = st[q];
       }
     };
-    const int iters = ngroups * nslices;
-    fetch(0);
+    // (small maps -- the reference's quick-start model runs at nside 64 .. 8 -- have fewer tiles than the device has CUs: the
+    // (map, slice) iterations of a tile are then split over gridDim.y workgroups)
+    const int iters_all = ngroups * nslices;
+    const int it_begin = (int)((int64_t)iters_all * blockIdx.y / gridDim.y), iters = (int)((int64_t)iters_all * (blockIdx.y + 1) / gridDim.y);
+    if (it_begin >= iters) continue;
+    fetch(it_begin);
     __syncthreads();  // (the previous tile's last reads of plane 0)
-    stage(smem);
-    for (int it = 0; it < iters; ++it) {
+    stage(smem + (unsigned)(it_begin & 1) * (TS_RMAX * 64));
+    for (int it = it_begin; it < iters; ++it) {
       if (it + 1 < iters) fetch(it + 1);
       __syncthreads();  // plane `it & 1` is staged; the other one's readers of iteration it - 1 are done
       const int grp = it / nslices, c = it - grp * nslices;
@@ -209,12 +213,17 @@ int launch_cheb_tstep(const TStepTables& tb, const float* in, const float* prev,
   a.F = F;
   a.alpha = alpha;
   a.beta = beta;
-  const int grid = std::max(8, std::min(tb.ntiles, num_cu) / 8 * 8);
+  // one workgroup per tile up to one per CU; with fewer tiles than CUs the iterations of a tile go to several workgroups
+  const int cpm = (F + 3) / 4, mpi = cpm <= 2 ? 4 / cpm : 1;
+  const int iters_all = (int)((N + mpi - 1) / mpi) * (mpi > 1 ? 1 : (F + 15) / 16);
+  const int gx = std::max(1, std::min(tb.ntiles, num_cu));
+  const int gy = std::max(1, std::min(iters_all, num_cu / gx));
+  const dim3 grid((unsigned)gx, (unsigned)gy);
   const bool vec = F % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(a.prev)) & 15) == 0;
 #define DSPH_TS(WT, RP)                                                                                                     \
   do {                                                                                                                      \
-    if (vec) hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, true>), dim3(grid), dim3(1024 / RP), 0, stream, a);               \
-    else hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, false>), dim3(grid), dim3(1024 / RP), 0, stream, a);                  \
+    if (vec) hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, true>), grid, dim3(1024 / RP), 0, stream, a);                     \
+    else hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, false>), grid, dim3(1024 / RP), 0, stream, a);                        \
   } while (0)
   switch (tb.width) {
     case 16: DSPH_TS(16, 1); break;
