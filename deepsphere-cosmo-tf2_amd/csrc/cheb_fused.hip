@@ -1441,6 +1441,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   args.N = pack ? (int)((N + pack - 1) / pack) : (int)N;  // (packed: groups of P maps)
   args.n_maps = (int)N;
   args.pack = pack;
+  args.num_cu = plan->fused->num_cu;
   args.Fin = Fin;
   args.Fout = Fout;
   args.ld = ld;

@@ -54,6 +54,7 @@ struct FusedArgs {
   // 16 q ..; the store sends each 16-column group to its own map.  N is then the number of GROUPS, n_maps the batch.
   // pack = 2: eight input channels, at most 32 columns, two maps of two slots and 32 columns each.
   int pack, n_maps;
+  int num_cu;  // (host side: CUs of the device, for the split of a small map's batch over gridDim.y)
   int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no contraction, 8 no y store
 };
 
@@ -328,7 +329,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   const int D = a.K - 1;
   const int row_l = tid >> 2;      // recurrence: this lane's row within a pass
   const unsigned qslot = tid & 3;  //             and its 16-byte slot
-  const int items = a.N * a.c_count;  // (map, slice) pairs per tile
+  // (small maps have fewer tiles than the device has CUs: the forward then splits the maps of the batch over gridDim.y workgroups)
+  const int n_first = (int)((int64_t)a.N * blockIdx.y / gridDim.y), n_end = (int)((int64_t)a.N * (blockIdx.y + 1) / gridDim.y);
+  if (n_first >= n_end) return;
+  const int items = (n_end - n_first) * a.c_count;  // (map, slice) pairs per tile
   const size_t wstride = (size_t)a.nchunks * NB * 2048;  // weight blocks: per order
   const bool do_g = !(a.dbg & 1), do_m = !(a.dbg & 2);
   const bool cheb = a.beta_rest != 0.f;  // Chebyshev (2, 1) or monomial (1, 0) steps from k = 2 on
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   };
   // Slice `item`'s loads, one float4 per lane and slot s: all of them (slot < 0) or those of one phase.
   auto issue_loads = [&](int item, int slot) {
-    const int n = item / a.c_count, c = a.c_begin + item - n * a.c_count;
+    const int ni = item / a.c_count, n = n_first + ni, c = a.c_begin + item - ni * a.c_count;
     const int ch0 = c * FUSED_CH + 4 * (tid & 3);
     const int ch = a.pack == 4 ? 0 : (a.pack == 2 ? 4 * (tid & 1) : (ch0 < a.Fin ? ch0 : a.Fin - 4));
     // (packed maps: this lane's 16-byte slot belongs to map P n + slot / (4 / P) -- the last map again where the batch ends
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     }
 
     for (int item = 0; item < items; ++item) {
-      const int n = item / a.c_count, c = a.c_begin + item - n * a.c_count;
+      const int ni = item / a.c_count, n = n_first + ni, c = a.c_begin + item - ni * a.c_count;
 #ifdef DSPH_STAMPS
       const bool stamp_on = blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
 #endif
@@ -693,7 +697,9 @@ static int launch_variant(const FusedArgs& args, int grid, size_t lds, hipStream
   // (the kernel declares the whole LDS statically; what does not fit it are the weight fragments of many slices: WG)
   auto kern = lds + FUSED_BIAS_BYTES > (size_t)LDS_BYTES ? cheb_fused_kernel<PR, WT, RPL, NB, PREC, 0, true>
                                                          : cheb_fused_kernel<PR, WT, RPL, NB, PREC, 0, false>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), 0, stream, args);
+  // (forward only: where the tiles do not fill the device the maps of the batch are split over the y dimension)
+  const int gy = std::max(1, std::min(args.N, args.num_cu / std::max(grid, 1)));
+  hipLaunchKernelGGL(kern, dim3(grid, gy), dim3(FUSED_THREADS), 0, stream, args);
   DSPH_HIP(hipGetLastError());
   return DSPH_OK;
 }

@@ -293,7 +293,9 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   else kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_FP32, true) : DSPH_ST_PICK(DSPH_PREC_FP32, false);
 #undef DSPH_ST_PICK
 #undef DSPH_ST_PICK2
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), 0, stream, a);
+  // one workgroup per CU; where the tiles do not fill the device the maps (or groups of maps) of the batch are split over the y dimension
+  const int gy = std::max(1, std::min<int>(a.N, s.num_cu / grid));
+  hipLaunchKernelGGL(kern, dim3(grid, gy), dim3(ST_THREADS), 0, stream, a);
   DSPH_HIP(hipGetLastError());
 #ifdef DSPH_STAMPS
   if (getenv("DSPH_STAMPS_DUMP")) {

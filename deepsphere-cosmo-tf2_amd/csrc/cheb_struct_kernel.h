@@ -461,7 +461,10 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   const int G = gridDim.x, xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
   const int nslots = (G + 7 - xcd) / 8;
   const int t_begin = (int)((int64_t)a.ntiles * xcd / 8), t_end = (int)((int64_t)a.ntiles * (xcd + 1) / 8);
-  const int items = a.N * a.C;
+  // (small maps have fewer tiles than the device has CUs: the maps of the batch are then split over gridDim.y workgroups)
+  const int n_first = (int)((int64_t)a.N * blockIdx.y / gridDim.y), n_end = (int)((int64_t)a.N * (blockIdx.y + 1) / gridDim.y);
+  if (n_first >= n_end) return;
+  const int items = (n_end - n_first) * a.C;
   constexpr unsigned py = ST_PLANE_BYTES;  // the Y plane; X alternates between planes 0 and 2
   if (t_begin + slot0 >= t_end) return;
 
@@ -571,9 +574,9 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     unsigned px = 0;
     __syncthreads();  // the contraction waves' row table (prologue)
     unsigned wbG = ST_LDS_W;  // weight buffer of the current item
-    gdma_group(0, 0, 0, px, wbG);
-    gdma_group(1, 0, 0, px, wbG);
-    gdma_group(2, 0, 0, px, wbG);
+    gdma_group(0, n_first, 0, px, wbG);
+    gdma_group(1, n_first, 0, px, wbG);
+    gdma_group(2, n_first, 0, px, wbG);
     if (stag) { worder(0, 0, 0, 0); worder(1, 0, 0, 6); worder(2, 0, 0, 4); worder(3, 0, 0, 2); }
     if (early) {  // the first item's slice: the only one waited for outside the item loop
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
           }
         }
       }
-      int n = 0, c = 0;  // map and slice of the current item
+      int n = n_first, c = 0;  // map and slice of the current item
       for (int item = 0; item < items; ++item) {
 #ifdef DSPH_STAMPS
         const bool stamp_on = wave < 7 && blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
         const unsigned wbnG = wbG == (unsigned)ST_LDS_W ? (unsigned)(ST_LDS_W + ST_WSLICE_BYTES) : (unsigned)ST_LDS_W;
         const bool more = item + 1 < items || t + nslots < t_end;
         const int cn = (c + 1 == a.C || item + 1 == items) ? 0 : c + 1;
-        const int nn = item + 1 == items ? 0 : (c + 1 == a.C ? n + 1 : n);
+        const int nn = item + 1 == items ? n_first : (c + 1 == a.C ? n + 1 : n);
         st_gather<true, false>(smem, px, py, gb, v, ta, tb, (lact & 2u) != 0, dummy);  // ta <- T_0, tb <- T_1
         ST_STAMP(2);
         __syncthreads();
@@ -779,9 +782,9 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   unsigned wb = ST_LDS_W;  // weight buffer of the current item
   build_rows(t);
   __syncthreads();  // (prologue only; the gather waves meet it below)
-  dma_group(0, 0, 0, px, wb);
-  dma_group(1, 0, 0, px, wb);
-  dma_group(2, 0, 0, px, wb);
+  dma_group(0, n_first, 0, px, wb);
+  dma_group(1, n_first, 0, px, wb);
+  dma_group(2, n_first, 0, px, wb);
   const bool early = a.K >= 5;  // (see the recurrence waves)
   if (early) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -816,7 +819,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
 
   for (; t < t_end; t += nslots) {
     const unsigned row0 = (unsigned)a.tiles[t] * 256u;
-    int n = 0, c = 0;  // map and slice of the current item
+    int n = n_first, c = 0;  // map and slice of the current item
     for (int item = 0; item < items; ++item) {
 #ifdef DSPH_STAMPS
       const bool stamp_on = cw == 0 && blockIdx.x == 72 && t == t_begin + slot0 + nslots && item >= 4 && item < 12;
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
       const bool more = item + 1 < items || t + nslots < t_end;
       // map and slice of the next item (of this tile, or the first of this workgroup's next tile)
       const int cn = (c + 1 == a.C || item + 1 == items) ? 0 : c + 1;
-      const int nn = item + 1 == items ? 0 : (c + 1 == a.C ? n + 1 : n);
+      const int nn = item + 1 == items ? n_first : (c + 1 == a.C ? n + 1 : n);
       // ---- interval 1: the previous item's last plane (and y of a finished map), then T_0 ----------------------------------
       if (item + 1 == items && more) build_rows(t + nslots);
       flush_pending();
