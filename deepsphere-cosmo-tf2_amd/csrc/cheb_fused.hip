@@ -1249,7 +1249,8 @@ size_t fused_wgrad_workspace_bytes(const dsph_plan* plan, int32_t Fin, int32_t F
   if (!fused_wgrad_supported(plan, Fin, Fout, K)) return 0;
   const FusedTiles& ft = get_tiles(plan, K - 1, true);
   const int C = (Fin + FUSED_CH - 1) / FUSED_CH;
-  return (size_t)2 * fused_grid(plan, ft) * C * K * 16 * 64 * sizeof(float);
+  // (a slab per workgroup and pixel half; a small map's batch is split over up to num_cu workgroups in all: fused_wgrad_gy)
+  return (size_t)2 * std::max(fused_grid(plan, ft), plan->fused->num_cu) * C * K * 16 * 64 * sizeof(float);
 }
 
 // dw[(f*K + k)*Fout + o] = sum over slabs, in a fixed order (deterministic): sixteen lanes per element, lane p sums the slabs
@@ -1281,9 +1282,17 @@ __global__ __launch_bounds__(256) void fused_wgrad_reduce_kernel(const float* __
   }
 }
 
+int launch_fused_pad(const float* x, float* xp, int64_t rows, int32_t Fin, int32_t Fp, hipStream_t stream) {
+  const int64_t work = rows * (Fp / 4);
+  hipLaunchKernelGGL(fused_pad_kernel, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 65536)), dim3(256), 0, stream, x,
+                     reinterpret_cast<float4*>(xp), rows, (int)Fin, (int)(Fp / 4));
+  DSPH_HIP(hipGetLastError());
+  return DSPH_OK;
+}
+
 int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* dy, float* dw, int64_t N,
                             int32_t Fin, int32_t Fout, int32_t K, int32_t precision, float alpha_rest, float beta_rest,
-                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                            void* workspace, size_t workspace_bytes, hipStream_t stream, int32_t Fin_w) {
   if (!fused_wgrad_supported(plan, Fin, Fout, K)) {
     set_error("cheb_fused_wgrad: plan/shape not supported");
     return DSPH_E_UNSUPPORTED;
@@ -1296,7 +1305,7 @@ int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* 
   for (int32_t cb = 0; cb < Fout; cb += 64) {
     const int rc = launch_fused_common(plan, x, nullptr, nullptr, static_cast<float*>(workspace), nullptr, N, Fin,
                                        std::min<int32_t>(64, Fout - cb), K, DSPH_ACT_NONE, precision, alpha_rest,
-                                       beta_rest, nullptr, 0, stream, dy + cb, dw + cb, Fout);
+                                       beta_rest, nullptr, 0, stream, dy + cb, dw + cb, Fout, 0, Fin_w);
     if (rc != DSPH_OK) return rc;
   }
   return DSPH_OK;
@@ -1491,9 +1500,10 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       const int rc = launch_one(la);
       if (rc != DSPH_OK) return rc;
     }
-    const int total = Fin * K * Fout;
+    // (Fin_w < Fin: x is a zero-padded copy, only the rows of the real channels exist in dw)
+    const int total = Fin_w * K * Fout;
     hipLaunchKernelGGL(fused_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, stream, args.slabs, dw,
-                       2 * grid, (int)Fin, (int)Fout, (int)K, C, (int)ld);
+                       2 * grid * fused_wgrad_gy(args.N, grid, args.num_cu), (int)Fin_w, (int)Fout, (int)K, C, (int)ld);
     DSPH_HIP(hipGetLastError());
     return DSPH_OK;
   }

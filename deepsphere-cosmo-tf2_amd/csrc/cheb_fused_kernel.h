@@ -678,7 +678,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     }
   }
   if (MODE == 2) {  // D[i = 4 (l >> 4) + r][j = l & 15] of tile (slice cl, order k): channel 16 c + i, column 16 nb + j
-    float* __restrict__ sl = a.slabs + (size_t)(blockIdx.x * 2 + wg_hp) * ((size_t)a.nchunks * a.K * 16 * 64);
+    // (one slab per workgroup and pixel half; small maps split the batch over gridDim.y: so many more slabs)
+    float* __restrict__ sl = a.slabs + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 2 + wg_hp) * ((size_t)a.nchunks * a.K * 16 * 64);
     for (int i = 0; i < a.c_count * a.K; ++i) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(sAcc + i * WG_TILE_BYTES);
 #pragma unroll
@@ -691,6 +692,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     store_pending();
   }
 }
+
+// weight-gradient mode on a small map: the batch split over so many workgroup rows (every row needs a map: gy <= N)
+static inline int fused_wgrad_gy(int N, int grid, int num_cu) { return std::max(1, std::min(N, num_cu / std::max(grid, 1))); }
 
 template <int PR, int WT, int RPL, int NB, int PREC>
 static int launch_variant(const FusedArgs& args, int grid, size_t lds, hipStream_t stream) {
@@ -710,7 +714,7 @@ static int dispatch_nb_prec(const FusedArgs& args, int nb, int prec, int grid, s
   if (args.slabs != nullptr) {  // weight-gradient mode
     auto kern = prec == DSPH_PREC_BF16X3 ? cheb_fused_kernel<PR, WT, RPL, 1, DSPH_PREC_BF16X3, 2>
                                          : cheb_fused_kernel<PR, WT, RPL, 1, DSPH_PREC_FP32, 2>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(FUSED_THREADS), 0, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid, fused_wgrad_gy(args.N, grid, args.num_cu)), dim3(FUSED_THREADS), 0, stream, args);
     DSPH_HIP(hipGetLastError());
     return DSPH_OK;
   }

@@ -424,7 +424,12 @@ static size_t planes_bytes(const dsph_plan* p, int64_t N, int32_t Fin, int32_t K
 size_t dsph_backward_weights_workspace_bytes(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                              int32_t algo) {
   if (!p || N <= 0 || Fin <= 0 || Fout <= 0 || K <= 0) return 0;
-  if (algo != DSPH_ALGO_UNFUSED && fused_wgrad_supported(p, Fin, Fout, K)) return fused_wgrad_workspace_bytes(p, Fin, Fout, K);
+  // (channel counts that are no multiple of four -- a first layer's single channel -- run the fused kernel on a zero-padded
+  // copy of x behind the slabs: the split-over-pixels kernel of the unfused route moves two pixel rows per MFMA whatever the
+  // channel count, 13.5 ms for the 5 x 16 numbers of a 1 -> 16 layer at nside 512)
+  const int32_t Fp = (Fin + 3) & ~3;
+  if (algo != DSPH_ALGO_UNFUSED && fused_wgrad_supported(p, Fp, Fout, K))
+    return align_up(fused_wgrad_workspace_bytes(p, Fp, Fout, K), 256) + (Fp != Fin ? (size_t)N * (size_t)p->n_cols * (size_t)Fp * 4 : 0);
   if (algo == DSPH_ALGO_FUSED) return 0;
   return planes_bytes(p, N, Fin, K) + wgrad_workspace_bytes(N, out_rows(p), Fin, Fout, K);
 }
@@ -457,7 +462,8 @@ int dsph_cheb_backward_weights(const dsph_plan* p, const float* x, const float* 
   const float beta_rest = basis == DSPH_BASIS_CHEBYSHEV ? 1.f : 0.f;
   hipStream_t stream = (hipStream_t)hip_stream;
   DeviceGuard guard0(p->device);  // the tables behind fused_wgrad_supported live on the plan's device
-  const bool can_fuse = fused_wgrad_supported(p, Fin, Fout, K);
+  const int32_t Fp = (Fin + 3) & ~3;
+  const bool can_fuse = fused_wgrad_supported(p, Fp, Fout, K);
   if (algo == DSPH_ALGO_FUSED && !can_fuse) {
     set_error("backward_weights: fused kernel cannot run this plan/shape (Fin=%d Fout=%d K=%d)", Fin, Fout, K);
     return DSPH_E_UNSUPPORTED;
@@ -469,8 +475,14 @@ int dsph_cheb_backward_weights(const dsph_plan* p, const float* x, const float* 
   }
   if (can_fuse && algo != DSPH_ALGO_UNFUSED) {
     DeviceGuard guard(p->device);
-    return launch_cheb_fused_wgrad(p, x, dy, dw, N, Fin, Fout, K, precision, alpha_rest, beta_rest, workspace,
-                                   workspace_bytes, stream);
+    const size_t slab_bytes = align_up(fused_wgrad_workspace_bytes(p, Fp, Fout, K), 256);
+    if (Fp != Fin) {
+      float* xp = reinterpret_cast<float*>(static_cast<char*>(workspace) + slab_bytes);
+      const int rc = launch_fused_pad(x, xp, N * p->n_cols, Fin, Fp, stream);
+      if (rc != DSPH_OK) return rc;
+      x = xp;
+    }
+    return launch_cheb_fused_wgrad(p, x, dy, dw, N, Fp, Fout, K, precision, alpha_rest, beta_rest, workspace, slab_bytes, stream, Fin);
   }
   // any L, any shape: K-1 gather launches into workspace planes, then the split-over-pixels MFMA kernel
   if (K > 64) { set_error("backward_weights: K = %d exceeds 64", K); return DSPH_E_UNSUPPORTED; }
