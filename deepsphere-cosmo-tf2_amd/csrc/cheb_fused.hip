@@ -1006,6 +1006,19 @@ static int istrip_nseg(const dsph_plan* plan, const FusedTiles& ft, int64_t N, i
   return it->second;
 }
 
+// conv + HealpyPool(p = 1) in one forward (launch_cheb_fused with a FusedPool): the level-packed strip kernel stores the pooled
+// map itself, the other tiles go through a full-resolution scratch.  One or two input channels (a first layer), whole unsharded
+// maps of whole tiles, bias and ReLU only (the other activations run as a separate pass over the full-resolution map).
+bool fused_pool_ok(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act) {
+  if (!plan->fused || N < 1 || !istrip_narrow(Fin) || !(act == DSPH_ACT_NONE || act == DSPH_ACT_RELU)) return false;
+  if (!plan->levels.empty() || plan->n_cols != plan->n_rows || plan->n_rows % FUSED_P != 0 || K < 2 || K - 1 > FUSED_DMAX) return false;
+  if (!fused_supported(plan, Fin, Fout, K)) return false;
+  const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
+  return ft.ok && ft.n_part != ft.ntiles && istrips_apply(plan, ft, pad4(Fin), K, std::min(Fout, 64), Fout) &&
+         (Fout <= 64 || Fout % 64 == 0 || istrips_apply(plan, ft, pad4(Fin), K, Fout % 64, Fout));
+}
+
+
 // tiles a forward of this shape hands to the strip kernel: the same predicate the launch uses, for the layer's first 64-column
 // block (a layer with Fout = 96 runs its first block through the strips and reports them; one with Fout < 64 has none)
 int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision) {
@@ -1112,12 +1125,18 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                void* workspace, size_t workspace_bytes, hipStream_t stream,
                                const float* dy = nullptr, float* dw = nullptr, int32_t ld = 0, int32_t part = 0,
                                int32_t Fin_w = 0, int32_t only = 0,  // only: 0 every launch, 1 the structured ones, 2 the BFS-tile one
-                               bool keep_weights = false);           // the weight images in the workspace are those of an earlier call
+                               bool keep_weights = false,            // the weight images in the workspace are those of an earlier call
+                               const FusedPool* pool = nullptr);     // conv + pool: the strips store the pooled map (launch_cheb_fused)
 
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream, int32_t part, bool keep_weights) {
+                      size_t workspace_bytes, hipStream_t stream, int32_t part, bool keep_weights, const FusedPool* pool) {
+  if (pool != nullptr && !(part == 0 && fused_pool_ok(plan, N, Fin, Fout, K, act) && pool->y != nullptr && (pool->type == 1 || pool->type == 2) &&
+                           ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(pool->y)) & 15) == 0)) {
+    set_error("cheb_fused: this plan / shape has no fused pooling (one or two input channels, whole unsharded maps, no or ReLU activation)");
+    return DSPH_E_UNSUPPORTED;
+  }
   // more than 64 output columns: one launch per 64-column block (the recurrence is repeated; still one pass
   // over x per block instead of the unfused path's K planes through HBM)
   // The structured-tile kernel fuses bias and ReLU; with any other activation both fused kernels write the pre-activation
@@ -1176,7 +1195,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
     auto run = [&](hipStream_t st, int32_t only) {
       return launch_fused_common(plan, x, w + cb, bias ? bias + cb : nullptr, y + cb, nullptr, N, Fin,
                                  std::min<int32_t>(64, Fout - cb), K, defer_act ? DSPH_ACT_NONE : act, precision, alpha_rest,
-                                 beta_rest, blk_ws, blk_frag, st, nullptr, nullptr, Fout, part, Fin_w, only, keep_weights);
+                                 beta_rest, blk_ws, blk_frag, st, nullptr, nullptr, Fout, part, Fin_w, only, keep_weights, pool);
     };
     if (fork) {
       std::unique_lock<std::mutex> lock(fp->fork_mu);
@@ -1204,6 +1223,15 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
     }
     const int rc = run(stream, 0);
     if (rc != DSPH_OK) return rc;
+  }
+  if (pool != nullptr) {
+    // the tiles the strips did not take: their full-resolution rows are in y (scratch), reduced here into the pooled map
+    const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
+    const bool maxp = pool->type == 1;
+    int rc = launch_healpix_pool_tiles(y, pool->y, ft.d_rrest, ft.n_rrest, N, plan->n_rows, Fout, maxp, stream);
+    if (rc == DSPH_OK) rc = launch_healpix_pool_tiles(y, pool->y, ft.d_tlist, ft.n_t, N, plan->n_rows, Fout, maxp, stream);
+    if (rc == DSPH_OK) rc = launch_healpix_pool_tiles(y, pool->y, ft.d_part, ft.n_part, N, plan->n_rows, Fout, maxp, stream);
+    return rc;
   }
   if (defer_act) {
     const int64_t orows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
@@ -1315,7 +1343,8 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream, const float* dy,
-                               float* dw, int32_t ld, int32_t part, int32_t Fin_w, int32_t only, bool keep_weights) {
+                               float* dw, int32_t ld, int32_t part, int32_t Fin_w, int32_t only, bool keep_weights,
+                               const FusedPool* pool) {
   if (ld <= 0) ld = Fout;
   if (Fin_w <= 0) Fin_w = Fin;  // channels of w; smaller than Fin when x is a zero-padded copy  // row stride of w, bias-less y / dy / dw: the layer's Fout when this is one column block
   const bool wgrad_mode = dy != nullptr;  // y then carries the slab workspace
@@ -1385,6 +1414,11 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       is.nseg = istrip_nseg(plan, ft, istrip_pairs(Fin_w, Fout) ? (N + 1) / 2 : N, K - 1, istrip_narrow(Fin_w));
       is.cheb = sl.cheb;
       is.prep_weights = !keep_weights;
+      if (pool != nullptr) {
+        is.pool = pool->type;
+        is.ypool = pool->y;
+        is.ypool_rows = plan->n_rows / 4;
+      }
       const int rc = launch_cheb_istrip(is, stream);
       if (rc != DSPH_OK) return rc;
     }

@@ -50,6 +50,9 @@ struct IStripArgs {
   int64_t x_rows, y_rows;
   int npairs, N, Fin, Fout, ld, act;  // Fout: columns of this block (<= 32)
   int nseg;                           // every strip is cut into nseg row segments (chosen per call: istrip_segments)
+  float* ypool;                       // cheb_istrip1_kernel, pool != 0: the 2 x 2 NEST-pooled output (column 0 of this launch's block), ypool_rows rows per map
+  int64_t ypool_rows;
+  int pool;                           //   0 none (y is written), 1 max, 2 mean of the four children (y is NOT written by this kernel)
   int pair;                           // cheb_istrip1_kernel: two maps per wave (one input channel, at most 16 output columns)
   int cheb;                           // T_k = 2 L~ T_{k-1} - T_{k-2} (1, Chebyshev) or L~ T_{k-1} (0, monomial), k >= 2
 };
@@ -411,7 +414,7 @@ template <int K, int PREC>
 __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs a) {
   constexpr int D = K - 1;
   constexpr int NP = K - 1;            // planes with rows kept: T_0 .. T_{K-2}
-  constexpr int WAVEB = IS_YSTB;       // LDS per wave: the y block (the rows of L~ live in registers here)
+  constexpr int WAVEB = 2 * IS_YSTB;   // LDS per wave: two y blocks (even and odd rows: the pooled epilogue needs both; the rows of L~ live in registers)
   __shared__ __attribute__((aligned(16))) unsigned char smem[IS1_WAVES * WAVEB + 128];
   float* const sBias = reinterpret_cast<float*>(smem + IS1_WAVES * WAVEB);
 
@@ -449,7 +452,13 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
   const bool cheb = __builtin_amdgcn_readfirstlane(a.cheb) != 0;
   // at most 16 output columns (a first layer: 1 -> 16): a y row is 64 bytes, FOUR lanes store it, and two store instructions with
   // every lane at work cover the strip row -- instead of four with half of their lanes masked
-  const bool nout = __builtin_amdgcn_readfirstlane(a.Fout) <= 16 && !pairm;
+  // Pooled epilogue (a.pool: the layer is followed by HealpyPool(p = 1), reference healpy_layers.py:20-63): the four children of a
+  // coarse pixel are the pixels (2 i, 2 j), (2 i + 1, 2 j), (2 i, 2 j + 1), (2 i + 1, 2 j + 1) -- two neighbouring pixels of two
+  // consecutive strip rows, i.e. the two 128-byte halves of one run of the y block, of the even row's block and of the odd row's.
+  // The odd row's store step reads the four, applies bias and activation to each, reduces them in child order and stores ONE row of
+  // the pooled map; the full-resolution y of these pixels never exists.  (Segments are then cut at even rows.)
+  const int pool = __builtin_amdgcn_readfirstlane(a.pool);
+  const bool nout = __builtin_amdgcn_readfirstlane(a.Fout) <= 16 && !pairm && pool == 0;
 
   for (int64_t q = q_begin + slot0 * IS1_WAVES + wave; q < q_end; q += (int64_t)nslots * IS1_WAVES) {
     const int n = (int)(q % NI);
@@ -458,7 +467,8 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
     const int p = (int)(q / (2 * (int64_t)NI * a.nseg));
     StripPair pr = a.pairs[p];
     {
-      const int H = pr.y1 - pr.y0, ya = pr.y0 + (int)((int64_t)H * sg / a.nseg), yb = pr.y0 + (int)((int64_t)H * (sg + 1) / a.nseg);
+      const int H = pr.y1 - pr.y0, em = pool ? ~1 : ~0;  // (pooled: cuts at even rows)
+      const int ya = pr.y0 + ((int)((int64_t)H * sg / a.nseg) & em), yb = pr.y0 + ((int)((int64_t)H * (sg + 1) / a.nseg) & em);
       pr.y0 = ya;
       pr.y1 = yb;
       if (yb <= ya) continue;
@@ -474,7 +484,8 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
     const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)n_x * a.x_rows * xrowb + (pairm ? 0u : (unsigned)g * 4u);
     const int n_y = pairm ? 2 * n + ((lane >> 2) & 1) : n;  // (pairs: chunks 0 .. 3 of a pixel are map 2 n's, 4 .. 7 map 2 n + 1's)
     const bool y_live = n_y < a.N;
-    char* __restrict__ ymap = reinterpret_cast<char*>(a.y) + (size_t)(y_live ? n_y : 0) * a.y_rows * yrowb;
+    char* __restrict__ ymap = pool ? reinterpret_cast<char*>(a.ypool) + (size_t)(y_live ? n_y : 0) * a.ypool_rows * yrowb
+                                   : reinterpret_cast<char*>(a.y) + (size_t)(y_live ? n_y : 0) * a.y_rows * yrowb;
     auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
       return st_spread((unsigned)min(max(yrow, pr.ylo), pr.yhi)) << 1;
     };
@@ -547,16 +558,17 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
       // (pixels per store instruction PPI = 8 with eight 16-byte chunks each, or 16 with four; wave-uniform)
       const unsigned ppi = nout ? 16u : 8u, cpl = nout ? (unsigned)lane & 3u : (unsigned)lane & 7u, pl = nout ? (unsigned)lane >> 2 : (unsigned)lane >> 3;
       const int och = 4 * (int)(pairm ? cpl & 3u : cpl);
-      sp_f32x4 yo4[4];
+      const int yr = ytop - D - 1;  // finished by the previous step
+      if (pool == 0) {
+        const unsigned char* yb_ = yst;
+        sp_f32x4 yo4[4];
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        if (nout && k4 >= 2) break;
-        const unsigned pk = ppi * k4 + pl, run = pk >> 1;
-        yo4[k4] = *reinterpret_cast<const sp_f32x4*>(yst + run_base(run) + (pk & 1u) * 128u + ((cpl ^ (run & 7u))) * 16u);
-      }
-      __builtin_amdgcn_wave_barrier();
-      {
-        const int yr = ytop - D - 1;  // finished by the previous step
+        for (int k4 = 0; k4 < 4; ++k4) {
+          if (nout && k4 >= 2) break;
+          const unsigned pk = ppi * k4 + pl, run = pk >> 1;
+          yo4[k4] = *reinterpret_cast<const sp_f32x4*>(yb_ + run_base(run) + (pk & 1u) * 128u + ((cpl ^ (run & 7u))) * 16u);
+        }
+        __builtin_amdgcn_wave_barrier();
         if (yr >= pr.y0 && yr < pr.y1) {  // (wave-uniform)
           const unsigned sY = st_spread((unsigned)yr) << 1;
           const sp_f32x4 bv = *reinterpret_cast<const sp_f32x4*>(sBias + och);
@@ -572,7 +584,39 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
             if (pk >= pfirst && pk < plast && och < a.Fout && y_live) *reinterpret_cast<sp_f32x4*>(dst) = o;
           }
         }
+      } else if ((yr & 1) && yr >= pr.y0 && yr < pr.y1) {  // (wave-uniform) rows yr - 1 (block 0) and yr (block 1) are both there
+        const sp_f32x4 bv = *reinterpret_cast<const sp_f32x4*>(sBias + och);
+        const unsigned sYp = st_spread((unsigned)yr >> 1) << 1;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          // pooled pixel pp of the strip: the pixels pk0, pk0 + 1 with an EVEN absolute x (the strip starts K - 1 columns left of
+          // its first output column: at an odd x when K is even)
+          const unsigned pp = 8u * k2 + pl, pk0u = 2u * pp + ((unsigned)xs & 1u), pk1u = min(pk0u + 1u, 31u);
+          const unsigned off0 = run_base(pk0u >> 1) + (pk0u & 1u) * 128u + ((cpl ^ ((pk0u >> 1) & 7u))) * 16u;
+          const unsigned off1 = run_base(pk1u >> 1) + (pk1u & 1u) * 128u + ((cpl ^ ((pk1u >> 1) & 7u))) * 16u;
+          sp_f32x4 c[4];
+          c[0] = *reinterpret_cast<const sp_f32x4*>(yst + off0);
+          c[1] = *reinterpret_cast<const sp_f32x4*>(yst + off1);
+          c[2] = *reinterpret_cast<const sp_f32x4*>(yst + IS_YSTB + off0);
+          c[3] = *reinterpret_cast<const sp_f32x4*>(yst + IS_YSTB + off1);
+          sp_f32x4 o;
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            float r = pool == 1 ? -__builtin_huge_valf() : 0.f;  // (healpix_pool_kernel's order: the children in row order)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float v = fmaxf(c[q][e4] + bv[e4], floor_v);
+              r = pool == 1 ? fmaxf(r, v) : r + v;
+            }
+            o[e4] = pool == 1 ? r : r * 0.25f;
+          }
+          const unsigned rid = st_spread(((unsigned)xs + pk0u) >> 1) | sYp;
+          float* dst = reinterpret_cast<float*>(ymap + (size_t)rid * yrowb) + och;
+          const int pk0 = (int)pk0u;
+          if (pk0 >= pfirst && pk0 + 1 < plast && och < a.Fout && y_live) *reinterpret_cast<sp_f32x4*>(dst) = o;
+        }
       }
+      __builtin_amdgcn_wave_barrier();
 
       // levels 1 .. K-1: T_k[ytop - k] from T_{k-1}'s three newest rows (ytop-k+1, ytop-k, ytop-k-1) and T_{k-2}[ytop - k]
       float row[8];  // the contraction's operand: slot j <- T_j[ytop - (K-1)]
@@ -624,7 +668,7 @@ __global__ __launch_bounds__(IS1_THREADS, 3) void cheb_istrip1_kernel(IStripArgs
       // y of row ytop - (K-1) into the staging block; the NEXT step turns it so that eight lanes store 128 contiguous bytes
       {
         const unsigned run = (unsigned)px >> 1;
-        unsigned char* wp = yst + run_base(run) + ((unsigned)px & 1u) * 128u;
+        unsigned char* wp = yst + (pool && ((ytop - D) & 1) ? IS_YSTB : 0) + run_base(run) + ((unsigned)px & 1u) * 128u;
 #pragma unroll
         for (int tq = 0; tq < 4; ++tq) {
           if (nout && tq >= 2) break;  // (columns 16 .. 31 do not exist)

@@ -235,6 +235,40 @@ static int resolve_algo(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K
   return algo == DSPH_ALGO_FUSED ? -1 : DSPH_ALGO_UNFUSED;
 }
 
+int dsph_plan_pool_fusable(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act) {
+  if (!p || N <= 0 || Fin <= 0 || Fout <= 0 || K <= 0) return 0;
+  DeviceGuard guard(p->device);
+  return (!use_split(p, Fin, Fout, K, DSPH_ALGO_AUTO, DSPH_PART_ALL) && fused_pool_ok(p, N, Fin, Fout, K, act)) ? 1 : 0;
+}
+
+int dsph_poly_forward_pool(const dsph_plan* p, const float* x, const float* w, const float* bias, float* y_scratch,
+                           float* y_pooled, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t basis, int32_t act,
+                           int32_t precision, int32_t pool_type, int32_t flags, void* workspace, size_t workspace_bytes,
+                           void* hip_stream) {
+  if (flags & ~DSPH_FWD_KEEP_WEIGHTS) { set_error("poly_forward_pool: unknown flags %d", flags); return DSPH_E_BADARG; }
+  if (basis != DSPH_BASIS_CHEBYSHEV && basis != DSPH_BASIS_MONOMIAL) { set_error("poly_forward_pool: unknown basis %d", basis); return DSPH_E_BADARG; }
+  if (pool_type != DSPH_POOL_MAX && pool_type != DSPH_POOL_AVG) { set_error("poly_forward_pool: unknown pool type %d", pool_type); return DSPH_E_BADARG; }
+  if (!p || !x || !w || !y_scratch || !y_pooled || N <= 0 || Fin <= 0 || Fout <= 0 || K <= 0) {
+    set_error("poly_forward_pool: bad arguments (NULL pointer or non-positive size)");
+    return DSPH_E_BADARG;
+  }
+  if (precision != DSPH_PREC_FP32 && precision != DSPH_PREC_BF16X3 && precision != DSPH_PREC_BF16X6) { set_error("poly_forward_pool: unknown precision %d", precision); return DSPH_E_BADARG; }
+  if (!dsph_plan_pool_fusable(p, N, Fin, Fout, K, act)) {
+    set_error("poly_forward_pool: no fused pooling for this plan / shape (dsph_plan_pool_fusable)");
+    return DSPH_E_UNSUPPORTED;
+  }
+  const size_t need = dsph_workspace_bytes(p, N, Fin, Fout, K, precision, DSPH_ALGO_FUSED);
+  if (need > 0 && (!workspace || workspace_bytes < need)) {
+    set_error("poly_forward_pool: workspace %zu bytes, need %zu", workspace_bytes, need);
+    return DSPH_E_WORKSPACE;
+  }
+  DeviceGuard guard(p->device);
+  const FusedPool fp{y_pooled, pool_type == DSPH_POOL_MAX ? 1 : 2};
+  return launch_cheb_fused(p, x, w, bias, y_scratch, N, Fin, Fout, K, act, precision, basis == DSPH_BASIS_CHEBYSHEV ? 2.f : 1.f,
+                           basis == DSPH_BASIS_CHEBYSHEV ? 1.f : 0.f, workspace, workspace_bytes, (hipStream_t)hip_stream,
+                           DSPH_PART_ALL, (flags & DSPH_FWD_KEEP_WEIGHTS) != 0, &fp);
+}
+
 size_t dsph_workspace_bytes(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                             int32_t precision, int32_t algo) {
   if (!p || N <= 0 || Fin <= 0 || K <= 0) return 0;

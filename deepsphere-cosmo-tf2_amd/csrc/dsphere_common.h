@@ -100,10 +100,19 @@ bool fused_weights_resident(const dsph_plan* plan, int32_t Fin, int32_t Fout, in
 bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
 int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision);
 int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_t cap);
+// conv + HealpyPool(p = 1) in one forward: the pooled map (N, n_rows / 4, Fout) and the kind of reduction (1 max, 2 mean)
+struct FusedPool {
+  float* y;
+  int32_t type;
+};
+bool fused_pool_ok(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act);
+int launch_healpix_pool_tiles(const float* x, float* y, const int32_t* tiles, int ntiles, int64_t N, int64_t rows_in, int32_t F, bool maxp,
+                              hipStream_t stream);
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream, int32_t part = 0, bool keep_weights = false);
+                      size_t workspace_bytes, hipStream_t stream, int32_t part = 0, bool keep_weights = false,
+                      const FusedPool* pool = nullptr);  // pool: y is then scratch (full resolution), pool->y the result
 bool fused_planes_supported(const dsph_plan* plan, int32_t Fin, int32_t K);
 int launch_cheb_fused_planes(const dsph_plan* plan, const float* x, float* planes_out, int64_t N, int32_t Fin,
                              int32_t K, float alpha_rest, float beta_rest, hipStream_t stream);
@@ -194,6 +203,9 @@ struct IStripLaunch {
   int64_t x_rows, y_rows, N;
   int32_t npairs, Fin, Fin_w, Fout, K, act, precision, ld, num_cu;
   int32_t nseg = 1;          // row segments per strip (istrip_segments)
+  float* ypool = nullptr;    // pool != 0 (one or two input channels only): the 2 x 2 pooled output, ypool_rows rows per map; y is not written
+  int64_t ypool_rows = 0;
+  int32_t pool = 0;          // 0 none, 1 max, 2 mean
   bool cheb;
   bool prep_weights = true;
 };

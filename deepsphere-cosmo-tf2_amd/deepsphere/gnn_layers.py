@@ -386,6 +386,44 @@ class Chebyshev(torch.nn.Module):
 
     call = forward
 
+    def forward_pool(self, input_tensor, pool_type="MAX"):
+        """``HealpyPool(p=1, pool_type)(self(input_tensor))`` in ONE pass where the kernels can (``dsph_poly_forward_pool``: a
+        first layer -- one or two input channels -- without batch norm, activation none or ReLU, inference, whole unsharded
+        maps): the strip kernel reduces the four NEST children in its epilogue and the full-resolution output, 16 times the
+        input of a 1 -> 16 layer, is never written.  Returns ``None`` when it cannot -- the caller then runs the two layers
+        (``HealpyGCNN.forward`` does).  Same values as the two layers (bit for bit for "MAX")."""
+        if pool_type not in ("MAX", "AVG") or self.use_bn or not isinstance(input_tensor, torch.Tensor) or input_tensor.dim() != 3:
+            return None
+        if self._act_code not in (_native.ACT_NONE, _native.ACT_RELU) or getattr(self, "_use_graph", False):
+            return None
+        if torch.is_grad_enabled() and (input_tensor.requires_grad or (self._built and (self.kernel.requires_grad or (
+                self.use_bias and self.bias.requires_grad)))):
+            return None
+        N, M, Fin = (int(v) for v in input_tensor.shape)
+        if M != self._M or not input_tensor.is_cuda:
+            return None
+        self._resolve_device(input_tensor)
+        if not self._built:
+            if torch.is_grad_enabled():
+                return None  # (new parameters require grad)
+            self.build(input_tensor.shape)
+        if Fin != self._Fin:
+            return None
+        plan = self._get_plan()
+        Fout = int(self.kernel.shape[1])
+        if not _native.pool_fusable(plan, N, Fin, Fout, self.K, self._act_code):
+            return None
+        x = input_tensor.detach().to(device=self._device, dtype=torch.float32).contiguous()
+        bias = self.bias.detach().reshape(-1).contiguous() if self.use_bias else None
+        wkey = (self.kernel.data_ptr(), self.kernel._version, self._prec_code(), (self.algo, N > 1),
+                None if self._workspace is None else self._workspace.data_ptr())
+        y, self._workspace, self._pool_scratch = _native.cheb_forward_pool(
+            plan, x, self.kernel.detach(), bias, self.K, pool_type=_native.POOL_MAX if pool_type == "MAX" else _native.POOL_AVG,
+            act=self._act_code, precision=self._prec_code(), workspace=self._workspace, scratch=getattr(self, "_pool_scratch", None),
+            basis=self._basis, keep_weights=getattr(self, "_wkey", None) == wkey)
+        self._wkey = wkey[:4] + (self._workspace.data_ptr() if self._workspace is not None else None,)
+        return y
+
     def invalidate_weights(self):
         """Forget the packed weight images (and a captured graph): the next forward re-packs.  The layer notices weight updates
         by the version counter of ``self.kernel`` -- optimiser steps, ``copy_``, ``load_state_dict`` all move it -- but an

@@ -119,13 +119,27 @@ class HealpyGCNN(torch.nn.Sequential):
                               "(or training=None to follow module.training).", stacklevel=2)
                 self._warned_training = True
         x = input_tensor
-        for layer in self:
+        layers = list(self)
+        i = 0
+        while i < len(layers):
+            layer = layers[i]
             if isinstance(layer, (gnn.Chebyshev, gnn.GCNN_ResidualLayer)):
+                # a graph convolution followed by HealpyPool(p = 1): one pass where the kernels can (inference, a first layer:
+                # the strip kernel stores the pooled map and the full-resolution output is never written), else the two layers
+                nxt = layers[i + 1] if i + 1 < len(layers) else None
+                if (isinstance(layer, gnn.Chebyshev) and isinstance(nxt, hp_nn.HealpyPool) and nxt.p == 1 and not training
+                        and isinstance(x, torch.Tensor)):
+                    y = layer.forward_pool(x, nxt.pool_type)
+                    if y is not None:
+                        x = y
+                        i += 2
+                        continue
                 x = layer(x, training=training)
             else:
                 if not isinstance(x, torch.Tensor):
                     x = torch.as_tensor(np.asarray(x), dtype=torch.float32)
                 x = layer(x)
+            i += 1
         return x
 
     call = forward

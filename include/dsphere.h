@@ -242,6 +242,21 @@ int dsph_poly_forward_ex(const dsph_plan* plan, const float* x, const float* w, 
                          int32_t act, int32_t precision, int32_t algo, int32_t part, int32_t flags, void* workspace,
                          size_t workspace_bytes, void* hip_stream);
 
+/* The forward followed by HealpyPool(p = 1) (reference healpy_layers.py:20-63: MaxPool1D / AveragePooling1D with pool size 4 over
+ * the NEST-ordered pixels, after gnn_layers.py:106-161) in one call: y_pooled (N, n_rows / 4, Fout) = pool(act(conv(x) + bias)).
+ * The strip kernel of a first layer (one or two input channels) reduces the four children in its epilogue and stores the pooled
+ * map only -- the full-resolution output of a 1 -> 16 layer is 16 times its input and, with the pooling's read of it, most of that
+ * layer's time; the tiles the strips do not take are written at full resolution into `y_scratch` (N, n_rows, Fout; contents
+ * afterwards unspecified) and reduced from there.  Same values as the two calls (bit for bit for the maximum; the mean adds the
+ * children in the same order).  pool_type: DSPH_POOL_MAX | DSPH_POOL_AVG.  Availability: dsph_plan_pool_fusable (whole
+ * unsharded maps of whole tiles, one or two input channels, activation none or ReLU); DSPH_E_UNSUPPORTED otherwise -- run
+ * dsph_poly_forward and dsph_healpix_pool then.  Workspace and flags as dsph_poly_forward_ex. */
+int dsph_plan_pool_fusable(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act);
+int dsph_poly_forward_pool(const dsph_plan* plan, const float* x, const float* w, const float* bias, float* y_scratch,
+                           float* y_pooled, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t basis, int32_t act,
+                           int32_t precision, int32_t pool_type, int32_t flags, void* workspace, size_t workspace_bytes,
+                           void* hip_stream);
+
 /* One recurrence step on (N, n_cols, F) planes:  out = alpha * (L~ @ in) - beta * prev
  * for rows [0, rows) of every map (rows <= n_rows; rows <= 0 means n_rows); prev may be NULL
  * when beta == 0.  Replaces one utils.split_sparse_dense_matmul call plus the `2*... - x0`

@@ -829,3 +829,91 @@ def test_kept_weight_images_across_batch_classes():
     for y, r in ((y1, ref[:1]), (y4, ref), (y4b, ref), (y1b, ref[:1]), (y1c, ref[:1])):
         assert rel_err(y.cpu().numpy(), r) < 2e-6
     assert torch.equal(y4, y4b) and torch.equal(y1, y1b) and torch.equal(y1, y1c)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# conv + HealpyPool(p = 1) in one forward (dsph_poly_forward_pool): the strip kernel of a first layer stores the pooled map
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("nside,N,Fin,Fout,K,basis,act,pool", [
+    (128, 4, 1, 16, 5, "chebyshev", "relu", "MAX"),    # the first layer of the networks, pairs of maps
+    (128, 3, 1, 16, 5, "chebyshev", "relu", "AVG"),    # the mean of the four children, an odd batch
+    (128, 2, 2, 32, 4, "monomial", None, "MAX"),       # two channels, 32 columns, K = 4
+    (256, 1, 1, 8, 3, "chebyshev", None, "AVG"),       # a single map, larger sphere (more row segments)
+    (128, 2, 1, 64, 5, "chebyshev", "relu", "MAX"),    # two 32-column blocks
+])
+def test_conv_and_pool_in_one_forward(nside, N, Fin, Fout, K, basis, act, pool, prec):
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    A = {None: _native.ACT_NONE, "relu": _native.ACT_RELU}[act]
+    assert _native.pool_fusable(plan, N, Fin, Fout, K, A)
+    assert not _native.pool_fusable(plan, N, 16, Fout, K, A), "only the level-packed kernel has the pooled epilogue"
+    assert not _native.pool_fusable(plan, N, Fin, Fout, K, _native.ACT_TANH), "deferred activations run before the pooling"
+    rng = np.random.default_rng(nside + Fout + K)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    P = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}[prec]
+    B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
+    T = _native.POOL_MAX if pool == "MAX" else _native.POOL_AVG
+    yp, ws, scr = _native.cheb_forward_pool(plan, _dev(x), _dev(W), _dev(b), K, pool_type=T, act=A, precision=P, basis=B)
+    # the two calls it replaces: bit for bit (same forward kernels, same order of the four children)
+    y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
+    y_ref = _native.healpix_pool(y, 4, T)
+    assert torch.equal(yp, y_ref), f"max |diff| {float((yp - y_ref).abs().max()):.3e}"
+    # and against the oracle
+    fwd = orc.chebyshev_forward if basis == "chebyshev" else orc.monomial_forward
+    ref = orc.healpy_pool(fwd(_csr(cols, vals), x, W, K, bias=b, activation=act), 1, pool)
+    tol = 2e-6 if prec != "bf16x3" else 2 * TOL
+    assert rel_err(yp.cpu().numpy(), ref) < tol
+    yp2, _, _ = _native.cheb_forward_pool(plan, _dev(x), _dev(W), _dev(b), K, pool_type=T, act=A, precision=P, basis=B, workspace=ws,
+                                          scratch=scr, keep_weights=True)
+    assert torch.equal(yp, yp2)
+
+
+@pytest.mark.parametrize("pool_type", ["MAX"])
+def test_model_fuses_a_first_layer_with_its_pooling(pool_type):
+    """HealpyGCNN (8-neighbour k-NN graphs, the reference's default) in inference: Chebyshev(1 -> 16, bias, ReLU) + HealpyPool(p=1)
+    run as one pass (Chebyshev.forward_pool), the later layers -- more input channels, or another activation -- as two; the
+    output equals the layer-by-layer walk bit for bit, and the float64 oracle composition to tolerance."""
+    from deepsphere import healpy_layers, healpy_networks
+
+    nside = 128  # (from here on a map has strip rectangles: below, every tile is on the tile kernels and nothing is fused)
+    indices = np.arange(12 * nside * nside)
+    layers = [healpy_layers.HealpyChebyshev(K=5, Fout=16, use_bias=True, activation="relu"),
+              healpy_layers.HealpyPool(p=1, pool_type=pool_type),
+              healpy_layers.HealpyChebyshev(K=5, Fout=8, use_bias=True, activation="elu"),
+              healpy_layers.HealpyPool(p=1, pool_type=pool_type)]
+    torch.manual_seed(3)
+    model = healpy_networks.HealpyGCNN(nside=nside, indices=indices, layers=layers, n_neighbors=8).cuda()
+    model.eval()
+    rng = np.random.default_rng(4)
+    x = _dev(rng.standard_normal((3, len(indices), 1)).astype(np.float32))
+    mods = list(model)
+    with torch.no_grad():
+        assert mods[0].forward_pool(x, pool_type) is not None, "the first layer has the fused pooling"
+        assert mods[2].forward_pool(torch.zeros((3, len(indices) // 4, 16), device="cuda"), pool_type) is None
+        y = model(x)
+        cur = x
+        for m in mods:
+            cur = m(cur)
+    assert torch.equal(y, cur)
+    # the oracle composition
+    ref, cur_nside, cur_idx = x.cpu().numpy().astype(np.float64), nside, np.asarray(indices)
+    for spec, mod in zip(layers, mods):
+        if isinstance(spec, healpy_layers.HealpyPool):
+            ref = orc.healpy_pool(ref, spec.p, spec.pool_type)
+            cur_idx = np.unique(cur_idx // 4)
+            cur_nside //= 2
+            continue
+        Lt, _ = orc.prepare_L(mod.L)  # (the graph the model built: the 8-neighbour k-NN Laplacian of this resolution)
+        Wk = mod.kernel.detach().cpu().numpy().astype(np.float64)
+        b = mod.bias.detach().cpu().numpy().reshape(-1).astype(np.float64) if mod.use_bias else None
+        ref = orc.chebyshev_forward(Lt, ref, Wk, spec.K, bias=b, activation=spec.activation)
+    assert rel_err(y.cpu().numpy(), ref) < 1e-5
+    # with autograd on the model takes the two layers (the fused pass has no backward)
+    xg = x.clone().requires_grad_(True)
+    assert mods[0].forward_pool(xg, pool_type) is None

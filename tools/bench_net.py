@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A DeepSphere-style stack end to end (SURVEY 8 f: the callers either side of the path): Chebyshev layers with NEST max-pooling
 between them, from nside 512 down to nside 8 -- the shapes a network has, first layers to the small maps at its end.
-    python tools/bench_net.py [batch] [knn]      (knn: the reference's 8-neighbour k-NN graphs instead of the grid stencil)
+    python tools/bench_net.py [batch] [knn] [nofuse]   (knn: the reference's 8-neighbour k-NN graphs instead of the grid stencil;
+                                                        nofuse: no conv + pool fusion)
 Prints one JSON line: ms per layer (HIP events) and for the whole forward."""
 import json
 import os
@@ -17,7 +18,8 @@ import bench  # noqa: E402
 from deepsphere import gnn_layers, healpy_layers  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-knn = len(sys.argv) > 2 and sys.argv[2] == "knn"
+knn = "knn" in sys.argv[2:]
+nofuse = "nofuse" in sys.argv[2:]  # every layer and every pooling on its own (default: conv + pool in one pass where the kernels can)
 dev = torch.device("cuda", 0)
 STACK = [(512, 1, 16), (256, 16, 32), (128, 32, 64), (64, 64, 64), (32, 64, 64), (16, 64, 128), (8, 128, 128)]
 layers = []
@@ -33,11 +35,17 @@ def forward(events=None):
     for i, layer in enumerate(layers):
         if events is not None:
             events[i][0].record()
-        x = layer(x)
-        if events is not None:
-            events[i][1].record()
-        if i + 1 < len(layers):
-            x = pool(x)
+        y = None if (nofuse or i + 1 == len(layers)) else layer.forward_pool(x, "MAX")
+        if y is None:
+            x = layer(x)
+            if events is not None:
+                events[i][1].record()
+            if i + 1 < len(layers):
+                x = pool(x)
+        else:
+            x = y
+            if events is not None:
+                events[i][1].record()
     return x
 
 
@@ -60,4 +68,5 @@ with torch.no_grad():
         per += np.array([s.elapsed_time(e) for s, e in ev]) / 10
 print(json.dumps({"stack": [f"nside {n}: {fi}->{fo}" for n, fi, fo in STACK], "K": 5, "batch": N, "graph": "knn8" if knn else "grid",
                   "layer_ms": [round(float(v), 3) for v in per], "forward_ms": round(total, 3),
-                  "note": "Chebyshev (bias, ReLU) + HealpyPool(MAX, p=1) between layers; layer_ms by one event pair per layer"}))
+                  "fused_pooling": not nofuse,
+                  "note": "Chebyshev (bias, ReLU) + HealpyPool(MAX, p=1) between layers; layer_ms by one event pair per layer (a layer that pools in its own epilogue: incl. the pooling)"}))
