@@ -1006,11 +1006,12 @@ static int istrip_nseg(const dsph_plan* plan, const FusedTiles& ft, int64_t N, i
   return it->second;
 }
 
-// conv + HealpyPool(p = 1) in one forward (launch_cheb_fused with a FusedPool): the level-packed strip kernel stores the pooled
-// map itself, the other tiles go through a full-resolution scratch.  One or two input channels (a first layer), whole unsharded
-// maps of whole tiles, bias and ReLU only (the other activations run as a separate pass over the full-resolution map).
+// conv + HealpyPool(p = 1) in one forward (launch_cheb_fused with a FusedPool): the input-side strip kernels store the pooled
+// map themselves, the other tiles go through a full-resolution scratch.  At most 16 input channels (the layers the input-side
+// strips take), whole unsharded maps of whole tiles, bias and ReLU only (the other activations run as a separate pass over the
+// full-resolution map).
 bool fused_pool_ok(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act) {
-  if (!plan->fused || N < 1 || !istrip_narrow(Fin) || !(act == DSPH_ACT_NONE || act == DSPH_ACT_RELU)) return false;
+  if (!plan->fused || N < 1 || !(act == DSPH_ACT_NONE || act == DSPH_ACT_RELU)) return false;
   if (!plan->levels.empty() || plan->n_cols != plan->n_rows || plan->n_rows % FUSED_P != 0 || K < 2 || K - 1 > FUSED_DMAX) return false;
   if (!fused_supported(plan, Fin, Fout, K)) return false;
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
@@ -1134,7 +1135,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
                       size_t workspace_bytes, hipStream_t stream, int32_t part, bool keep_weights, const FusedPool* pool) {
   if (pool != nullptr && !(part == 0 && fused_pool_ok(plan, N, Fin, Fout, K, act) && pool->y != nullptr && (pool->type == 1 || pool->type == 2) &&
                            ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(pool->y)) & 15) == 0)) {
-    set_error("cheb_fused: this plan / shape has no fused pooling (one or two input channels, whole unsharded maps, no or ReLU activation)");
+    set_error("cheb_fused: this plan / shape has no fused pooling (at most 16 input channels, whole unsharded maps, no or ReLU activation)");
     return DSPH_E_UNSUPPORTED;
   }
   // more than 64 output columns: one launch per 64-column block (the recurrence is repeated; still one pass

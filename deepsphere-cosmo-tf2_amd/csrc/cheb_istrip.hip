@@ -141,7 +141,7 @@ int launch_cheb_istrip(const IStripLaunch& s, hipStream_t stream) {
     a.nseg = s.nseg;
     a.cheb = s.cheb ? 1 : 0;
     a.pair = pair ? 1 : 0;
-    a.pool = narrow ? s.pool : 0;  // (only the level-packed kernel has the pooled epilogue; the caller checks: fused_pool_ok)
+    a.pool = s.pool;  // (both kernels have the pooled epilogue; the caller has checked the rest: fused_pool_ok)
     a.ypool = s.ypool ? s.ypool + cb : nullptr;
     a.ypool_rows = s.ypool_rows;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(narrow ? IS1_THREADS : IS_THREADS), 0, stream, a);

@@ -37,7 +37,7 @@ constexpr int IS_WAVES = 8;
 constexpr int IS_CRING = 6;                    // rows of L~ held per wave: ytop - 4 .. ytop + 1
 constexpr int IS_CROWB = 32 * 32 + 32 * 4;     // one ring row: [directions 0-3][px] | [directions 4-7][px] | [px] diagonal
 constexpr int IS_YSTB = 4096;                  // y staging block: 32 pixels x 32 channels
-constexpr int IS_WAVEB = IS_CRING * IS_CROWB + IS_YSTB;
+constexpr int IS_WAVEB = IS_CRING * IS_CROWB + 2 * IS_YSTB;  // (two y blocks: the pooled epilogue keeps an even and an odd row)
 
 struct IStripArgs {
   const float* x;
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
   const int nch = a.Fin;  // real channels (multiple of four); this lane's are CH * g .. CH * g + CH - 1
   const bool cheb = __builtin_amdgcn_readfirstlane(a.cheb) != 0;
   const bool all_ch = nch == 2 * CH || pairm;             // every lane's CH channels exist: no masking of the loads
+  const int pool = __builtin_amdgcn_readfirstlane(a.pool);  // pooled epilogue: see cheb_istrip1_kernel below
 
   for (int64_t q = q_begin + slot0 * IS_WAVES + wave; q < q_end; q += (int64_t)nslots * IS_WAVES) {
     const int n = (int)(q % NI);
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
     const int p = (int)(q / (2 * (int64_t)NI * a.nseg));
     StripPair pr = a.pairs[p];
     {
-      const int H = pr.y1 - pr.y0, ya = pr.y0 + (int)((int64_t)H * sg / a.nseg), yb = pr.y0 + (int)((int64_t)H * (sg + 1) / a.nseg);
+      const int H = pr.y1 - pr.y0, em = pool ? ~1 : ~0;  // (pooled: cuts at even rows)
+      const int ya = pr.y0 + ((int)((int64_t)H * sg / a.nseg) & em), yb = pr.y0 + ((int)((int64_t)H * (sg + 1) / a.nseg) & em);
       pr.y0 = ya;
       pr.y1 = yb;
       if (yb <= ya) continue;
@@ -218,7 +220,8 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
     const int n_y = pairm ? 2 * n + ((lane >> 2) & 1) : n;
     const bool y_live = n_y < a.N;
     const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)n_x * a.x_rows * xrowb;
-    char* __restrict__ ymap = reinterpret_cast<char*>(a.y) + (size_t)(y_live ? n_y : 0) * a.y_rows * yrowb;
+    char* __restrict__ ymap = pool ? reinterpret_cast<char*>(a.ypool) + (size_t)(y_live ? n_y : 0) * a.ypool_rows * yrowb
+                                   : reinterpret_cast<char*>(a.y) + (size_t)(y_live ? n_y : 0) * a.y_rows * yrowb;
     auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
       return st_spread((unsigned)min(max(yrow, pr.ylo), pr.yhi)) << 1;
     };
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
         auto run_base = [](unsigned run) -> unsigned { return run * 256u; };
         {
           const unsigned run = (unsigned)px >> 1;
-          unsigned char* wp = yst + run_base(run) + ((unsigned)px & 1u) * 128u;
+          unsigned char* wp = yst + (pool && (yr & 1) ? IS_YSTB : 0) + run_base(run) + ((unsigned)px & 1u) * 128u;
 #pragma unroll
           for (int tq = 0; tq < 4; ++tq)
             *reinterpret_cast<sp_f32x4*>(wp + (((unsigned)(2 * tq + g)) ^ (run & 7u)) * 16u) =
@@ -359,9 +362,9 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (yr >= pr.y0 && yr < pr.y1) {  // (wave-uniform)
+        const int och = 4 * (pairm ? lane & 3 : lane & 7);
+        if (pool == 0 && yr >= pr.y0 && yr < pr.y1) {  // (wave-uniform)
           const unsigned sY = st_spread((unsigned)yr) << 1;
-          const int och = 4 * (pairm ? lane & 3 : lane & 7);
           const sp_f32x4 bv = *reinterpret_cast<const sp_f32x4*>(sBias + och);
           sp_f32x4 yo4[4];
 #pragma unroll
@@ -379,6 +382,35 @@ __global__ __launch_bounds__(IS_THREADS, 2) void cheb_istrip_kernel(IStripArgs a
             for (int e4 = 0; e4 < 4; ++e4) o[e4] = fmaxf(yo4[k4][e4] + bv[e4], floor_v);
             // (the launch guarantees 16-byte stores: the block's width and the row stride of y are multiples of four)
             if (pk >= pfirst && pk < plast && och < a.Fout && y_live) *reinterpret_cast<sp_f32x4*>(dst) = o;
+          }
+        } else if (pool != 0 && (yr & 1) && yr >= pr.y0 && yr < pr.y1) {
+          // pooled epilogue (cheb_istrip1_kernel below): rows yr - 1 (block 0) and yr (block 1), the pixel pairs with an even x
+          const sp_f32x4 bv = *reinterpret_cast<const sp_f32x4*>(sBias + och);
+          const unsigned sYp = st_spread((unsigned)yr >> 1) << 1, cpl = (unsigned)lane & 7u, pl = (unsigned)lane >> 3;
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const unsigned pp = 8u * k2 + pl, pk0u = 2u * pp + ((unsigned)xs & 1u), pk1u = min(pk0u + 1u, 31u);
+            const unsigned off0 = run_base(pk0u >> 1) + (pk0u & 1u) * 128u + ((cpl ^ ((pk0u >> 1) & 7u))) * 16u;
+            const unsigned off1 = run_base(pk1u >> 1) + (pk1u & 1u) * 128u + ((cpl ^ ((pk1u >> 1) & 7u))) * 16u;
+            sp_f32x4 c[4];
+            c[0] = *reinterpret_cast<const sp_f32x4*>(yst + off0);
+            c[1] = *reinterpret_cast<const sp_f32x4*>(yst + off1);
+            c[2] = *reinterpret_cast<const sp_f32x4*>(yst + IS_YSTB + off0);
+            c[3] = *reinterpret_cast<const sp_f32x4*>(yst + IS_YSTB + off1);
+            sp_f32x4 o;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              float r = pool == 1 ? -__builtin_huge_valf() : 0.f;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float v = fmaxf(c[q][e4] + bv[e4], floor_v);
+                r = pool == 1 ? fmaxf(r, v) : r + v;
+              }
+              o[e4] = pool == 1 ? r : r * 0.25f;
+            }
+            const unsigned rid = st_spread(((unsigned)xs + pk0u) >> 1) | sYp;
+            float* dst = reinterpret_cast<float*>(ymap + (size_t)rid * yrowb) + och;
+            if ((int)pk0u >= pfirst && (int)pk0u + 1 < plast && och < a.Fout && y_live) *reinterpret_cast<sp_f32x4*>(dst) = o;
           }
         }
         __builtin_amdgcn_wave_barrier();  // (the block is rewritten in the next step)

@@ -843,6 +843,10 @@ def test_kept_weight_images_across_batch_classes():
     (128, 2, 2, 32, 4, "monomial", None, "MAX"),       # two channels, 32 columns, K = 4
     (256, 1, 1, 8, 3, "chebyshev", None, "AVG"),       # a single map, larger sphere (more row segments)
     (128, 2, 1, 64, 5, "chebyshev", "relu", "MAX"),    # two 32-column blocks
+    (128, 3, 16, 32, 5, "chebyshev", "relu", "MAX"),   # the second layer of the networks: the eight-channel form
+    (128, 2, 4, 8, 5, "chebyshev", None, "AVG"),       # 4 -> 8: the four-channel form with two maps per wave
+    (128, 2, 8, 48, 4, "monomial", "relu", "MAX"),     # both halves of the four-channel form, two column blocks, K = 4 (an odd strip origin)
+    (128, 1, 12, 16, 3, "chebyshev", None, "AVG"),     # twelve channels, K = 3
 ])
 def test_conv_and_pool_in_one_forward(nside, N, Fin, Fout, K, basis, act, pool, prec):
     cols, vals = _grid_ell(nside)
@@ -850,7 +854,7 @@ def test_conv_and_pool_in_one_forward(nside, N, Fin, Fout, K, basis, act, pool, 
     plan = _native.LaplacianPlan(cols, vals, device=0)
     A = {None: _native.ACT_NONE, "relu": _native.ACT_RELU}[act]
     assert _native.pool_fusable(plan, N, Fin, Fout, K, A)
-    assert not _native.pool_fusable(plan, N, 16, Fout, K, A), "only the level-packed kernel has the pooled epilogue"
+    assert not _native.pool_fusable(plan, N, 32, Fout, K, A), "only the input-side strip kernels have the pooled epilogue"
     assert not _native.pool_fusable(plan, N, Fin, Fout, K, _native.ACT_TANH), "deferred activations run before the pooling"
     rng = np.random.default_rng(nside + Fout + K)
     x = rng.standard_normal((N, M, Fin)).astype(np.float32)
