@@ -1006,17 +1006,18 @@ static int istrip_nseg(const dsph_plan* plan, const FusedTiles& ft, int64_t N, i
   return it->second;
 }
 
-// conv + HealpyPool(p = 1) in one forward (launch_cheb_fused with a FusedPool): the input-side strip kernels store the pooled
-// map themselves, the other tiles go through a full-resolution scratch.  At most 16 input channels (the layers the input-side
-// strips take), whole unsharded maps of whole tiles, bias and ReLU only (the other activations run as a separate pass over the
-// full-resolution map).
+// conv + HealpyPool(p = 1) in one forward (launch_cheb_fused with a FusedPool): the input-side strip kernels and the structured
+// kernel store the pooled map themselves, the BFS tiles go through a full-resolution scratch.  Every layer whose tiles those
+// kernels take -- not the 64 -> 64 shape on maps large enough for the Clenshaw strips --, whole unsharded maps of whole tiles,
+// a width that is a multiple of four, bias and ReLU only (the other activations run as a separate pass over the full-resolution map).
 bool fused_pool_ok(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act) {
   if (!plan->fused || N < 1 || !(act == DSPH_ACT_NONE || act == DSPH_ACT_RELU)) return false;
   if (!plan->levels.empty() || plan->n_cols != plan->n_rows || plan->n_rows % FUSED_P != 0 || K < 2 || K - 1 > FUSED_DMAX) return false;
   if (!fused_supported(plan, Fin, Fout, K)) return false;
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
-  return ft.ok && ft.n_part != ft.ntiles && istrips_apply(plan, ft, pad4(Fin), K, std::min(Fout, 64), Fout) &&
-         (Fout <= 64 || Fout % 64 == 0 || istrips_apply(plan, ft, pad4(Fin), K, Fout % 64, Fout));
+  if (!ft.ok || ft.n_part == ft.ntiles || Fout % 4 != 0) return false;  // (every tile on the BFS kernel: nothing to fuse)
+  // the Clenshaw strip kernel has no pooled epilogue: not where it would take tiles (either precision could be asked for)
+  return !strips_apply(plan, ft, pad4(Fin), std::min(Fout, 64), K, DSPH_PREC_BF16X3, N, Fout);
 }
 
 
@@ -1135,7 +1136,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
                       size_t workspace_bytes, hipStream_t stream, int32_t part, bool keep_weights, const FusedPool* pool) {
   if (pool != nullptr && !(part == 0 && fused_pool_ok(plan, N, Fin, Fout, K, act) && pool->y != nullptr && (pool->type == 1 || pool->type == 2) &&
                            ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(pool->y)) & 15) == 0)) {
-    set_error("cheb_fused: this plan / shape has no fused pooling (at most 16 input channels, whole unsharded maps, no or ReLU activation)");
+    set_error("cheb_fused: this plan / shape has no fused pooling (whole unsharded maps, no or ReLU activation, not the Clenshaw strips' shape)");
     return DSPH_E_UNSUPPORTED;
   }
   // more than 64 output columns: one launch per 64-column block (the recurrence is repeated; still one pass
@@ -1193,10 +1194,12 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
   }
   for (int32_t cb = 0; cb < Fout; cb += 64) {
     unsigned char* blk_ws = static_cast<unsigned char*>(workspace) + (size_t)(cb / 64) * blk_frag;  // this block's weight images
+    const FusedPool pool_blk{pool ? pool->y + cb : nullptr, pool ? pool->type : 0};  // (this block's columns of the pooled map)
+    const FusedPool* pool_b = pool ? &pool_blk : nullptr;
     auto run = [&](hipStream_t st, int32_t only) {
       return launch_fused_common(plan, x, w + cb, bias ? bias + cb : nullptr, y + cb, nullptr, N, Fin,
                                  std::min<int32_t>(64, Fout - cb), K, defer_act ? DSPH_ACT_NONE : act, precision, alpha_rest,
-                                 beta_rest, blk_ws, blk_frag, st, nullptr, nullptr, Fout, part, Fin_w, only, keep_weights, pool);
+                                 beta_rest, blk_ws, blk_frag, st, nullptr, nullptr, Fout, part, Fin_w, only, keep_weights, pool_b);
     };
     if (fork) {
       std::unique_lock<std::mutex> lock(fp->fork_mu);
@@ -1226,13 +1229,10 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
     if (rc != DSPH_OK) return rc;
   }
   if (pool != nullptr) {
-    // the tiles the strips did not take: their full-resolution rows are in y (scratch), reduced here into the pooled map
+    // the BFS tiles (class G): their full-resolution rows are in y (scratch), reduced here into the pooled map; the input-side
+    // strips and the structured kernel have stored theirs pooled
     const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
-    const bool maxp = pool->type == 1;
-    int rc = launch_healpix_pool_tiles(y, pool->y, ft.d_rrest, ft.n_rrest, N, plan->n_rows, Fout, maxp, stream);
-    if (rc == DSPH_OK) rc = launch_healpix_pool_tiles(y, pool->y, ft.d_tlist, ft.n_t, N, plan->n_rows, Fout, maxp, stream);
-    if (rc == DSPH_OK) rc = launch_healpix_pool_tiles(y, pool->y, ft.d_part, ft.n_part, N, plan->n_rows, Fout, maxp, stream);
-    return rc;
+    return launch_healpix_pool_tiles(y, pool->y, ft.d_part, ft.n_part, N, plan->n_rows, Fout, pool->type == 1, stream);
   }
   if (defer_act) {
     const int64_t orows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
@@ -1382,6 +1382,11 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     sl.cheb = beta_rest != 0.f;
     sl.prep_weights = !keep_weights;  // the first of the two launches packs the fragments
     sl.allow_pack = plan->opt.pack;
+    if (pool != nullptr) {
+      sl.pool = pool->type;
+      sl.ypool = pool->y;
+      sl.ypool_rows = plan->n_rows / 4;
+    }
     // rectangles of interior class-R tiles: the strip kernel, when it has this shape; the class-R list shrinks to the rest
     const bool strips = strips_apply(plan, ft, Fin, Fout, K, precision, N, ld) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     if (strips && part != 2 && !dbg_only('b')) {

@@ -276,6 +276,9 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
   a.C = C;
   a.act = s.act;
   a.ld = s.ld;
+  a.pool = s.pool;
+  a.ypool = s.ypool;
+  a.ypool_rows = s.ypool_rows;
   const int grid = std::max(8, std::min(s.num_cu, (s.ntiles + 7) / 8 * 8));
 #ifdef DSPH_STAMPS
   static unsigned long long* d_stamps = nullptr;

@@ -107,6 +107,11 @@ struct StructArgs {
   // columns (64 / P) q ..: struct_wprep_kernel), the store sends every column group to its own map.  N is then the number of
   // groups, n_maps the batch.  (The same form as FusedArgs::pack, cheb_fused_kernel.h.)
   int pack, n_maps;
+  // conv + HealpyPool(p = 1) in one forward (pool = 1 max, 2 mean; see cheb_istrip1_kernel): the store reduces the four NEST
+  // children -- a 2 x 2 pixel block of the tile, all in the wave's transposition block -- and writes the pooled map only
+  float* ypool;
+  int64_t ypool_rows;
+  int pool;
 #ifdef DSPH_STAMPS
   unsigned long long* stamps;  // diagnostic build only: [8 waves][8 items][32 points] s_memtime values
 #endif
@@ -370,7 +375,8 @@ template <int NB>
 __device__ __forceinline__ void st_store(const st_f32x16 (&acc)[2][NB], unsigned char* __restrict__ smem, unsigned plane,
                                          int cw, float* __restrict__ ytile, int ld, const float* __restrict__ sBias,
                                          int lane, int Fout, float floor_v, bool vec, int pack = 0, int64_t map_stride = 0,
-                                         int maps_left = 4) {  // pack = P: ytile is map P n's, maps_left = n_maps - P n
+                                         int maps_left = 4,  // pack = P: ytile is map P n's, maps_left = n_maps - P n
+                                         int pool = 0) {     // pool: ytile / map_stride are the POOLED map's (64 rows per tile)
   if (ST_ABL_SKIP & 8) return;
   const unsigned r = lane & 31, h = lane >> 5, j = lane & 7, pq = lane >> 3;
   // byte a of the 4 KiB block lives in chunk a >> 9 (512 B = the 8 cells of one column parity of one tile pixel row)
@@ -393,6 +399,24 @@ __device__ __forceinline__ void st_store(const st_f32x16 (&acc)[2][NB], unsigned
       const int ch = pack ? ch0 & ((1 << gsh) - 1) : ch0;       // column of y
       const bool live = !pack || (ch0 >> gsh) < maps_left;      // (a batch that ends inside the group)
       float* __restrict__ ymap = ytile + (pack && live ? (int64_t)(ch0 >> gsh) * map_stride : 0);
+      if (pool) {
+        // the block holds the tile's pixel rows 4 cw + 2 pb and + 1 (p = 0 .. 15 and 16 .. 31): pooled pixel (pq, 2 cw + pb) of the
+        // pooled tile from the children p = 2 pq, 2 pq + 1, 16 + 2 pq, 17 + 2 pq, in that (row) order
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pool == 1) o = make_float4(-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf());
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned p = 2u * pq + (q & 1u) + 16u * (q >> 1);
+          const float4 v = *reinterpret_cast<const float4*>(smem + scr(p * 128u + 16u * (j ^ (p & 7u))));
+          const float vx = fmaxf(v.x + bv.x, floor_v), vy = fmaxf(v.y + bv.y, floor_v), vz = fmaxf(v.z + bv.z, floor_v), vw = fmaxf(v.w + bv.w, floor_v);
+          if (pool == 1) { o.x = fmaxf(o.x, vx); o.y = fmaxf(o.y, vy); o.z = fmaxf(o.z, vz); o.w = fmaxf(o.w, vw); }
+          else { o.x += vx; o.y += vy; o.z += vz; o.w += vw; }
+        }
+        if (pool != 1) { o.x *= 0.25f; o.y *= 0.25f; o.z *= 0.25f; o.w *= 0.25f; }
+        float* __restrict__ yp = ymap + (int64_t)st_morton(pq, 2u * cw + pb) * ld + ch;
+        if (ch < Fout && live) *reinterpret_cast<float4*>(yp) = o;  // (the launch guarantees 16-byte stores when pooling)
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const unsigned p = pq + 8 * i;  // pixel (p & 15, 4 cw + 2 pb + (p >> 4)) of the tile
@@ -803,10 +827,11 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     if (!pend) return;
     st_contract<NB, PREC>(smem, pend_plane, pend_w, mb, lane, acc);
     if (pend_store) {  // that completed a map: y, then fresh accumulators
-      float* __restrict__ yt = a.y + ((int64_t)(a.pack ? a.pack * pend_n : pend_n) * a.y_rows + pend_row0) * a.ld;
+      float* __restrict__ yt = a.pool ? a.ypool + ((int64_t)(a.pack ? a.pack * pend_n : pend_n) * a.ypool_rows + (pend_row0 >> 2)) * a.ld
+                                      : a.y + ((int64_t)(a.pack ? a.pack * pend_n : pend_n) * a.y_rows + pend_row0) * a.ld;
       st_store<NB>(acc, smem, pend_plane, cw, yt, a.ld, sBias, lane, a.Fout,
-                   a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf(), vec_ok, a.pack, a.y_rows * (int64_t)a.ld,
-                   a.n_maps - a.pack * pend_n);
+                   a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf(), vec_ok, a.pack, (a.pool ? a.ypool_rows : a.y_rows) * (int64_t)a.ld,
+                   a.n_maps - a.pack * pend_n, a.pool);
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
 #pragma unroll

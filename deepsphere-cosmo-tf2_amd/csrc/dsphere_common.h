@@ -160,6 +160,9 @@ struct StructLaunch {
   const float* tabvals = nullptr;   // (null: class-R tiles, rows by Morton arithmetic, values from gvals8 / gdiag)
   bool prep_weights = true;         // pack the weight fragments first (false: an earlier launch of this forward did)
   bool allow_pack = true;           // DSPH_OPT_PACK of the plan
+  float* ypool = nullptr;           // pool != 0: the 2 x 2 pooled output (n_rows / 4 rows per map); y is not written
+  int64_t ypool_rows = 0;
+  int32_t pool = 0;                 // 0 none, 1 max, 2 mean
 };
 int struct_build_rows(const dsph_plan* plan, float** gvals8, float** gdiag, unsigned char** flag);
 int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, int ntiles, int D, int64_t out_rows,

@@ -388,8 +388,8 @@ class Chebyshev(torch.nn.Module):
 
     def forward_pool(self, input_tensor, pool_type="MAX"):
         """``HealpyPool(p=1, pool_type)(self(input_tensor))`` in ONE pass where the kernels can (``dsph_poly_forward_pool``: a
-        layer with at most 16 input channels -- the first layers of a network -- without batch norm, activation none or ReLU,
-        inference, whole unsharded maps): the strip kernel reduces the four NEST children in its epilogue and the full-resolution output, 16 times the
+        layer without batch norm, activation none or ReLU, a width that is a multiple of four, inference, whole unsharded maps --
+        every shape but 64 -> 64 on maps large enough for the Clenshaw strips): the strip kernel reduces the four NEST children in its epilogue and the full-resolution output, 16 times the
         input of a 1 -> 16 layer, is never written.  Returns ``None`` when it cannot -- the caller then runs the two layers
         (``HealpyGCNN.forward`` does).  Same values as the two layers (bit for bit for "MAX")."""
         if pool_type not in ("MAX", "AVG") or self.use_bn or not isinstance(input_tensor, torch.Tensor) or input_tensor.dim() != 3:

@@ -244,12 +244,13 @@ int dsph_poly_forward_ex(const dsph_plan* plan, const float* x, const float* w, 
 
 /* The forward followed by HealpyPool(p = 1) (reference healpy_layers.py:20-63: MaxPool1D / AveragePooling1D with pool size 4 over
  * the NEST-ordered pixels, after gnn_layers.py:106-161) in one call: y_pooled (N, n_rows / 4, Fout) = pool(act(conv(x) + bias)).
- * The input-side strip kernels (layers with at most 16 input channels: the first layers of a network) reduce the four children in
- * their epilogue and store the pooled map only -- the full-resolution output of a 1 -> 16 layer is 16 times its input and, with the pooling's read of it, most of that
- * layer's time; the tiles the strips do not take are written at full resolution into `y_scratch` (N, n_rows, Fout; contents
+ * The input-side strip kernels and the structured-tile kernel reduce the four children in their store step and write the pooled map
+ * only -- the full-resolution output of a 1 -> 16 layer is 16 times its input and, with the pooling's read of it, most of that
+ * layer's time; the tiles of the BFS-tile kernel are written at full resolution into `y_scratch` (N, n_rows, Fout; contents
  * afterwards unspecified) and reduced from there.  Same values as the two calls (bit for bit for the maximum; the mean adds the
  * children in the same order).  pool_type: DSPH_POOL_MAX | DSPH_POOL_AVG.  Availability: dsph_plan_pool_fusable (whole
- * unsharded maps of whole tiles, at most 16 input channels, activation none or ReLU); DSPH_E_UNSUPPORTED otherwise -- run
+ * unsharded maps of whole tiles, a width that is a multiple of four, activation none or ReLU, not the 64 -> 64 shape where the
+ * Clenshaw strip kernel takes tiles); DSPH_E_UNSUPPORTED otherwise -- run
  * dsph_poly_forward and dsph_healpix_pool then.  Workspace and flags as dsph_poly_forward_ex. */
 int dsph_plan_pool_fusable(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act);
 int dsph_poly_forward_pool(const dsph_plan* plan, const float* x, const float* w, const float* bias, float* y_scratch,

@@ -847,6 +847,10 @@ def test_kept_weight_images_across_batch_classes():
     (128, 2, 4, 8, 5, "chebyshev", None, "AVG"),       # 4 -> 8: the four-channel form with two maps per wave
     (128, 2, 8, 48, 4, "monomial", "relu", "MAX"),     # both halves of the four-channel form, two column blocks, K = 4 (an odd strip origin)
     (128, 1, 12, 16, 3, "chebyshev", None, "AVG"),     # twelve channels, K = 3
+    (64, 4, 32, 64, 5, "chebyshev", "relu", "MAX"),    # 32 inputs: every structured tile pools in the structured kernel's store
+    (64, 2, 64, 128, 5, "chebyshev", "relu", "AVG"),   # two 64-column blocks, four slices (a map too small for the Clenshaw strips)
+    (32, 3, 4, 8, 5, "monomial", None, "MAX"),         # packed maps (four to an item) with the pooled store, no strips at all
+    (128, 2, 1, 96, 5, "chebyshev", "relu", "MAX"),    # a first layer with three 32-column blocks over two 64-column launches
 ])
 def test_conv_and_pool_in_one_forward(nside, N, Fin, Fout, K, basis, act, pool, prec):
     cols, vals = _grid_ell(nside)
@@ -854,7 +858,7 @@ def test_conv_and_pool_in_one_forward(nside, N, Fin, Fout, K, basis, act, pool, 
     plan = _native.LaplacianPlan(cols, vals, device=0)
     A = {None: _native.ACT_NONE, "relu": _native.ACT_RELU}[act]
     assert _native.pool_fusable(plan, N, Fin, Fout, K, A)
-    assert not _native.pool_fusable(plan, N, 32, Fout, K, A), "only the input-side strip kernels have the pooled epilogue"
+    assert not _native.pool_fusable(plan, N, Fin, Fout + 1, K, A), "pooled stores are 16 bytes wide"
     assert not _native.pool_fusable(plan, N, Fin, Fout, K, _native.ACT_TANH), "deferred activations run before the pooling"
     rng = np.random.default_rng(nside + Fout + K)
     x = rng.standard_normal((N, M, Fin)).astype(np.float32)

@@ -53,13 +53,14 @@ with torch.no_grad():
     for _ in range(3):
         forward()
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(20):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in evs:
+        a.record()
         forward()
-    b.record()
+        b.record()
     torch.cuda.synchronize()
-    total = a.elapsed_time(b) / 20
+    each = sorted(a.elapsed_time(b) for a, b in evs)
+    total = each[len(each) // 2]  # median of 20 forwards (one event pair each)
     per = np.zeros(len(layers))
     for _ in range(10):
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in layers]
@@ -68,5 +69,6 @@ with torch.no_grad():
         per += np.array([s.elapsed_time(e) for s, e in ev]) / 10
 print(json.dumps({"stack": [f"nside {n}: {fi}->{fo}" for n, fi, fo in STACK], "K": 5, "batch": N, "graph": "knn8" if knn else "grid",
                   "layer_ms": [round(float(v), 3) for v in per], "forward_ms": round(total, 3),
+                  "forward_ms_min_max": [round(each[0], 3), round(each[-1], 3)],
                   "fused_pooling": not nofuse,
                   "note": "Chebyshev (bias, ReLU) + HealpyPool(MAX, p=1) between layers; layer_ms by one event pair per layer (a layer that pools in its own epilogue: incl. the pooling)"}))
