@@ -1006,16 +1006,16 @@ static int istrip_nseg(const dsph_plan* plan, const FusedTiles& ft, int64_t N, i
   return it->second;
 }
 
-// conv + HealpyPool(p = 1) in one forward (launch_cheb_fused with a FusedPool): the input-side strip kernels and the structured
-// kernel store the pooled map themselves, the BFS tiles go through a full-resolution scratch.  Every layer whose tiles those
-// kernels take -- not the 64 -> 64 shape on maps large enough for the Clenshaw strips --, whole unsharded maps of whole tiles,
+// conv + HealpyPool(p = 1) in one forward (launch_cheb_fused with a FusedPool): the input-side strip kernels, the structured
+// kernel and the BFS-tile kernel store the pooled map themselves.  Every layer whose tiles those kernels take -- not the
+// 64 -> 64 shape on maps large enough for the Clenshaw strips --, whole unsharded maps of whole tiles,
 // a width that is a multiple of four, bias and ReLU only (the other activations run as a separate pass over the full-resolution map).
 bool fused_pool_ok(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act) {
   if (!plan->fused || N < 1 || !(act == DSPH_ACT_NONE || act == DSPH_ACT_RELU)) return false;
   if (!plan->levels.empty() || plan->n_cols != plan->n_rows || plan->n_rows % FUSED_P != 0 || K < 2 || K - 1 > FUSED_DMAX) return false;
   if (!fused_supported(plan, Fin, Fout, K)) return false;
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
-  if (!ft.ok || ft.n_part == ft.ntiles || Fout % 4 != 0) return false;  // (every tile on the BFS kernel: nothing to fuse)
+  if (!ft.ok || Fout % 4 != 0) return false;  // (pooled stores are 16 bytes wide)
   // the Clenshaw strip kernel has no pooled epilogue: not where it would take tiles (either precision could be asked for)
   return !strips_apply(plan, ft, pad4(Fin), std::min(Fout, 64), K, DSPH_PREC_BF16X3, N, Fout);
 }
@@ -1229,10 +1229,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
     if (rc != DSPH_OK) return rc;
   }
   if (pool != nullptr) {
-    // the BFS tiles (class G): their full-resolution rows are in y (scratch), reduced here into the pooled map; the input-side
-    // strips and the structured kernel have stored theirs pooled
-    const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
-    return launch_healpix_pool_tiles(y, pool->y, ft.d_part, ft.n_part, N, plan->n_rows, Fout, pool->type == 1, stream);
+    return DSPH_OK;  // (every kernel has stored its tiles pooled; y, the scratch of the C ABI, stays untouched)
   }
   if (defer_act) {
     const int64_t orows = plan->levels.empty() ? plan->n_rows : plan->levels[0];
@@ -1491,6 +1488,9 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   args.n_maps = (int)N;
   args.pack = pack;
   args.num_cu = plan->fused->num_cu;
+  args.pool = pool ? pool->type : 0;
+  args.ypool = pool ? pool->y : nullptr;
+  args.ypool_rows = plan->n_rows / 4;
   args.Fin = Fin;
   args.Fout = Fout;
   args.ld = ld;

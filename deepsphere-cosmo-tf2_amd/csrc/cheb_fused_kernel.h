@@ -54,6 +54,11 @@ struct FusedArgs {
   // 16 q ..; the store sends each 16-column group to its own map.  N is then the number of GROUPS, n_maps the batch.
   // pack = 2: eight input channels, at most 32 columns, two maps of two slots and 32 columns each.
   int pack, n_maps;
+  // conv + HealpyPool(p = 1) in one forward (pool = 1 max, 2 mean): a tile is 256 consecutive NEST rows, the four children of a
+  // coarse pixel four consecutive rows of the wave's 32 x 32 block -- the store reduces them and writes the pooled map only
+  float* ypool;
+  int64_t ypool_rows;
+  int pool;
   int num_cu;  // (host side: CUs of the device, for the split of a small map's batch over gridDim.y)
   int dbg;  // timing-only ablation bits (DSPH_FUSED_DEBUG): 1 no recurrence, 2 no contraction, 8 no y store
 };
@@ -401,6 +406,26 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       const int gsh = a.pack == 4 ? 4 : 5;  // log2 of the columns per map
       const int ymap = a.pack ? a.pack * pend_n + (cq >> gsh) : pend_n, ycol = a.pack ? cq & ((1 << gsh) - 1) : cq;
       const bool ylive = !a.pack || ymap < a.n_maps;
+      if (VEC && a.pool) {
+        // pooled row rsub of this wave's eight: rows 4 rsub .. 4 rsub + 3 of the block, bias and activation first, in row order
+        float4 o = a.pool == 1 ? make_float4(-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf())
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = *reinterpret_cast<const float4*>(tw + (4 * rsub + q) * T_LD + cq0);
+          v.x = apply_act(v.x + bv.x, act);
+          v.y = apply_act(v.y + bv.y, act);
+          v.z = apply_act(v.z + bv.z, act);
+          v.w = apply_act(v.w + bv.w, act);
+          if (a.pool == 1) { o.x = fmaxf(o.x, v.x); o.y = fmaxf(o.y, v.y); o.z = fmaxf(o.z, v.z); o.w = fmaxf(o.w, v.w); }
+          else { o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+        }
+        if (a.pool != 1) { o.x *= 0.25f; o.y *= 0.25f; o.z *= 0.25f; o.w *= 0.25f; }
+        float* __restrict__ ypp = a.ypool + ((int64_t)(ylive ? ymap : 0) * a.ypool_rows + ((pend_row0 + wave * 32) >> 2) + rsub) * a.ld + ycol;
+        if (wave * 32 + 4 * rsub + 3 < pend_Pt && ylive && ycol < a.Fout) *reinterpret_cast<float4*>(ypp) = o;
+        lds_wave_sync();
+        continue;
+      }
       float* __restrict__ yp0 = a.y + ((int64_t)(ylive ? ymap : 0) * a.y_rows + pend_row0 + wave * 32 + rsub) * a.ld + ycol;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {

@@ -248,7 +248,7 @@ int dsph_poly_forward_pool(const dsph_plan* p, const float* x, const float* w, c
   if (flags & ~DSPH_FWD_KEEP_WEIGHTS) { set_error("poly_forward_pool: unknown flags %d", flags); return DSPH_E_BADARG; }
   if (basis != DSPH_BASIS_CHEBYSHEV && basis != DSPH_BASIS_MONOMIAL) { set_error("poly_forward_pool: unknown basis %d", basis); return DSPH_E_BADARG; }
   if (pool_type != DSPH_POOL_MAX && pool_type != DSPH_POOL_AVG) { set_error("poly_forward_pool: unknown pool type %d", pool_type); return DSPH_E_BADARG; }
-  if (!p || !x || !w || !y_scratch || !y_pooled || N <= 0 || Fin <= 0 || Fout <= 0 || K <= 0) {
+  if (!p || !x || !w || !y_pooled || N <= 0 || Fin <= 0 || Fout <= 0 || K <= 0) {
     set_error("poly_forward_pool: bad arguments (NULL pointer or non-positive size)");
     return DSPH_E_BADARG;
   }

@@ -106,8 +106,6 @@ struct FusedPool {
   int32_t type;
 };
 bool fused_pool_ok(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act);
-int launch_healpix_pool_tiles(const float* x, float* y, const int32_t* tiles, int ntiles, int64_t N, int64_t rows_in, int32_t F, bool maxp,
-                              hipStream_t stream);
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
                       int32_t precision, float alpha_rest, float beta_rest, void* workspace,

@@ -70,49 +70,6 @@ __global__ __launch_bounds__(256) void healpix_pool_backward_kernel(const float*
   }
 }
 
-// The same reduction for the rows of a list of 256-row tiles only (p = 1): the tiles of a fused conv + pool forward whose
-// full-resolution y the tile kernels wrote (cheb_fused.hip: the strips store the pooled map themselves).
-template <bool MAXP>
-__global__ __launch_bounds__(256) void healpix_pool_tiles_kernel(const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ tiles,
-                                                                 int ntiles, int N, int64_t rows_in, int F) {
-  const int Q = F / 4;
-  const int64_t total = (int64_t)ntiles * N * 64 * Q;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int q = (int)(e % Q);
-    const int r = (int)((e / Q) % 64);
-    const int n = (int)((e / ((int64_t)Q * 64)) % N);
-    const int t = tiles[e / ((int64_t)Q * 64 * N)];
-    const float* src = x + ((int64_t)n * rows_in + (int64_t)t * 256 + 4 * r) * F + 4 * q;
-    float acc[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) acc[v] = MAXP ? -__builtin_huge_valf() : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 f = *reinterpret_cast<const float4*>(src + (int64_t)i * F);
-      acc[0] = MAXP ? fmaxf(acc[0], f.x) : acc[0] + f.x;
-      acc[1] = MAXP ? fmaxf(acc[1], f.y) : acc[1] + f.y;
-      acc[2] = MAXP ? fmaxf(acc[2], f.z) : acc[2] + f.z;
-      acc[3] = MAXP ? fmaxf(acc[3], f.w) : acc[3] + f.w;
-    }
-    if (!MAXP) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) acc[v] *= 0.25f;
-    }
-    *reinterpret_cast<float4*>(y + ((int64_t)n * (rows_in / 4) + (int64_t)t * 64 + r) * F + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  }
-}
-
-int launch_healpix_pool_tiles(const float* x, float* y, const int32_t* tiles, int ntiles, int64_t N, int64_t rows_in, int32_t F, bool maxp,
-                              hipStream_t stream) {
-  if (ntiles <= 0 || N <= 0) return DSPH_OK;
-  const int64_t total = (int64_t)ntiles * N * 64 * (F / 4);
-  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20);
-  if (maxp) hipLaunchKernelGGL((healpix_pool_tiles_kernel<true>), dim3(grid), dim3(256), 0, stream, x, y, tiles, ntiles, (int)N, rows_in, (int)F);
-  else hipLaunchKernelGGL((healpix_pool_tiles_kernel<false>), dim3(grid), dim3(256), 0, stream, x, y, tiles, ntiles, (int)N, rows_in, (int)F);
-  DSPH_HIP(hipGetLastError());
-  return DSPH_OK;
-}
-
 static unsigned pool_grid(int64_t total) { return (unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20); }
 
 int launch_healpix_pool(const float* x, float* y, int64_t rows_out, int32_t F, int32_t group, bool maxp, hipStream_t stream) {

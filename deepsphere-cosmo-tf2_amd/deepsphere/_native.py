@@ -312,11 +312,10 @@ def pool_fusable(plan, N, Fin, Fout, K, act=ACT_NONE):
     return bool(lib().dsph_plan_pool_fusable(plan.handle, int(N), int(Fin), int(Fout), int(K), int(act)))
 
 
-def cheb_forward_pool(plan, x, w, bias, K, pool_type=POOL_MAX, act=ACT_NONE, precision=PREC_FP32, workspace=None, scratch=None,
+def cheb_forward_pool(plan, x, w, bias, K, pool_type=POOL_MAX, act=ACT_NONE, precision=PREC_FP32, workspace=None,
                       basis=BASIS_CHEBYSHEV, keep_weights=False):
-    """pool(act(conv(x) + bias)) with HealpyPool(p = 1) reduced in the strip kernel's epilogue (``dsph_poly_forward_pool``):
-    -> (y_pooled (N, rows / 4, Fout), workspace, scratch).  ``scratch`` (N, rows, Fout) holds the full-resolution rows of the
-    tiles the strips do not take; pass the returned one back in to reuse it."""
+    """pool(act(conv(x) + bias)) with HealpyPool(p = 1) reduced in the kernels' store step (``dsph_poly_forward_pool``):
+    -> (y_pooled (N, rows / 4, Fout), workspace).  The full-resolution output is never written."""
     import torch
 
     _check_dev(x, plan, "x")
@@ -327,16 +326,14 @@ def cheb_forward_pool(plan, x, w, bias, K, pool_type=POOL_MAX, act=ACT_NONE, pre
     if need > 0 and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
         keep_weights = False
-    if scratch is None or tuple(scratch.shape) != (N, rows, Fout):
-        scratch = torch.empty((N, rows, Fout), dtype=torch.float32, device=x.device)
     out = torch.empty((N, rows // 4, Fout), dtype=torch.float32, device=x.device)
     rc = lib().dsph_poly_forward_pool(
-        plan.handle, _ptr(x), _ptr(w), _ptr(bias), _ptr(scratch), _ptr(out), int(N), int(Fin), Fout, int(K), int(basis), int(act),
+        plan.handle, _ptr(x), _ptr(w), _ptr(bias), _c_vp(), _ptr(out), int(N), int(Fin), Fout, int(K), int(basis), int(act),
         int(precision), int(pool_type), FWD_KEEP_WEIGHTS if (keep_weights and need > 0) else 0,
         _ptr(workspace) if need > 0 else _c_vp(), (workspace.numel() * workspace.element_size()) if need > 0 else 0,
         _stream_ptr(x.device))
     check(rc, "dsph_poly_forward_pool")
-    return out, workspace, scratch
+    return out, workspace
 
 
 def cheb_step(plan, inp, prev, alpha, beta, rows=0, out=None):

@@ -417,9 +417,9 @@ class Chebyshev(torch.nn.Module):
         bias = self.bias.detach().reshape(-1).contiguous() if self.use_bias else None
         wkey = (self.kernel.data_ptr(), self.kernel._version, self._prec_code(), (self.algo, N > 1),
                 None if self._workspace is None else self._workspace.data_ptr())
-        y, self._workspace, self._pool_scratch = _native.cheb_forward_pool(
+        y, self._workspace = _native.cheb_forward_pool(
             plan, x, self.kernel.detach(), bias, self.K, pool_type=_native.POOL_MAX if pool_type == "MAX" else _native.POOL_AVG,
-            act=self._act_code, precision=self._prec_code(), workspace=self._workspace, scratch=getattr(self, "_pool_scratch", None),
+            act=self._act_code, precision=self._prec_code(), workspace=self._workspace,
             basis=self._basis, keep_weights=getattr(self, "_wkey", None) == wkey)
         self._wkey = wkey[:4] + (self._workspace.data_ptr() if self._workspace is not None else None,)
         return y

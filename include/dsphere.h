@@ -244,10 +244,10 @@ int dsph_poly_forward_ex(const dsph_plan* plan, const float* x, const float* w, 
 
 /* The forward followed by HealpyPool(p = 1) (reference healpy_layers.py:20-63: MaxPool1D / AveragePooling1D with pool size 4 over
  * the NEST-ordered pixels, after gnn_layers.py:106-161) in one call: y_pooled (N, n_rows / 4, Fout) = pool(act(conv(x) + bias)).
- * The input-side strip kernels and the structured-tile kernel reduce the four children in their store step and write the pooled map
+ * The input-side strip kernels and both tile kernels reduce the four children in their store step and write the pooled map
  * only -- the full-resolution output of a 1 -> 16 layer is 16 times its input and, with the pooling's read of it, most of that
- * layer's time; the tiles of the BFS-tile kernel are written at full resolution into `y_scratch` (N, n_rows, Fout; contents
- * afterwards unspecified) and reduced from there.  Same values as the two calls (bit for bit for the maximum; the mean adds the
+ * layer's time; `y_scratch` is not used any more (every kernel pools in
+ * its store) and may be NULL.  Same values as the two calls (bit for bit for the maximum; the mean adds the
  * children in the same order).  pool_type: DSPH_POOL_MAX | DSPH_POOL_AVG.  Availability: dsph_plan_pool_fusable (whole
  * unsharded maps of whole tiles, a width that is a multiple of four, activation none or ReLU, not the 64 -> 64 shape where the
  * Clenshaw strip kernel takes tiles); DSPH_E_UNSUPPORTED otherwise -- run

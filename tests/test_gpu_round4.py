@@ -851,6 +851,8 @@ def test_kept_weight_images_across_batch_classes():
     (64, 2, 64, 128, 5, "chebyshev", "relu", "AVG"),   # two 64-column blocks, four slices (a map too small for the Clenshaw strips)
     (32, 3, 4, 8, 5, "monomial", None, "MAX"),         # packed maps (four to an item) with the pooled store, no strips at all
     (128, 2, 1, 96, 5, "chebyshev", "relu", "MAX"),    # a first layer with three 32-column blocks over two 64-column launches
+    (16, 3, 32, 32, 8, "chebyshev", "relu", "MAX"),    # K = 8: every tile on the BFS-tile kernel, which pools in its store too
+    (8, 5, 128, 64, 5, "chebyshev", None, "AVG"),      # three tiles, eight slices read from global memory, the batch split over workgroups
 ])
 def test_conv_and_pool_in_one_forward(nside, N, Fin, Fout, K, basis, act, pool, prec):
     cols, vals = _grid_ell(nside)
@@ -867,7 +869,7 @@ def test_conv_and_pool_in_one_forward(nside, N, Fin, Fout, K, basis, act, pool, 
     P = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}[prec]
     B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
     T = _native.POOL_MAX if pool == "MAX" else _native.POOL_AVG
-    yp, ws, scr = _native.cheb_forward_pool(plan, _dev(x), _dev(W), _dev(b), K, pool_type=T, act=A, precision=P, basis=B)
+    yp, ws = _native.cheb_forward_pool(plan, _dev(x), _dev(W), _dev(b), K, pool_type=T, act=A, precision=P, basis=B)
     # the two calls it replaces: bit for bit (same forward kernels, same order of the four children)
     y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=A, precision=P, algo=_native.ALGO_FUSED, basis=B)
     y_ref = _native.healpix_pool(y, 4, T)
@@ -877,8 +879,8 @@ def test_conv_and_pool_in_one_forward(nside, N, Fin, Fout, K, basis, act, pool, 
     ref = orc.healpy_pool(fwd(_csr(cols, vals), x, W, K, bias=b, activation=act), 1, pool)
     tol = 2e-6 if prec != "bf16x3" else 2 * TOL
     assert rel_err(yp.cpu().numpy(), ref) < tol
-    yp2, _, _ = _native.cheb_forward_pool(plan, _dev(x), _dev(W), _dev(b), K, pool_type=T, act=A, precision=P, basis=B, workspace=ws,
-                                          scratch=scr, keep_weights=True)
+    yp2, _ = _native.cheb_forward_pool(plan, _dev(x), _dev(W), _dev(b), K, pool_type=T, act=A, precision=P, basis=B, workspace=ws,
+                                       keep_weights=True)
     assert torch.equal(yp, yp2)
 
 
