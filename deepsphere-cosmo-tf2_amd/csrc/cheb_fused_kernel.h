@@ -299,8 +299,12 @@ __device__ __forceinline__ void wgrad_plane_bf16(unsigned char* __restrict__ til
 // WG: the weight fragments of all slices do not fit the LDS beside the planes (more than 64 input channels at K = 5): every
 // level's fragments are then read from the packed image in global memory (L2-resident, at most a few hundred KB) as they are
 // needed, instead of from an LDS copy made once per workgroup.
-template <int PR, int WT, int RP, int NB, int PREC, int MODE = 0, bool WG = false>
+// PX: the forward packs maps (FusedArgs::pack) or pools in its store (FusedArgs::pool); without it neither path exists in the code --
+// the K = 6 .. 9 instantiations are at the register limit, the two paths cost them 13 more spilled registers (BASELINE configs[3]
+// 21.0 -> 23.3 ms when they were run-time branches)
+template <int PR, int WT, int RP, int NB, int PREC, int MODE = 0, bool WG = false, bool PX = false>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs a) {
+  const int pack_ = PX ? a.pack : 0, pool_ = PX ? a.pool : 0;
   constexpr int PLANE_BYTES = PR * FUSED_CH * 4;
   constexpr int NS = (PR * 4 + FUSED_THREADS - 1) / FUSED_THREADS;  // staging float4 per lane
   // all of the CU's LDS, statically: the base is then a compile-time constant that folds into the
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
     for (int i = tid * 16; i < 2 * PLANE_BYTES; i += FUSED_THREADS * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0, 0, 0, 0};
   }
   if (MODE == 0 && tid < FUSED_BIAS_BYTES / 4) {
-    const int bc = a.pack == 4 ? tid & 15 : (a.pack == 2 ? tid & 31 : tid);  // (packed maps: every column group carries the layer's columns)
+    const int bc = pack_ == 4 ? tid & 15 : (pack_ == 2 ? tid & 31 : tid);  // (packed maps: every column group carries the layer's columns)
     sBias[tid] = (a.bias != nullptr && bc < a.Fout) ? a.bias[bc] : 0.f;
   }
   if (MODE == 0 && !WG) {
@@ -364,10 +368,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
   auto issue_loads = [&](int item, int slot) {
     const int ni = item / a.c_count, n = n_first + ni, c = a.c_begin + item - ni * a.c_count;
     const int ch0 = c * FUSED_CH + 4 * (tid & 3);
-    const int ch = a.pack == 4 ? 0 : (a.pack == 2 ? 4 * (tid & 1) : (ch0 < a.Fin ? ch0 : a.Fin - 4));
+    const int ch = pack_ == 4 ? 0 : (pack_ == 2 ? 4 * (tid & 1) : (ch0 < a.Fin ? ch0 : a.Fin - 4));
     // (packed maps: this lane's 16-byte slot belongs to map P n + slot / (4 / P) -- the last map again where the batch ends
     // inside the group)
-    const int nx = a.pack ? min(a.pack * n + (a.pack == 4 ? tid & 3 : (tid & 3) >> 1), a.n_maps - 1) : n;
+    const int nx = pack_ ? min(pack_ * n + (pack_ == 4 ? tid & 3 : (tid & 3) >> 1), a.n_maps - 1) : n;
     const float* __restrict__ xb = a.x + (int64_t)nx * a.x_rows * a.Fin + ch;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -403,12 +407,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       lds_wave_sync();
       const int cq = 32 * b + cq0;
       const float4 bv = *reinterpret_cast<const float4*>(sBias + cq);
-      const int gsh = a.pack == 4 ? 4 : 5;  // log2 of the columns per map
-      const int ymap = a.pack ? a.pack * pend_n + (cq >> gsh) : pend_n, ycol = a.pack ? cq & ((1 << gsh) - 1) : cq;
-      const bool ylive = !a.pack || ymap < a.n_maps;
-      if (VEC && a.pool) {
+      const int gsh = pack_ == 4 ? 4 : 5;  // log2 of the columns per map
+      const int ymap = pack_ ? pack_ * pend_n + (cq >> gsh) : pend_n, ycol = pack_ ? cq & ((1 << gsh) - 1) : cq;
+      const bool ylive = !pack_ || ymap < a.n_maps;
+      if (VEC && pool_) {
         // pooled row rsub of this wave's eight: rows 4 rsub .. 4 rsub + 3 of the block, bias and activation first, in row order
-        float4 o = a.pool == 1 ? make_float4(-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf())
+        float4 o = pool_ == 1 ? make_float4(-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf())
                                : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -417,10 +421,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
           v.y = apply_act(v.y + bv.y, act);
           v.z = apply_act(v.z + bv.z, act);
           v.w = apply_act(v.w + bv.w, act);
-          if (a.pool == 1) { o.x = fmaxf(o.x, v.x); o.y = fmaxf(o.y, v.y); o.z = fmaxf(o.z, v.z); o.w = fmaxf(o.w, v.w); }
+          if (pool_ == 1) { o.x = fmaxf(o.x, v.x); o.y = fmaxf(o.y, v.y); o.z = fmaxf(o.z, v.z); o.w = fmaxf(o.w, v.w); }
           else { o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
         }
-        if (a.pool != 1) { o.x *= 0.25f; o.y *= 0.25f; o.z *= 0.25f; o.w *= 0.25f; }
+        if (pool_ != 1) { o.x *= 0.25f; o.y *= 0.25f; o.z *= 0.25f; o.w *= 0.25f; }
         float* __restrict__ ypp = a.ypool + ((int64_t)(ylive ? ymap : 0) * a.ypool_rows + ((pend_row0 + wave * 32) >> 2) + rsub) * a.ld + ycol;
         if (wave * 32 + 4 * rsub + 3 < pend_Pt && ylive && ycol < a.Fout) *reinterpret_cast<float4*>(ypp) = o;
         lds_wave_sync();
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
       __syncthreads();  // the previous slice's last plane is still being read
       DSPH_STAMP(1);
       // ---- T_0: the prefetched x slice goes to plane X; fetch the next slice meanwhile -------
-      const bool ch_ok = a.pack || c * FUSED_CH + 4 * (tid & 3) < a.Fin;
+      const bool ch_ok = pack_ || c * FUSED_CH + 4 * (tid & 3) < a.Fin;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const unsigned idx = tid + s * FUSED_THREADS;
@@ -724,8 +728,9 @@ static inline int fused_wgrad_gy(int N, int grid, int num_cu) { return std::max(
 template <int PR, int WT, int RPL, int NB, int PREC>
 static int launch_variant(const FusedArgs& args, int grid, size_t lds, hipStream_t stream) {
   // (the kernel declares the whole LDS statically; what does not fit it are the weight fragments of many slices: WG)
-  auto kern = lds + FUSED_BIAS_BYTES > (size_t)LDS_BYTES ? cheb_fused_kernel<PR, WT, RPL, NB, PREC, 0, true>
-                                                         : cheb_fused_kernel<PR, WT, RPL, NB, PREC, 0, false>;
+  const bool wg = lds + FUSED_BIAS_BYTES > (size_t)LDS_BYTES, px = args.pack != 0 || args.pool != 0;
+  auto kern = wg ? (px ? cheb_fused_kernel<PR, WT, RPL, NB, PREC, 0, true, true> : cheb_fused_kernel<PR, WT, RPL, NB, PREC, 0, true, false>)
+                 : (px ? cheb_fused_kernel<PR, WT, RPL, NB, PREC, 0, false, true> : cheb_fused_kernel<PR, WT, RPL, NB, PREC, 0, false, false>);
   // (forward only: where the tiles do not fill the device the maps of the batch are split over the y dimension)
   const int gy = std::max(1, std::min(args.N, args.num_cu / std::max(grid, 1)));
   hipLaunchKernelGGL(kern, dim3(grid, gy), dim3(FUSED_THREADS), 0, stream, args);

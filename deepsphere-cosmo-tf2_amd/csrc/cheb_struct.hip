@@ -289,13 +289,16 @@ int launch_cheb_struct(const StructLaunch& s, hipStream_t stream) {
 #endif
   void (*kern)(StructArgs) = nullptr;
   const bool tab = s.tabrow != nullptr;
-#define DSPH_ST_PICK2(P, CH, TB) (NB == 1 ? cheb_struct_kernel<1, P, CH, TB> : cheb_struct_kernel<2, P, CH, TB>)
+  const bool px = a.pack != 0 || a.pool != 0;
+#define DSPH_ST_PICK3(N_, P, CH, TB) (px ? cheb_struct_kernel<N_, P, CH, TB, true> : cheb_struct_kernel<N_, P, CH, TB, false>)
+#define DSPH_ST_PICK2(P, CH, TB) (NB == 1 ? DSPH_ST_PICK3(1, P, CH, TB) : DSPH_ST_PICK3(2, P, CH, TB))
 #define DSPH_ST_PICK(P, CH) (tab ? DSPH_ST_PICK2(P, CH, true) : DSPH_ST_PICK2(P, CH, false))
   if (prec == DSPH_PREC_BF16X3) kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_BF16X3, true) : DSPH_ST_PICK(DSPH_PREC_BF16X3, false);
   else if (prec == DSPH_PREC_BF16X6) kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_BF16X6, true) : DSPH_ST_PICK(DSPH_PREC_BF16X6, false);
   else kern = s.cheb ? DSPH_ST_PICK(DSPH_PREC_FP32, true) : DSPH_ST_PICK(DSPH_PREC_FP32, false);
 #undef DSPH_ST_PICK
 #undef DSPH_ST_PICK2
+#undef DSPH_ST_PICK3
   // one workgroup per CU; where the tiles do not fill the device the maps (or groups of maps) of the batch are split over the y dimension
   const int gy = std::max(1, std::min<int>(a.N, s.num_cu / grid));
   hipLaunchKernelGGL(kern, dim3(grid, gy), dim3(ST_THREADS), 0, stream, a);

@@ -465,8 +465,11 @@ template <int PREC> struct StPieces {
 // TAB: the rows of the plane cells and their values of L~ come from per-tile tables (class-T tiles: the region is a
 // stencil square, but the row numbers of its halo are not a Morton continuation of the tile's) instead of Morton
 // arithmetic + gvals8 / gdiag (class R).  Everything else is the same code.
-template <int NB, int PREC, bool CHEB, bool TAB>
+// PX: the forward packs maps (StructArgs::pack) or pools in its store (StructArgs::pool); without it neither path is in the code
+// (as run-time branches they cost the kernel, which lives on 168 registers, up to 70 spilled ones)
+template <int NB, int PREC, bool CHEB, bool TAB, bool PX = false>
 __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a) {
+  const int pack_ = PX ? a.pack : 0, pool_ = PX ? a.pool : 0;
   __shared__ __attribute__((aligned(16))) unsigned char smem[ST_LDS_TOTAL];
   float* const sBias = reinterpret_cast<float*>(smem + ST_LDS_BIAS);
 
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   const int cw = wave - ST_GATHER_WAVES;  // contraction wave 0..3
   const int D = a.K - 1;
   if (tid < 64) {
-    const int bc = a.pack == 4 ? tid & 15 : (a.pack == 2 ? tid & 31 : tid);  // (packed maps: every column group carries the layer's columns)
+    const int bc = pack_ == 4 ? tid & 15 : (pack_ == 2 ? tid & 31 : tid);  // (packed maps: every column group carries the layer's columns)
     sBias[tid] = (a.bias != nullptr && bc < a.Fout) ? a.bias[bc] : 0.f;
   }
   const unsigned map_bytes = (unsigned)(a.x_rows * a.Fin * 4);  // (pack only: the launch makes sure three of them fit 32 bits)
@@ -549,15 +552,15 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
                         __builtin_amdgcn_readfirstlane((unsigned)ST_LDS_W + slot0 * ST_WBLK3 + 1024u * (unsigned)p));
     };
     const unsigned* const sRowG = reinterpret_cast<const unsigned*>(smem + ST_LDS_ROWS);
-    const bool raggedG = (a.Fin & 15) != 0 && !a.pack;
+    const bool raggedG = (a.Fin & 15) != 0 && !pack_;
     auto gdma = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
       constexpr int s = decltype(s_c)::value;
       const int piece = wave + 8 * s;
-      const float* __restrict__ base = a.x + ((int64_t)(a.pack ? a.pack * n : n) * a.x_rows * a.Fin + c * 16);
+      const float* __restrict__ base = a.x + ((int64_t)(pack_ ? pack_ * n : n) * a.x_rows * a.Fin + c * 16);
       unsigned off = sRowG[16 * piece + (lane >> 2)];
-      if (a.pack) {  // slot q: map P n + q / (4 / P), its 16-byte piece q % (4 / P)
-        const unsigned q = (ginfo >> (3 * s)) & 3u, mq = a.pack == 4 ? q : q >> 1;
-        off += (unsigned)min((int)mq, a.n_maps - 1 - a.pack * n) * map_bytes + (a.pack == 4 ? 0u : 16u * (q & 1u));
+      if (pack_) {  // slot q: map P n + q / (4 / P), its 16-byte piece q % (4 / P)
+        const unsigned q = (ginfo >> (3 * s)) & 3u, mq = pack_ == 4 ? q : q >> 1;
+        off += (unsigned)min((int)mq, a.n_maps - 1 - pack_ * n) * map_bytes + (pack_ == 4 ? 0u : 16u * (q & 1u));
       } else {
         off += 16u * ((ginfo >> (3 * s)) & 3u);
       }
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   unsigned itC = 0;  // this workgroup's item counter
   const int wpieces = wslice / 1024;
   const bool vec_ok = (a.Fout % 4 == 0) && (a.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
-  const bool ragged = (a.Fin & 15) != 0 && !a.pack;  // the last slice has channels past Fin: they are read from valid channels
+  const bool ragged = (a.Fin & 15) != 0 && !pack_;  // the last slice has channels past Fin: they are read from valid channels
   // Byte offsets (from the map's first element) of the x rows of the region cells of the tile being PREFETCHED, in LDS:
   // ten offsets per lane in registers (and what hipcc hoists around them) cost the contraction role 40 spilled registers.
   // Rebuilt by the four contraction waves in the first interval of a tile's last item, used from the second interval on
@@ -745,12 +748,12 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
   // piece s (compile-time) of the x slice of item (n, c) -> plane at pdst
   auto dma_x = [&](auto s_c, int n, int c, unsigned pdst) __attribute__((always_inline)) {
     constexpr int s = decltype(s_c)::value;
-    const float* __restrict__ base = a.x + ((int64_t)(a.pack ? a.pack * n : n) * a.x_rows * a.Fin + c * 16);
+    const float* __restrict__ base = a.x + ((int64_t)(pack_ ? pack_ * n : n) * a.x_rows * a.Fin + c * 16);
     constexpr int piece_base = GX + ST_CONTRACT_WAVES * s;
     unsigned off = sRow[16 * (piece_base + cw) + (lane >> 2)];
-    if (a.pack) {
-      const unsigned q = (dinfo >> (3 * s)) & 3u, mq = a.pack == 4 ? q : q >> 1;
-      off += (unsigned)min((int)mq, a.n_maps - 1 - a.pack * n) * map_bytes + (a.pack == 4 ? 0u : 16u * (q & 1u));
+    if (pack_) {
+      const unsigned q = (dinfo >> (3 * s)) & 3u, mq = pack_ == 4 ? q : q >> 1;
+      off += (unsigned)min((int)mq, a.n_maps - 1 - pack_ * n) * map_bytes + (pack_ == 4 ? 0u : 16u * (q & 1u));
     } else {
       off += 16u * ((dinfo >> (3 * s)) & 3u);
     }
@@ -827,11 +830,11 @@ __global__ __launch_bounds__(ST_THREADS, 3) void cheb_struct_kernel(StructArgs a
     if (!pend) return;
     st_contract<NB, PREC>(smem, pend_plane, pend_w, mb, lane, acc);
     if (pend_store) {  // that completed a map: y, then fresh accumulators
-      float* __restrict__ yt = a.pool ? a.ypool + ((int64_t)(a.pack ? a.pack * pend_n : pend_n) * a.ypool_rows + (pend_row0 >> 2)) * a.ld
-                                      : a.y + ((int64_t)(a.pack ? a.pack * pend_n : pend_n) * a.y_rows + pend_row0) * a.ld;
+      float* __restrict__ yt = pool_ ? a.ypool + ((int64_t)(pack_ ? pack_ * pend_n : pend_n) * a.ypool_rows + (pend_row0 >> 2)) * a.ld
+                                      : a.y + ((int64_t)(pack_ ? pack_ * pend_n : pend_n) * a.y_rows + pend_row0) * a.ld;
       st_store<NB>(acc, smem, pend_plane, cw, yt, a.ld, sBias, lane, a.Fout,
-                   a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf(), vec_ok, a.pack, (a.pool ? a.ypool_rows : a.y_rows) * (int64_t)a.ld,
-                   a.n_maps - a.pack * pend_n, a.pool);
+                   a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf(), vec_ok, pack_, (pool_ ? a.ypool_rows : a.y_rows) * (int64_t)a.ld,
+                   a.n_maps - pack_ * pend_n, pool_);
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
 #pragma unroll

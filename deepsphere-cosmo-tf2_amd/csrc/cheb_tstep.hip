@@ -44,7 +44,9 @@ struct TStepArgs {
 
 // VEC: the channel count is a multiple of four and the planes are 16-byte aligned (16-byte loads and stores); otherwise a lane
 // moves its four channels one by one (the reference's own models have 5 or 2 channels: examples/quick_start.ipynb:118-127)
-template <int WT, int TS_RP, bool VEC>
+// YS: the iterations of a tile are split over gridDim.y (small maps); without it the loop starts at zero as it always did (the
+// split costs the 24-wide kernel six more spilled registers: not on the large maps' path)
+template <int WT, int TS_RP, bool VEC, bool YS = false>
 __global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
   constexpr int TS_THREADS = 1024 / TS_RP, TS_ROWS = TS_THREADS / 4;  // rows per pass
   constexpr int TS_SQ = TS_RMAX / TS_ROWS;                            // staged 16-byte pieces per lane
@@ -57,6 +59,12 @@ __global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
   const int nslices = mpi > 1 ? 1 : (a.F + 15) / 16;
   const int ngroups = (a.N + mpi - 1) / mpi;
   const unsigned nblk = gridDim.x;
+  // (small maps -- the reference's quick-start model runs at nside 64 .. 8 -- have fewer tiles than the device has CUs: the
+  // (map, slice) iterations of a tile are then split over gridDim.y workgroups)
+  const int iters_all = ngroups * nslices;
+  const int it_begin = YS ? __builtin_amdgcn_readfirstlane((int)((int64_t)iters_all * blockIdx.y / gridDim.y)) : 0;
+  const int iters = YS ? __builtin_amdgcn_readfirstlane((int)((int64_t)iters_all * (blockIdx.y + 1) / gridDim.y)) : iters_all;
+  if (it_begin >= iters) return;
   for (unsigned tb = xcd_remap(blockIdx.x, nblk); tb < (unsigned)a.ntiles; tb += nblk) {
     const int t = (int)tb;
     const int base = a.tile_off[t];
@@ -116,11 +124,6 @@ __global__ __launch_bounds__(1024 / TS_RP) void cheb_tstep_kernel(TStepArgs a) {
         if (i < R) *reinterpret_cast<float4*>(plane + plane_byte((unsigned)i, (unsigned)slot)) = st[q];
       }
     };
-    // (small maps -- the reference's quick-start model runs at nside 64 .. 8 -- have fewer tiles than the device has CUs: the
-    // (map, slice) iterations of a tile are then split over gridDim.y workgroups)
-    const int iters_all = ngroups * nslices;
-    const int it_begin = (int)((int64_t)iters_all * blockIdx.y / gridDim.y), iters = (int)((int64_t)iters_all * (blockIdx.y + 1) / gridDim.y);
-    if (it_begin >= iters) continue;
     fetch(it_begin);
     __syncthreads();  // (the previous tile's last reads of plane 0)
     stage(smem + (unsigned)(it_begin & 1) * (TS_RMAX * 64));
@@ -222,8 +225,11 @@ int launch_cheb_tstep(const TStepTables& tb, const float* in, const float* prev,
   const bool vec = F % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(a.prev)) & 15) == 0;
 #define DSPH_TS(WT, RP)                                                                                                     \
   do {                                                                                                                      \
-    if (vec) hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, true>), grid, dim3(1024 / RP), 0, stream, a);                     \
-    else hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, false>), grid, dim3(1024 / RP), 0, stream, a);                        \
+    if (gy > 1) {                                                                                                           \
+      if (vec) hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, true, true>), grid, dim3(1024 / RP), 0, stream, a);             \
+      else hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, false, true>), grid, dim3(1024 / RP), 0, stream, a);                \
+    } else if (vec) hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, true, false>), grid, dim3(1024 / RP), 0, stream, a);       \
+    else hipLaunchKernelGGL((cheb_tstep_kernel<WT, RP, false, false>), grid, dim3(1024 / RP), 0, stream, a);                 \
   } while (0)
   switch (tb.width) {
     case 16: DSPH_TS(16, 1); break;
