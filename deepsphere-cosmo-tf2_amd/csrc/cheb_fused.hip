@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "cheb_fused_kernel.h"
@@ -114,7 +115,46 @@ struct FusedPlan {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_failed = false;
   std::mutex fork_mu;
+  // DSPH_FWD_KEEP_WEIGHTS: the caller vouches for the weight VALUES; WHICH images a workspace block holds is the library's
+  // own business -- it depends on per-call choices (strips or tiles by the batch, maps packed or not) the caller cannot see.
+  // Per workspace block: the shape key the images were packed for and the set of images packed since (IMG_* bits).  A kept
+  // call packs what the set lacks; a call that does not keep starts an empty set.
+  struct Images { uint64_t key = 0; uint32_t mask = 0; };
+  std::mutex img_mu;
+  std::unordered_map<const void*, Images> images;
 };
+
+void fused_images_begin(const dsph_plan* plan, const void* ws, uint64_t key, bool keep) {
+  FusedPlan* fp = plan->fused;
+  if (!fp || !ws) return;
+  std::lock_guard<std::mutex> lock(fp->img_mu);
+  if (fp->images.size() > 16384 && fp->images.find(ws) == fp->images.end()) fp->images.clear();  // (forgetting only costs a re-pack)
+  FusedPlan::Images& im = fp->images[ws];
+  if (!keep || im.key != key) { im.key = key; im.mask = 0; }
+}
+// true: image `bit` of this block has to be packed now (and counts as packed from here on)
+bool fused_images_claim(const dsph_plan* plan, const void* ws, uint32_t bit) {
+  FusedPlan* fp = plan->fused;
+  if (!fp || !ws) return true;
+  std::lock_guard<std::mutex> lock(fp->img_mu);
+  auto it = fp->images.find(ws);
+  if (it == fp->images.end()) return true;
+  if (it->second.mask & bit) return false;
+  it->second.mask |= bit;
+  return true;
+}
+void fused_images_forget(const dsph_plan* plan, const void* ws) {
+  FusedPlan* fp = plan->fused;
+  if (!fp || !ws) return;
+  std::lock_guard<std::mutex> lock(fp->img_mu);
+  fp->images.erase(ws);
+}
+uint64_t fused_images_key(int32_t Fin, int32_t Fin_w, int32_t Fout, int32_t K, int32_t ld, int32_t precision, bool cheb, bool many, bool pack) {
+  // (values beyond the fields' widths alias at worst to "another key": a re-pack)
+  return ((uint64_t)(Fin & 0xfff)) | ((uint64_t)(Fin_w & 0xfff) << 12) | ((uint64_t)(Fout & 0xff) << 24) | ((uint64_t)(K & 0x3f) << 32) |
+         ((uint64_t)(ld & 0xffff) << 38) | ((uint64_t)(precision & 3) << 54) | ((uint64_t)cheb << 56) | ((uint64_t)many << 57) |
+         ((uint64_t)pack << 58) | (1ull << 63);
+}
 
 static int template_width(int w) {
   if (w <= 9) return 9;
@@ -1194,6 +1234,8 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
   }
   for (int32_t cb = 0; cb < Fout; cb += 64) {
     unsigned char* blk_ws = static_cast<unsigned char*>(workspace) + (size_t)(cb / 64) * blk_frag;  // this block's weight images
+    fused_images_begin(plan, blk_ws, fused_images_key(Fin, Fin_w, std::min<int32_t>(64, Fout - cb), K, Fout, precision, beta_rest != 0.f,
+                                                      N >= 2, plan->opt.pack), keep_weights);
     const FusedPool pool_blk{pool ? pool->y + cb : nullptr, pool ? pool->type : 0};  // (this block's columns of the pooled map)
     const FusedPool* pool_b = pool ? &pool_blk : nullptr;
     auto run = [&](hipStream_t st, int32_t only) {
@@ -1218,6 +1260,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
           hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
           if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) e_join = hipStreamSynchronize(fp->side);
         }
+        if (rc_b != DSPH_OK || rc_s != DSPH_OK) fused_images_forget(plan, blk_ws);
         if (rc_b != DSPH_OK) return rc_b;
         if (rc_s != DSPH_OK) return rc_s;
         if (e_rec != hipSuccess) return hip_fail(e_rec, "hipEventRecord(join)");
@@ -1226,7 +1269,7 @@ int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, con
       }
     }
     const int rc = run(stream, 0);
-    if (rc != DSPH_OK) return rc;
+    if (rc != DSPH_OK) { fused_images_forget(plan, blk_ws); return rc; }
   }
   if (pool != nullptr) {
     return DSPH_OK;  // (every kernel has stored its tiles pooled; y, the scratch of the C ABI, stays untouched)
@@ -1377,7 +1420,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     sl.Fin = Fin; sl.Fin_w = Fin_w; sl.Fout = Fout; sl.K = K; sl.act = act; sl.precision = precision; sl.ld = ld;
     sl.num_cu = plan->fused->num_cu;
     sl.cheb = beta_rest != 0.f;
-    sl.prep_weights = !keep_weights;  // the first of the two launches packs the fragments
+    bool struct_prep = true;  // the first structured launch of this call packs the fragments, if the block lacks them
     sl.allow_pack = plan->opt.pack;
     if (pool != nullptr) {
       sl.pool = pool->type;
@@ -1398,7 +1441,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       st.num_cu = plan->fused->num_cu;
       st.cheb = sl.cheb;
       st.generic = plan->opt.strip_generic;
-      st.prep_weights = !keep_weights;
+      st.prep_weights = fused_images_claim(plan, workspace, IMG_STRIP);
       const int rc = launch_cheb_strip(st, stream);
       if (rc != DSPH_OK) return rc;
     }
@@ -1416,7 +1459,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       // (row segments for the items the kernel will deal: maps, or pairs of maps in the one-channel kernel's pair mode)
       is.nseg = istrip_nseg(plan, ft, istrip_pairs(Fin_w, Fout) ? (N + 1) / 2 : N, K - 1, istrip_narrow(Fin_w));
       is.cheb = sl.cheb;
-      is.prep_weights = !keep_weights;
+      is.prep_weights = fused_images_claim(plan, workspace, IMG_ISTRIP);
       if (pool != nullptr) {
         is.pool = pool->type;
         is.ypool = pool->y;
@@ -1434,9 +1477,10 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       sl.tabrow = nullptr;
       sl.tabvals = nullptr;
       sl.ntiles = nr;
+      sl.prep_weights = struct_prep && fused_images_claim(plan, workspace, IMG_STRUCT);
+      struct_prep = false;
       const int rc = launch_cheb_struct(sl, stream);
       if (rc != DSPH_OK) return rc;
-      sl.prep_weights = false;
     }
     const int nt = part == 0 ? ft.n_t : (part == 1 ? ft.n_t_interior : ft.n_t - ft.n_t_interior);
     if (nt > 0 && !dbg_only('b')) {
@@ -1445,6 +1489,8 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       sl.tabrow = ft.d_tabrow + first * ST_CELLS;
       sl.tabvals = ft.d_tabvals + first * ST_CELLS * ST_TABV;
       sl.ntiles = nt;
+      sl.prep_weights = struct_prep && fused_images_claim(plan, workspace, IMG_STRUCT);
+      struct_prep = false;
       const int rc = launch_cheb_struct(sl, stream);
       if (rc != DSPH_OK) return rc;
     }
@@ -1457,7 +1503,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   // four maps per item where the layer has at most four input channels and 16 output columns (FusedArgs::pack)
   const int pack = (plan->opt.pack && !planes_mode && !wgrad_mode && N >= 2) ? bfs_packs(Fin, Fout) : 0;  // (a single map gains nothing from two column blocks)
   const int NBb = pack ? 2 : NB;
-  if (!planes_mode && !keep_weights) {
+  if (!planes_mode && fused_images_claim(plan, workspace, IMG_BFS)) {
     hipLaunchKernelGGL(fused_wprep_kernel, dim3(K * C * NBb), dim3(256), 0, stream, w,
                        static_cast<unsigned char*>(workspace), (int)Fin_w, (int)Fout, (int)K, C, NBb,
                        (int)precision, (int)ld, pack);

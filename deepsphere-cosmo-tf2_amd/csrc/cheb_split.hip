@@ -124,10 +124,11 @@ void pass_shape(const SplitShape& s, int32_t Fin, int32_t Fout, int l, int32_t* 
 
 bool split_layout(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, SplitShape* s, SplitLayout* lay) {
   if (!split_shape(Fin, Fout, K, s)) return false;
+  // Everything a kept call (DSPH_FWD_KEEP_WEIGHTS) reads again sits at offsets that do not depend on the batch: the terms of
+  // the levels, the weight matrices of the passes, the passes' own workspaces (their packed weight images come first in
+  // them; only the deepest pass, whose input is x itself, may append a zero-padded copy of x -- so it goes last); the
+  // concatenation buffers, N maps each, follow.
   size_t off = 0;
-  const size_t zb = align256((size_t)N * (size_t)p->n_cols * (size_t)s->Cz * sizeof(float));
-  lay->z[0] = off; off += zb;
-  if (s->L >= 2) { lay->z[1] = off; off += zb; }
   for (int l = 1; l <= s->L; ++l) {
     lay->lvl[l] = off;
     off += align256((size_t)Fin * s->Kl[l] * Fout * sizeof(float));
@@ -139,13 +140,16 @@ bool split_layout(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fout, int3
     lay->wgt_pass[l] = off;
     off += align256((size_t)fi * k * fo * sizeof(float));
   }
-  for (int l = s->L; l >= 0; --l) {
+  for (int l = 0; l <= s->L; ++l) {
     int32_t fi, fo, k;
     pass_shape(*s, Fin, Fout, l, &fi, &fo, &k);
     lay->sub_pass[l] = off;
     lay->sub_bytes[l] = align256(fused_workspace_bytes(p, N, fi, fo, k, precision));
     off += lay->sub_bytes[l];
   }
+  const size_t zb = align256((size_t)N * (size_t)p->n_cols * (size_t)s->Cz * sizeof(float));
+  lay->z[0] = off; off += zb;
+  if (s->L >= 2) { lay->z[1] = off; off += zb; }
   lay->total = off;
   return true;
 }
@@ -193,12 +197,15 @@ int launch_split_forward(const dsph_plan* p, const float* x, const float* w, con
   // the terms of the levels, then the weight matrices of all passes (tiny), then the passes
   auto blocks = [](int64_t total) { return dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)); };
   auto level_w = [&](int l) -> const float* { return l == 0 ? w : reinterpret_cast<const float*>(ws + lay.lvl[l]); };
-  for (int l = 0; l < s.L && !keep_weights; ++l) {
+  // (the derived matrices are kept like the packed images: the library's own record says whether this workspace holds them)
+  fused_images_begin(p, ws, fused_images_key(Fin, Fin, Fout & 0xff, K & 0x3f, Fout, precision, cheb, false, false) ^ ((uint64_t)K << 20), keep_weights);
+  const bool derive = fused_images_claim(p, ws, IMG_SPLIT);
+  for (int l = 0; l < s.L && derive; ++l) {
     hipLaunchKernelGGL(split_next_kernel, blocks((int64_t)Fin * Fout * 8), dim3(256), 0, stream, level_w(l),
                        reinterpret_cast<float*>(ws + lay.lvl[l + 1]), (int)Fin, (int)Fout, s.Kl[l], cheb ? 1 : 0);
     DSPH_HIP(hipGetLastError());
   }
-  for (int l = s.L; l >= 0 && !keep_weights; --l) {
+  for (int l = s.L; l >= 0 && derive; --l) {
     int32_t fi, fo, k;
     pass_shape(s, Fin, Fout, l, &fi, &fo, &k);
     hipLaunchKernelGGL(split_weights_kernel, blocks((int64_t)fi * k * fo), dim3(256), 0, stream, level_w(l),
@@ -213,8 +220,8 @@ int launch_split_forward(const dsph_plan* p, const float* x, const float* w, con
     float* out = l == 0 ? y : reinterpret_cast<float*>(ws + lay.z[(s.L - l) & 1]);
     const int rc = launch_cheb_fused(p, in, reinterpret_cast<const float*>(ws + lay.wgt_pass[l]), l == 0 ? bias : nullptr, out, N, fi, fo,
                                      k, l == 0 ? act : DSPH_ACT_NONE, precision, alpha_rest, beta_rest, ws + lay.sub_pass[l],
-                                     lay.sub_bytes[l], stream, DSPH_PART_ALL, keep_weights);
-    if (rc != DSPH_OK) return rc;
+                                     lay.sub_bytes[l], stream, DSPH_PART_ALL, keep_weights && !derive);
+    if (rc != DSPH_OK) { fused_images_forget(p, ws); return rc; }
     in = out;
   }
   return DSPH_OK;

@@ -175,21 +175,25 @@ int dsph_plan_strip_pairs(const dsph_plan* p, int32_t K, int32_t* out, int64_t c
   return DSPH_OK;
 }
 
-int dsph_plan_prepare(dsph_plan* p, int32_t K, int32_t Fin, int32_t flags) {
-  if (!p || K <= 0 || Fin <= 0 || (flags & ~(DSPH_PREPARE_BACKWARD | DSPH_PREPARE_RELEASE_HOST))) {
-    set_error("plan_prepare: bad arguments (plan %p, K %d, Fin %d, flags %d)", (void*)p, K, Fin, flags);
+static bool use_split(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo, int32_t part);
+
+int dsph_plan_prepare_layer(dsph_plan* p, int32_t K, int32_t Fin, int32_t Fout, int32_t flags) {
+  if (!p || K <= 0 || Fin <= 0 || Fout <= 0 || (flags & ~(DSPH_PREPARE_BACKWARD | DSPH_PREPARE_RELEASE_HOST))) {
+    set_error("plan_prepare: bad arguments (plan %p, K %d, Fin %d, Fout %d, flags %d)", (void*)p, K, Fin, Fout, flags);
     return DSPH_E_BADARG;
   }
   DeviceGuard guard(p->device);
   if (!guard.ok) { set_error("plan_prepare: cannot select device %d", p->device); return DSPH_E_HIP; }
   // a layer with more than five terms may run as a chain of passes (cheb_split.hip): then it is their tables that are
-  // built, not the breadth-first tables of depth K - 1.  (The output width is not an argument here; the tables depend on it
-  // only through the 4 GiB-per-map limit of the structured kernel, judged with Fout = Fin.)
-  if (K > 5 && p->n_cols == p->n_rows && p->levels.empty() &&
-      (p->opt.split_order == 1 || (p->opt.split_order == 0 && K - 1 > fused_dmax())))
-    return split_prepare(p, K, Fin, Fin, flags);
+  // built, not the breadth-first tables of depth K - 1 -- by the predicate the forward itself uses (use_split), so that a
+  // prepared forward of this (K, Fin, Fout) allocates nothing whichever route it takes.
+  if (use_split(p, Fin, Fout, K, DSPH_ALGO_AUTO, DSPH_PART_ALL)) return split_prepare(p, K, Fin, Fout, flags);
   return fused_prepare(p, K, Fin, flags);
 }
+
+// (the output width unknown: judged as Fout = Fin; a layer of another width whose route differs builds its tables in its
+// first forward -- dsph_plan_prepare_layer takes the width)
+int dsph_plan_prepare(dsph_plan* p, int32_t K, int32_t Fin, int32_t flags) { return dsph_plan_prepare_layer(p, K, Fin, Fin, flags); }
 
 // A plan with halo columns and no shrinking schedule cannot run more than one recurrence step by itself: step 2
 // would gather halo entries of T_1 that no step wrote (the fused kernels reject it; the unfused path must too).
@@ -199,8 +203,6 @@ int64_t dsph_plan_rows(const dsph_plan* p) { return p ? p->n_rows : 0; }
 int64_t dsph_plan_cols(const dsph_plan* p) { return p ? p->n_cols : 0; }
 int32_t dsph_plan_ell_width(const dsph_plan* p) { return p ? p->width : 0; }
 int64_t dsph_plan_out_rows(const dsph_plan* p, int32_t K) { (void)K; return p ? out_rows(p) : 0; }
-
-static bool use_split(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo, int32_t part);
 
 int dsph_plan_fused_ok(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K) {
   // (tables are built under the plan's device: get_tiles)

@@ -122,6 +122,12 @@ int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* 
                             void* workspace, size_t workspace_bytes, hipStream_t stream, int32_t Fin_w = 0);  // Fin_w: real channels (rows of dw) when x is a zero-padded copy
 size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                              int32_t precision);
+// which packed weight images a workspace block holds (DSPH_FWD_KEEP_WEIGHTS; FusedPlan::images)
+enum : uint32_t { IMG_BFS = 1, IMG_STRUCT = 2, IMG_STRIP = 4, IMG_ISTRIP = 8, IMG_QSTRIP = 16, IMG_SPLIT = 32 };
+void fused_images_begin(const dsph_plan* plan, const void* ws, uint64_t key, bool keep);
+bool fused_images_claim(const dsph_plan* plan, const void* ws, uint32_t bit);
+void fused_images_forget(const dsph_plan* plan, const void* ws);
+uint64_t fused_images_key(int32_t Fin, int32_t Fin_w, int32_t Fout, int32_t K, int32_t ld, int32_t precision, bool cheb, bool many, bool pack);
 
 // K > 5 as a chain of passes with K <= 5 on the fused kernels (cheb_split.hip)
 int fused_dmax();

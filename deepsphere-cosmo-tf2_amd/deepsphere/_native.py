@@ -19,6 +19,7 @@ PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
 ALGO_AUTO, ALGO_UNFUSED, ALGO_FUSED = 0, 1, 2
 PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
 FWD_KEEP_WEIGHTS = 1
+ABI_VERSION = 2  # DSPH_ABI_VERSION of include/dsphere.h this binding was written against
 POOL_MAX, POOL_AVG = 0, 1
 PREPARE_BACKWARD, PREPARE_RELEASE_HOST = 1, 2
 BASIS_CHEBYSHEV, BASIS_MONOMIAL = 0, 1
@@ -47,6 +48,7 @@ SIGNATURES = {
     "dsph_plan_out_rows": (_c_i64, [_c_vp, _c_i32]),
     "dsph_plan_fused_ok": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
     "dsph_plan_prepare": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
+    "dsph_plan_prepare_layer": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32, _c_i32]),
     "dsph_plan_tile_counts": (ctypes.c_int, [_c_vp, _c_i32, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
     "dsph_plan_strip_tiles": (ctypes.c_int, [_c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, ctypes.POINTER(_c_i64)]),
     "dsph_workspace_bytes": (ctypes.c_size_t, [_c_vp, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32]),
@@ -124,7 +126,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if handle.dsph_abi_version() != 1:
+        if handle.dsph_abi_version() != ABI_VERSION:
             raise RuntimeError("libdsphere_hip.so has an unexpected ABI version")
         _lib = handle
     return _lib
@@ -199,11 +201,12 @@ class LaplacianPlan:
     def fused_ok(self, Fin, Fout, K):
         return bool(lib().dsph_plan_fused_ok(self.handle, int(Fin), int(Fout), int(K)))
 
-    def prepare(self, K, Fin, backward=False, release_host=False):
-        """Build the fused kernels' tables for a K-term layer now (``dsph_plan_prepare``): afterwards a forward
-        neither allocates nor synchronises, so it can be timed and captured into a graph."""
+    def prepare(self, K, Fin, backward=False, release_host=False, Fout=None):
+        """Build the fused kernels' tables for a K-term layer now (``dsph_plan_prepare_layer``; without ``Fout`` the width is
+        taken as ``Fin``): afterwards a forward neither allocates nor synchronises, so it can be timed and captured into a graph."""
         flags = (PREPARE_BACKWARD if backward else 0) | (PREPARE_RELEASE_HOST if release_host else 0)
-        check(lib().dsph_plan_prepare(self.handle, int(K), int(Fin), flags), "dsph_plan_prepare")
+        check(lib().dsph_plan_prepare_layer(self.handle, int(K), int(Fin), int(Fin if Fout is None else Fout), flags),
+              "dsph_plan_prepare_layer")
 
     def tile_counts(self, K):
         """(tiles run by the structured-tile kernel, tiles run by the BFS-tile kernel) of a K-term fused forward."""

@@ -331,8 +331,8 @@ class Chebyshev(torch.nn.Module):
             raise ValueError(f"layer was built for Fin = {self._Fin}, got {Fin}")
         plan = self._get_plan()
         if getattr(self, "_prepared", None) != (self.K, Fin):
-            # tile tables now, not inside the first kernel launch (allocation + synchronisation: dsph_plan_prepare)
-            plan.prepare(self.K, Fin)
+            # tile tables now, not inside the first kernel launch (allocation + synchronisation: dsph_plan_prepare_layer)
+            plan.prepare(self.K, Fin, Fout=self.Fout)
             self._prepared = (self.K, Fin)
         wants_grad = torch.is_grad_enabled() and (
             self.kernel.requires_grad or input_tensor.requires_grad or (self.use_bias and self.bias.requires_grad))

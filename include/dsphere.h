@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define DSPH_ABI_VERSION 1
+#define DSPH_ABI_VERSION 2  /* 2: dsph_plan_prepare_layer; the entry points added since version 1 (set_option,
+                              * forward_ex, forward_pool, healpix_pool, strip_pairs) are part of it */
 
 /* error codes */
 #define DSPH_OK 0
@@ -108,6 +109,11 @@ int dsph_plan_set_levels(dsph_plan* plan, int32_t n_levels, const int64_t* rows_
 #define DSPH_PREPARE_BACKWARD 1
 #define DSPH_PREPARE_RELEASE_HOST 2
 int dsph_plan_prepare(dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags);
+/* The same for a layer whose output width is known: a K > 5 layer runs either on the breadth-first tables of depth K - 1 or as
+ * a chain of K <= 5 passes (DSPH_OPT_SPLIT), and which of the two depends on Fin AND Fout; this call builds exactly the tables
+ * the forward of (K, Fin, Fout) will use, by the forward's own rule.  dsph_plan_prepare(plan, K, Fin, flags) is this call with
+ * Fout = Fin. */
+int dsph_plan_prepare_layer(dsph_plan* plan, int32_t K, int32_t Fin, int32_t Fout, int32_t flags);
 
 /* Per-plan choices.  The library reads no environment variable: what used to be process-global switches of the fused path
  * are options of the plan, set before the tables of a K are built (dsph_plan_prepare or the first forward) -- setting one that

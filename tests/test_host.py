@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in dsphere.h but not exported"
     assert declared == set(_native.SIGNATURES), "ctypes table and header disagree"
-    assert lib.dsph_abi_version() == 1
+    assert lib.dsph_abi_version() == 2
 
 
 def test_bad_arguments_are_reported_not_fatal():
