@@ -183,6 +183,9 @@ def measured_error(cols, vals, x, y, w_np, K, nside, seed=3, n_random=24):
     return float(np.abs(got - ref).max() / s_max), int(centres.size * x.shape[0])
 
 
+STRIP_FORM = "quad"  # --strip-form: which strip kernel the 64 -> 64 shape runs (names the kernel in the roofline block)
+
+
 def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1, split="auto"):
     """Which kernels one fused forward launches: the strip kernel on the rectangles of plain structured tiles it takes for this
     shape (dsph_plan_strip_tiles), the structured-tile kernel on the other structured tiles, the BFS-tile kernel on the rest
@@ -202,7 +205,7 @@ def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1, split="auto"):
     n_strip = plan.strip_tiles(Fin, Fout, K, prec_code, N=N)
     parts = []
     if n_strip:
-        parts.append(f"{'cheb_istrip1_kernel' if Fin <= 2 else ('cheb_istrip_kernel' if Fin <= 16 else 'cheb_strip5_kernel')} ({n_strip} tiles)")
+        parts.append(f"{'cheb_istrip1_kernel' if Fin <= 2 else ('cheb_istrip_kernel' if Fin <= 16 else ('cheb_qstrip5_kernel' if STRIP_FORM == 'quad' else 'cheb_strip5_kernel'))} ({n_strip} tiles)")
     if n_struct - n_strip:
         parts.append(f"cheb_struct_kernel ({n_struct - n_strip} tiles)")
     if n_bfs:
@@ -237,6 +240,8 @@ def main():
     ap.add_argument("--split", default="auto", choices=["auto", "always", "never"],
                     help="K > 5: the product-identity chain of K <= 5 passes (csrc/cheb_split.hip) -- plan option DSPH_OPT_SPLIT")
     ap.add_argument("--strips", default="auto", choices=["auto", "always", "never"], help="plan option DSPH_OPT_STRIPS")
+    ap.add_argument("--strip-form", default="quad", choices=["quad", "pairs"],
+                    help="plan option DSPH_OPT_STRIP_FORM: quad strips (round 5) or the strip pairs of round 3")
     ap.add_argument("--tstep", default="on", choices=["on", "off"], help="plan option DSPH_OPT_TSTEP (wide graphs: tiled step)")
     ap.add_argument("--fork", default="on", choices=["on", "off"],
                     help="plan option DSPH_OPT_FORK (the BFS-tile launch beside the structured ones, on the plan's side stream)")
@@ -248,6 +253,8 @@ def main():
     ap.add_argument("--allow-replicas", action="store_true",
                     help="with --gpus > 1: if the sharded forward fails, time independent replicas instead of exiting non-zero")
     args = ap.parse_args()
+    global STRIP_FORM
+    STRIP_FORM = args.strip_form
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -275,6 +282,7 @@ def main():
 
     plan_options = {_native.OPT_SPLIT: {"auto": 0, "always": 1, "never": 2}[args.split],
                     _native.OPT_STRIPS: {"auto": 0, "always": 1, "never": 2}[args.strips],
+                    _native.OPT_STRIP_FORM: _native.STRIP_FORM_QUAD if args.strip_form == "quad" else _native.STRIP_FORM_PAIRS,
                     _native.OPT_TSTEP: 1 if args.tstep == "on" else 0,
                     _native.OPT_FORK: 1 if args.fork == "on" else 0}
     nside, K, Fin, Fout, N = CONFIGS[args.config]

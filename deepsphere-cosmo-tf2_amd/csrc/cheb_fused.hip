@@ -37,6 +37,7 @@
 
 #include "cheb_fused_kernel.h"
 #include "cheb_istrip_kernel.h"
+#include "cheb_qstrip_kernel.h"
 #include "cheb_strip_kernel.h"
 #include "cheb_struct_kernel.h"
 
@@ -78,6 +79,12 @@ struct FusedTiles {
   std::vector<StripPair> h_pairs;          // host copy of d_pairs (dsph_plan_strip_pairs: what the seam tests read)
   mutable std::map<int64_t, int64_t> strip_span;  // batch N -> steps of the busiest workgroup (strip_makespan; under FusedPlan::mu)
   bool strip_forced = false;               // DSPH_OPT_STRIPS = 1 when the tables were built: the cost gate is off
+  // quad-strip kernel (cheb_qstrip_kernel.h): the same rectangles, merged side by side and cut into 64-column strips
+  QStrip* d_qstrips = nullptr;             // uncut along y: the kernel cuts the tape of their rows evenly over its workgroups
+  int32_t* d_qprefix = nullptr;            // [n_qstrips + 1] rows before each strip
+  int n_qstrips = 0;
+  int64_t qtape_rows = 0;
+  std::vector<QStrip> h_qstrips;
   // input-side strip kernel (cheb_istrip_kernel.h): the same rectangles, uncut along y (the kernel cuts every strip into the
   // number of row segments that istrip_segments picks for the batch)
   StripPair* d_ipairs = nullptr;
@@ -175,6 +182,8 @@ static void free_tiles(FusedTiles& ft) {
   if (ft.d_tabrow) (void)hipFree(ft.d_tabrow);
   if (ft.d_tabvals) (void)hipFree(ft.d_tabvals);
   if (ft.d_pairs) (void)hipFree(ft.d_pairs);
+  if (ft.d_qstrips) (void)hipFree(ft.d_qstrips);
+  if (ft.d_qprefix) (void)hipFree(ft.d_qprefix);
   if (ft.d_rrest) (void)hipFree(ft.d_rrest);
   if (ft.d_all) (void)hipFree(ft.d_all);
   if (ft.d_ipairs) (void)hipFree(ft.d_ipairs);
@@ -404,7 +413,9 @@ constexpr int SMALL_MAP_TILES = 512;  // structured tiles up to which a plan wit
 // and into row segments sized so that the items fill the CUs evenly.  The other tiles stay with the tile kernels (`rest`).
 static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_cu, const PlanOptions& opt,
                          std::vector<StripPair>& pairs, std::vector<int32_t>& rest, int64_t* n_taken, std::vector<int32_t>& steps,
-                         std::vector<StripPair>& whole) {  // whole: the same strips uncut along y (input-side strip kernel)
+                         std::vector<StripPair>& whole,  // whole: the same strips uncut along y (input-side strip kernel)
+                         std::vector<QStrip>* qstrips = nullptr) {  // quad-strip kernel
+  if (qstrips) qstrips->clear();
   steps.clear();
   pairs.clear();
   whole.clear();
@@ -555,6 +566,27 @@ static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_
   cut(best_h, pairs);
   steps_of(pairs, steps);
   cut(1 << 30, whole);
+  // The quad strips: rectangles that stand side by side over the same rows become one (a full base pixel: one rectangle of all
+  // its interior columns), cut into strips of 56 output columns (the last one narrower), uncut along y.
+  if (qstrips && D == QS_D) {
+    std::vector<Rect> wide(take);
+    std::sort(wide.begin(), wide.end(), [](const Rect& a, const Rect& b) { return a.ty != b.ty ? a.ty < b.ty : (a.ht != b.ht ? a.ht < b.ht : a.tx < b.tx); });
+    std::vector<Rect> merged;
+    for (const Rect& r : wide) {
+      if (!merged.empty() && merged.back().ty == r.ty && merged.back().ht == r.ht && merged.back().tx + merged.back().wt == r.tx) merged.back().wt += r.wt;
+      else merged.push_back(r);
+    }
+    for (const Rect& r : merged) {
+      const int X0 = 16 * r.tx, X1 = 16 * (r.tx + r.wt), Y0 = 16 * r.ty, Y1 = 16 * (r.ty + r.ht);
+      for (int x0 = X0; x0 < X1; x0 += QS_USE) {
+        QStrip q{};
+        q.x0 = x0; q.w = std::min(QS_USE, X1 - x0); q.xs = x0 - D;
+        q.y0 = Y0; q.y1 = Y1;
+        q.xlo = X0 - D; q.xhi = X1 - 1 + D; q.ylo = Y0 - D; q.yhi = Y1 - 1 + D;
+        qstrips->push_back(q);
+      }
+    }
+  }
 #ifdef DSPH_ABLATE
   if (getenv("DSPH_STRIP_DEBUG"))
     fprintf(stderr, "build_strips: segments of %d rows, %zu pairs, busiest workgroup %ld / %ld / %ld steps for 1 / 4 / 16 maps; tile cost "
@@ -828,12 +860,19 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   ft.strip_steps.clear();
   ft.strip_span.clear();
   ft.strip_forced = plan->opt.strips == 1;
+  std::vector<QStrip> qstrips;
   if (!full && D <= SP_DMAX && plan->opt.strips != 2)
-    build_strips(r_interior, D, fp->num_cu, plan->opt, pairs, rrest, &ft.n_strip_tiles, ft.strip_steps, ipairs);
+    build_strips(r_interior, D, fp->num_cu, plan->opt, pairs, rrest, &ft.n_strip_tiles, ft.strip_steps, ipairs, &qstrips);
   else
     rrest = r_interior;
   ft.n_pairs = (int)pairs.size();
   ft.h_pairs = pairs;
+  ft.n_qstrips = (int)qstrips.size();
+  ft.h_qstrips = qstrips;
+  std::vector<int32_t> qprefix(1, 0);
+  for (const QStrip& q : qstrips) qprefix.push_back(qprefix.back() + (q.y1 - q.y0));
+  ft.qtape_rows = qprefix.back();
+  if (qstrips.empty()) qstrips.push_back(QStrip());
   ft.n_ipairs = (int)ipairs.size();
   ft.ipair_h.clear();
   ft.ipair_second.clear();
@@ -872,6 +911,8 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
               up((void**)&ft.d_rrest, rrest.data(), rrest.size() * 4) &&
               up((void**)&ft.d_all, all_tiles.data(), all_tiles.size() * 4) &&
               up((void**)&ft.d_pairs, pairs.data(), pairs.size() * sizeof(StripPair)) &&
+              up((void**)&ft.d_qstrips, qstrips.data(), qstrips.size() * sizeof(QStrip)) &&
+              up((void**)&ft.d_qprefix, qprefix.data(), qprefix.size() * 4) &&
               up((void**)&ft.d_ipairs, ipairs.data(), ipairs.size() * sizeof(StripPair));
   if (!good) {
     FusedTiles keep = ft;
@@ -902,7 +943,8 @@ static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
 // weight images of the three fused kernels, back to back in the workspace: BFS-tile | structured-tile | strip
 static size_t all_frag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
   return wfrag_bytes(Fin, Fout, K) + struct_wfrag_bytes(Fin, Fout, K) + strip_wimg_bytes(Fin, Fout, K) +
-         2 * istrip_wimg_bytes(K, DSPH_PREC_BF16X6);  // (the largest of the three arithmetics, two 32-column blocks)
+         2 * istrip_wimg_bytes(K, DSPH_PREC_BF16X6) +  // (the largest of the three arithmetics, two 32-column blocks)
+         (qstrip_shape_ok(Fin, Fout, K) ? qstrip_wimg_bytes() : 0);
 }
 
 // The structured-tile kernel addresses x by 32-bit byte offsets inside a map: larger maps take BFS tables throughout.
@@ -1013,19 +1055,29 @@ bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int6
 // same map can be summed in two different orders at two batch sizes (both within the tolerance of the precision); a caller
 // that needs batch- or shard-invariant bits fixes the choice per plan: dsph_plan_set_option(DSPH_OPT_STRIPS, 1 always | 2 never).
 //   Fout: the columns of THIS launch (one 64-column block of the layer); ld: the layer's row stride of y.
+static bool use_qstrips(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K) {
+  return plan->opt.strip_form == 0 && ft.n_qstrips > 0 && qstrip_shape_ok(Fin, Fout, K);
+}
 static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t N,
                          int32_t ld) {
   if (!(ft.n_pairs > 0 && precision == DSPH_PREC_BF16X3 && strip_shape_ok(Fin, Fout, K) && ld % 4 == 0 &&
         plan->n_cols * (int64_t)std::max(Fin, ld) * 4 < (1ll << 32)))
     return false;
   if (ft.strip_forced) return true;
-  if (N < 1 || (int64_t)ft.strip_steps.size() * N > (1ll << 24)) return false;
   FusedPlan* fp = plan->fused;
+  if (use_qstrips(plan, ft, Fin, Fout, K)) {
+    // (a quad-strip step takes 2.8 us, a tile-map 18.7; the tape of rows is cut evenly, so the span is a formula)
+    if (N < 1) return false;
+    const int64_t span = qstrip_span(fp->num_cu, ft.qtape_rows * N, ft.qtape_rows / std::max(1, ft.n_qstrips));
+    return span * 28 * 103 < ft.n_strip_tiles * N * 187 / fp->num_cu * 100;
+  }
+  const std::vector<int32_t>& steps = ft.strip_steps;
+  if (N < 1 || (int64_t)steps.size() * N > (1ll << 24)) return false;
   int64_t span;
   {
     std::lock_guard<std::mutex> lock(fp->mu);
     auto it = ft.strip_span.find(N);
-    if (it == ft.strip_span.end()) it = ft.strip_span.emplace(N, strip_makespan(ft.strip_steps, N, fp->num_cu)).first;
+    if (it == ft.strip_span.end()) it = ft.strip_span.emplace(N, strip_makespan(steps, N, fp->num_cu)).first;
     span = it->second;
   }
   return span * 30 * 103 < ft.n_strip_tiles * N * 187 / fp->num_cu * 100;
@@ -1082,6 +1134,15 @@ int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_
   const FusedTiles& ft = get_tiles(plan, K - 1, false);
   if (!ft.ok) return -1;
   static_assert(sizeof(StripPair) == 12 * sizeof(int32_t), "StripPair is twelve int32");
+  if (plan->opt.strip_form == 0 && K == 5 && !ft.h_qstrips.empty()) {  // the quad strips, in the same record: one strip, the second empty
+    const int64_t n = (int64_t)ft.h_qstrips.size();
+    for (int64_t i = 0; i < n && i < cap; ++i) {
+      const QStrip& q = ft.h_qstrips[(size_t)i];
+      const int32_t rec[12] = {q.x0, q.x0, q.w, 0, q.xs, q.xs, q.y0, q.y1, q.xlo, q.xhi, q.ylo, q.yhi};
+      memcpy(out + 12 * i, rec, sizeof(rec));
+    }
+    return n;
+  }
   const int64_t n = (int64_t)ft.h_pairs.size();
   for (int64_t i = 0; i < n && i < cap; ++i) memcpy(out + 12 * i, &ft.h_pairs[(size_t)i], sizeof(StripPair));
   return n;
@@ -1429,7 +1490,24 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     }
     // rectangles of interior class-R tiles: the strip kernel, when it has this shape; the class-R list shrinks to the rest
     const bool strips = strips_apply(plan, ft, Fin, Fout, K, precision, N, ld) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-    if (strips && part != 2 && !dbg_only('b')) {
+    if (strips && part != 2 && !dbg_only('b') && use_qstrips(plan, ft, Fin, Fout, K)) {
+      QStripLaunch qs;
+      qs.x = x; qs.w = w; qs.bias = bias; qs.y = y;
+      qs.wimg = static_cast<unsigned char*>(workspace) + wb + struct_wfrag_bytes(Fin, Fout, K) + strip_wimg_bytes(Fin, Fout, K) +
+                2 * istrip_wimg_bytes(K, DSPH_PREC_BF16X6);
+      qs.strips = ft.d_qstrips;
+      qs.prefix = ft.d_qprefix;
+      qs.tape_rows = ft.qtape_rows;
+      qs.gvals8 = plan->fused->d_gvals8;
+      qs.gdiag = plan->fused->d_gdiag;
+      qs.x_rows = sl.x_rows; qs.y_rows = sl.y_rows; qs.N = N;
+      qs.nstrips = ft.n_qstrips; qs.Fin = Fin; qs.Fout = Fout; qs.act = act; qs.ld = ld;
+      qs.num_cu = plan->fused->num_cu;
+      qs.cheb = sl.cheb;
+      qs.prep_weights = fused_images_claim(plan, workspace, IMG_QSTRIP);
+      const int rc = launch_cheb_qstrip(qs, stream);
+      if (rc != DSPH_OK) return rc;
+    } else if (strips && part != 2 && !dbg_only('b')) {
       StripLaunch st;
       st.x = x; st.w = w; st.bias = bias; st.y = y;
       st.wimg = static_cast<unsigned char*>(workspace) + wb + struct_wfrag_bytes(Fin, Fout, K);

@@ -1,0 +1,105 @@
+// Host side of the quad-strip kernel (cheb_qstrip_kernel.h): weight image and launch.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "cheb_qstrip_kernel.h"
+
+namespace dsph {
+
+// Weight image: one 1 KiB A-operand fragment of v_mfma_f32_16x16x32_bf16 per (role, quarter oq, level of the role, 32-channel
+// block kb, hi | lo): lane l, element i <- s_j m_j w[(32 kb + 8 (l >> 4) + i) * K + j][16 oq + (l & 15)], j the level (H: 4 - lev,
+// L: 1 - lev), s_j the sign kept with the plane (qs_wsign), m_0 = 2 in the Chebyshev basis (level 0 runs doubled: the kernel
+// halves y when it stores it).  The third level of role L is a zero block.
+__global__ __launch_bounds__(256) void qstrip_wprep_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Fin,
+                                                           int Fout, int cheb, int ld) {
+  constexpr int K = 5;
+  const int blk = blockIdx.x;  // ((role * 4 + oq) * 3 + lev) * 2 + kb
+  const int kb = blk & 1, lev = (blk >> 1) % 3, oq = ((blk >> 1) / 3) & 3, role = (blk >> 1) / 12;
+  const int j = role == 0 ? K - 1 - lev : 1 - lev;
+  const bool have = role == 0 || lev < 2;
+  const float sc = qs_wsign(cheb != 0, j) * ((cheb != 0 && j == 0) ? 2.f : 1.f);
+  unsigned char* base = out + (size_t)blk * 2 * QS_FRAG;
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int l = e >> 3, i = e & 7;
+    const int ch = 32 * kb + 8 * (l >> 4) + i, col = 16 * oq + (l & 15);
+    const float v = (have && ch < Fin && col < Fout) ? sc * w[((int64_t)ch * K + j) * ld + col] : 0.f;
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    reinterpret_cast<__bf16*>(base)[l * 8 + i] = hi;
+    reinterpret_cast<__bf16*>(base + QS_FRAG)[l * 8 + i] = lo;
+  }
+}
+
+bool qstrip_shape_ok(int32_t Fin, int32_t Fout, int32_t K) { return K == 5 && Fin == 64 && Fout == 64; }
+
+// one workgroup per CU (a multiple of 8: the kernel deals XCD by XCD); fewer when a workgroup would get under 64 rows
+int qstrip_grid(int num_cu, int64_t tape_rows) { return (int)std::max<int64_t>(8, std::min<int64_t>(num_cu / 8 * 8, tape_rows / 64 / 8 * 8)); }
+// steps of the busiest workgroup: its share of the tape plus nine run-in steps per piece, every piece rounded up to whole
+// triples of steps (the step body is unrolled three times)
+int64_t qstrip_span(int num_cu, int64_t tape_rows, int64_t mean_height) {
+  const int g = qstrip_grid(num_cu, tape_rows);
+  const int64_t share = (tape_rows + g - 1) / g, pieces = share / std::max<int64_t>(1, mean_height) + 2;
+  return share + pieces * (2 * QS_D + 1 + 1);
+}
+
+size_t qstrip_wimg_bytes() { return (size_t)2 * 4 * 3 * 2 * 2 * QS_FRAG; }  // 96 KiB
+
+int launch_cheb_qstrip(const QStripLaunch& s, hipStream_t stream) {
+  if (s.prep_weights) {
+    hipLaunchKernelGGL(qstrip_wprep_kernel, dim3(2 * 4 * 3 * 2), dim3(256), 0, stream, s.w, s.wimg, (int)s.Fin, (int)s.Fout, s.cheb ? 1 : 0,
+                       (int)s.ld);
+    DSPH_HIP(hipGetLastError());
+  }
+  QStripArgs a;
+  a.x = s.x;
+  a.bias = s.bias;
+  a.y = s.y;
+  a.wimg = s.wimg;
+  a.gvals8 = s.gvals8;
+  a.gdiag = s.gdiag;
+  a.strips = s.strips;
+  a.prefix = s.prefix;
+  a.x_rows = s.x_rows;
+  a.y_rows = s.y_rows;
+  a.nstrips = s.nstrips;
+  a.N = (int)s.N;
+  a.Fin = s.Fin;
+  a.Fout = s.Fout;
+  a.ld = s.ld;
+  a.act = s.act;
+  const int grid = qstrip_grid(s.num_cu, s.tape_rows * s.N);
+  void (*kern)(QStripArgs) = s.cheb ? cheb_qstrip5_kernel<true> : cheb_qstrip5_kernel<false>;
+#ifdef DSPH_QS_STAMPS
+  static unsigned* d_stamps = nullptr;
+  constexpr size_t NST = 8 * 4 * 10;
+  if (!d_stamps) DSPH_HIP(hipMalloc(&d_stamps, NST * 4));
+  DSPH_HIP(hipMemsetAsync(d_stamps, 0, NST * 4, stream));
+  a.stamps = d_stamps;
+#endif
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(QS_THREADS), 0, stream, a);
+  DSPH_HIP(hipGetLastError());
+#ifdef DSPH_QS_STAMPS
+  if (getenv("DSPH_STAMPS_DUMP")) {
+    std::vector<unsigned> h(NST);
+    if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(h.data(), d_stamps, NST * 4, hipMemcpyDeviceToHost) == hipSuccess)
+      for (int w = 0; w < 8; ++w)
+        for (int it = 0; it < 4; ++it) {
+          const unsigned* r = &h[((size_t)w * 4 + it) * 10];
+          fprintf(stderr, "QSSTAMP wave %d step %2d:", w, it);
+          unsigned prev = r[0];
+          for (int i = 1; i <= 8; ++i) {
+            if (r[i] == 0) { fprintf(stderr, "      -"); continue; }
+            fprintf(stderr, " %6u", r[i] - prev);
+            prev = r[i];
+          }
+          fprintf(stderr, " | step %u | t0 %u\n", r[8] - r[0], r[0]);
+        }
+  }
+#endif
+  return DSPH_OK;
+}
+
+}  // namespace dsph

@@ -153,6 +153,10 @@ int dsph_plan_set_option(dsph_plan* p, int32_t option, int64_t value) {
       break;
     case DSPH_OPT_TSTEP: o.tstep = value != 0; tables = false; break;
     case DSPH_OPT_PACK: o.pack = value != 0; tables = false; break;
+    case DSPH_OPT_STRIP_FORM:
+      if (value < 0 || value > 1) { set_error("plan_set_option: DSPH_OPT_STRIP_FORM takes 0 (quad strips) or 1 (strip pairs)"); return DSPH_E_BADARG; }
+      o.strip_form = (int)value;
+      break;
     default: set_error("plan_set_option: unknown option %d", (int)option); return DSPH_E_BADARG;
   }
   if (tables && p->fused) {

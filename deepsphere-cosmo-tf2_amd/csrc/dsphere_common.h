@@ -47,6 +47,7 @@ struct PlanOptions {
   bool strip_generic = false;  // DSPH_OPT_STRIP_GENERIC: compiler-scheduled strip kernel instead of the hand-ordered one
   int split_order = 0;       // DSPH_OPT_SPLIT: K > 5 by the product identity (0 auto, 1 always when possible, 2 never)
   bool tstep = true;         // DSPH_OPT_TSTEP: wide graphs step through LDS tiles (cheb_tstep.hip) instead of the gather kernel
+  int strip_form = 0;        // DSPH_OPT_STRIP_FORM: 0 quad strips (cheb_qstrip_kernel.h), 1 strip pairs (cheb_strip_kernel.h)
   bool pack = true;          // DSPH_OPT_PACK: narrow layers run several maps per item / wave when the batch has more than one
 };
 
@@ -195,6 +196,26 @@ struct StripLaunch {
 bool strip_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
 size_t strip_wimg_bytes(int32_t Fin, int32_t Fout, int32_t K);
 int launch_cheb_strip(const StripLaunch& s, hipStream_t stream);
+
+// quad-strip kernel (cheb_qstrip.hip, round 5): the same rectangles in 64-column strips, four pixels per lane
+struct QStrip;
+struct QStripLaunch {
+  const float* x; const float* w; const float* bias; float* y;
+  unsigned char* wimg;       // workspace: qstrip_wimg_bytes()
+  const QStrip* strips;      // device list of strips (uncut along y: the kernel cuts the tape of their rows by workgroup)
+  const int32_t* prefix;     // device [nstrips + 1]: rows of the strips before each one
+  int64_t tape_rows;         // prefix[nstrips]
+  const float* gvals8; const float* gdiag;
+  int64_t x_rows, y_rows, N;
+  int32_t nstrips, Fin, Fout, act, ld, num_cu;
+  bool cheb;
+  bool prep_weights = true;
+};
+bool qstrip_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
+size_t qstrip_wimg_bytes();
+int qstrip_grid(int num_cu, int64_t tape_rows);
+int64_t qstrip_span(int num_cu, int64_t tape_rows, int64_t mean_height);
+int launch_cheb_qstrip(const QStripLaunch& s, hipStream_t stream);
 
 // NEST pooling (healpix_pool.hip)
 int launch_healpix_pool(const float* x, float* y, int64_t rows_out, int32_t F, int32_t group, bool maxp, hipStream_t stream);

@@ -26,6 +26,8 @@ BASIS_CHEBYSHEV, BASIS_MONOMIAL = 0, 1
 # dsph_plan_set_option (include/dsphere.h: DSPH_OPT_*)
 OPT_STRIPS, OPT_STRUCT, OPT_TABLES, OPT_FORK, OPT_STRIP_SEG, OPT_STRIP_MINROWS, OPT_STRIP_GENERIC, OPT_SPLIT, OPT_TSTEP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_PACK = 10
+OPT_STRIP_FORM = 11
+STRIP_FORM_QUAD, STRIP_FORM_PAIRS = 0, 1
 STRIPS_AUTO, STRIPS_ALWAYS, STRIPS_NEVER = 0, 1, 2
 SPLIT_AUTO, SPLIT_ALWAYS, SPLIT_NEVER = 0, 1, 2
 

@@ -131,6 +131,10 @@ int dsph_plan_prepare_layer(dsph_plan* plan, int32_t K, int32_t Fin, int32_t Fou
  *   DSPH_OPT_STRIP_SEG      rows per strip segment, 0 (default) = chosen by the makespan rule          (tuning)
  *   DSPH_OPT_STRIP_MINROWS  least height of a strip rectangle in tiles, default 4                      (tuning)
  *   DSPH_OPT_STRIP_GENERIC  0 (default) / 1: the compiler-scheduled strip kernel at K = 5              (diagnosis)
+ *   DSPH_OPT_STRIP_FORM     which strip kernel takes the rectangles of the 64 -> 64, K = 5, three-term shape: 0 (default) the
+ *                           quad strips of round 5 (64-column strips, four pixels per lane, csrc/cheb_qstrip_kernel.h),
+ *                           1 the strip pairs of round 3 (32-column strips, csrc/cheb_strip_kernel.h).  Same rectangles, same
+ *                           arithmetic, another order of summation inside a row: equal to rounding, not bit for bit.
  *   DSPH_OPT_SPLIT          K > 5: 0 (default) the faster of the two routes by rule, 1 always the product identity
  *                           T_{4+j} = 2 T_4 T_j - T_{|4-j|} (passes of K <= 5 on the fast kernels), 2 never
  *   DSPH_OPT_TSTEP          1 (default) / 0: graphs wider than the fused kernels take (ELL width 13 .. 32: the reference's 20
@@ -153,6 +157,7 @@ int dsph_plan_prepare_layer(dsph_plan* plan, int32_t K, int32_t Fin, int32_t Fou
 #define DSPH_OPT_SPLIT 8
 #define DSPH_OPT_TSTEP 9
 #define DSPH_OPT_PACK 10
+#define DSPH_OPT_STRIP_FORM 11
 int dsph_plan_set_option(dsph_plan* plan, int32_t option, int64_t value);
 
 int64_t dsph_plan_rows(const dsph_plan* plan);

@@ -193,7 +193,7 @@ def test_headline_config_as_benchmarked():
     # batch on this device (if the rule flipped on another box the test would silently check other kernels)
     assert plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N) == 46128, "12 base pixels x (62 x 62) interior class-R tiles"
     pairs = plan.strip_pairs(K)
-    assert pairs.shape == (252, 12), "21 pairs per base pixel"
+    assert pairs.shape == (216, 12), "18 quad strips (56 output columns each, the last one 40) per base pixel, uncut along y"
     seams = _strip_seam_rows(pairs)
     assert seams.size > 1500 and seams.max() < M
     centres = np.unique(np.concatenate([_special_rows(nside, M, np.random.default_rng(3)), seams]))
