@@ -1068,7 +1068,7 @@ static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fi
   if (use_qstrips(plan, ft, Fin, Fout, K)) {
     // (a quad-strip step takes 2.8 us, a tile-map 18.7; the tape of rows is cut evenly, so the span is a formula)
     if (N < 1) return false;
-    const int64_t span = qstrip_span(fp->num_cu, ft.qtape_rows * N, ft.qtape_rows / std::max(1, ft.n_qstrips));
+    const int64_t span = qstrip_split(fp->num_cu, ft.qtape_rows, N, ft.qtape_rows / std::max(1, ft.n_qstrips), nullptr, nullptr, nullptr);
     return span * 28 * 103 < ft.n_strip_tiles * N * 187 / fp->num_cu * 100;
   }
   const std::vector<int32_t>& steps = ft.strip_steps;

@@ -35,14 +35,29 @@ __global__ __launch_bounds__(256) void qstrip_wprep_kernel(const float* __restri
 
 bool qstrip_shape_ok(int32_t Fin, int32_t Fout, int32_t K) { return K == 5 && Fin == 64 && Fout == 64; }
 
-// one workgroup per CU (a multiple of 8: the kernel deals XCD by XCD); fewer when a workgroup would get under 64 rows
-int qstrip_grid(int num_cu, int64_t tape_rows) { return (int)std::max<int64_t>(8, std::min<int64_t>(num_cu / 8 * 8, tape_rows / 64 / 8 * 8)); }
-// steps of the busiest workgroup: its share of the tape plus nine run-in steps per piece, every piece rounded up to whole
-// triples of steps (the step body is unrolled three times)
-int64_t qstrip_span(int num_cu, int64_t tape_rows, int64_t mean_height) {
-  const int g = qstrip_grid(num_cu, tape_rows);
-  const int64_t share = (tape_rows + g - 1) / g, pieces = share / std::max<int64_t>(1, mean_height) + 2;
-  return share + pieces * (2 * QS_D + 1 + 1);
+// How the kernel's workgroups share the work (cheb_qstrip_kernel.h): G workgroups (a multiple of 8: the kernel deals XCD by
+// XCD; one per CU, fewer when a workgroup would get under 64 rows), the per-map tape of `tape_rows` rows cut into P pieces, w
+// workgroups per piece taking every w-th map.  w = N (one map each, in step on the same rows of L~) when the batch fits;
+// otherwise the w in {1, 2, 4, ...} with the shortest busiest workgroup.  Returns that workgroup's steps: its rows plus nine
+// run-in steps per run of rows, every run rounded up to whole triples of steps (the step body is unrolled three times).
+int64_t qstrip_split(int num_cu, int64_t tape_rows, int64_t N, int64_t mean_height, int* grid, int* pieces, int* wg_per_piece) {
+  const int g = (int)std::max<int64_t>(8, std::min<int64_t>(num_cu / 8 * 8, tape_rows * N / 64 / 8 * 8));
+  auto span_of = [&](int64_t w) {
+    const int64_t P = std::max<int64_t>(1, g / w), share = (tape_rows + P - 1) / P, maps = (N + w - 1) / w;
+    const int64_t runs = share / std::max<int64_t>(1, mean_height) + 2;
+    return (share + runs * (2 * QS_D + 1 + 1)) * maps;
+  };
+  int64_t best_w = 1, best = -1;
+  if (N <= g) { best_w = N; best = span_of(N); }
+  else
+    for (int64_t w = 1; w <= g; w *= 2) {
+      const int64_t sp = span_of(w);
+      if (best < 0 || sp < best) { best = sp; best_w = w; }
+    }
+  if (grid) *grid = g;
+  if (pieces) *pieces = (int)std::max<int64_t>(1, g / best_w);
+  if (wg_per_piece) *wg_per_piece = (int)best_w;
+  return best;
 }
 
 size_t qstrip_wimg_bytes() { return (size_t)2 * 4 * 3 * 2 * 2 * QS_FRAG; }  // 96 KiB
@@ -70,7 +85,8 @@ int launch_cheb_qstrip(const QStripLaunch& s, hipStream_t stream) {
   a.Fout = s.Fout;
   a.ld = s.ld;
   a.act = s.act;
-  const int grid = qstrip_grid(s.num_cu, s.tape_rows * s.N);
+  int grid;
+  (void)qstrip_split(s.num_cu, s.tape_rows, s.N, s.tape_rows / std::max(1, s.nstrips), &grid, &a.pieces, &a.wg_per_piece);
   void (*kern)(QStripArgs) = s.cheb ? cheb_qstrip5_kernel<true> : cheb_qstrip5_kernel<false>;
 #ifdef DSPH_QS_STAMPS
   static unsigned* d_stamps = nullptr;

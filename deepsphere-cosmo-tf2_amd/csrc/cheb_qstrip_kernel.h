@@ -20,9 +20,11 @@
 //   wave = (role H | L) x (output-channel quarter oq).  H: levels 4, 3, 2; L: levels 1, 0 one step later, b2 and the dying b3
 //   row crossing through LDS under a counter as in the strip kernel.  Every wave keeps the weights of its levels and quarter
 //   in registers (H 48, L 32 VGPRs).
-// Work items: the rows of all (strip, map) units laid end to end form one tape (strip-major: the maps of a strip are
-//   neighbours); workgroup i of G takes rows [R i / G, R (i + 1) / G) of it, i.e. a few pieces of strips, each a run of rows
-//   with its own 9 run-in steps -- every workgroup gets the same number of rows whatever the strips' heights and the batch.
+// Work items: the rows of all strips laid end to end form one tape per map; it is cut into P equal pieces (a piece = a few runs
+//   of rows of consecutive strips, each run with its own 9 run-in steps), and w workgroups share a piece, workgroup j of them
+//   taking the maps j, j + w, ... -- for a batch of N <= G maps w = N and P = G / N: every workgroup gets the same number of
+//   rows whatever the strips' heights, and the N workgroups of a piece (neighbours on one XCD) walk the same rows of L~ at the
+//   same time, one map each (the host picks P and w: qstrip_split).
 // LDS (162,880 B): ring of 7 rows of x as bf16 hi | lo B-operand fragments (16 KiB per row: [32-channel block][hi | lo][tile]
 //   1 KiB fragments), hand-over 4 x 8 KiB, ring of 6 rows of L~ (2,560 B per row: directions 0-3 per [tile][p], directions
 //   4-7 per [tile][p], diagonal per [p][tile], W once more per [p][tile]), counters.
@@ -73,6 +75,7 @@ struct QStripArgs {
   const int32_t* prefix;      // [nstrips + 1] rows of the strips before strip s (the "tape" of one map; prefix[nstrips] = all rows)
   int64_t x_rows, y_rows;
   int nstrips, N, Fin, Fout, ld, act;
+  int pieces, wg_per_piece;   // the tape is cut into `pieces`; `wg_per_piece` workgroups share a piece, each taking every wg_per_piece-th map
 #ifdef DSPH_QS_STAMPS
   unsigned* stamps;
 #endif
@@ -99,7 +102,8 @@ struct QStripArgs {
 #endif
 
 // Tuning builds only (results wrong by construction): -DDSPH_QS_ABL=bits: 2 no MFMA, 4 no stencil units, 8 no x loads,
-// 16 no y stores, 64 plain multiply-adds for the DPP ones
+// 16 no y stores, 64 plain multiply-adds for the DPP ones, 512 B fragments not read from LDS, 1024 values of L~ not read from
+// LDS, 2048 no hand-over rows, 4096 no fragment stores of x
 #ifdef DSPH_QS_ABL
 #define QS_ABL DSPH_QS_ABL
 #else
@@ -249,22 +253,22 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   };
   for (int i = tid; i < (LDS_FLAG + 64) / 16; i += QS_THREADS) reinterpret_cast<qs_f4*>(smem)[i] = qs_f4{0.f, 0.f, 0.f, 0.f};
 
-  // this workgroup's piece of the tape: the workgroups of one XCD (blockIdx & 7) take neighbouring pieces (they share an L2)
+  // this workgroup's piece of the tape and its maps: the workgroups of one XCD (blockIdx & 7) are neighbours in `ord`
   const int G = gridDim.x, ord = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // (the host launches a multiple of 8)
-  const int64_t tape = (int64_t)a.prefix[a.nstrips] * a.N;
-  const int64_t tape_begin = tape * ord / G, tape_end = tape * (ord + 1) / G;
+  const int piece = ord / a.wg_per_piece, map0 = ord - piece * a.wg_per_piece;
+  if (piece >= a.pieces) return;  // (before the first barrier: the whole workgroup leaves)
+  const int64_t tape = (int64_t)a.prefix[a.nstrips];
+  const int64_t tape_begin = tape * piece / a.pieces, tape_end = tape * (piece + 1) / a.pieces;
   // the piece that starts at tape row r: strip, map, first row and length (wave-uniform arithmetic)
-  auto locate = [&](int64_t r, int64_t r_end, QStrip& st, int& nq) __attribute__((always_inline)) -> int {
+  auto locate = [&](int64_t r, int64_t r_end, QStrip& st) __attribute__((always_inline)) -> int {
     int lo = 0, hi = a.nstrips;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if ((int64_t)a.prefix[mid] * a.N <= r) lo = mid; else hi = mid;
+      if ((int64_t)a.prefix[mid] <= r) lo = mid; else hi = mid;
     }
     st = a.strips[lo];
     const int h = st.y1 - st.y0;
-    const int64_t rel = r - (int64_t)a.prefix[lo] * a.N;
-    nq = (int)(rel / h);
-    const int off = (int)(rel - (int64_t)nq * h);
+    const int off = (int)(r - (int64_t)a.prefix[lo]);
     const int len = (int)(((int64_t)(h - off) < r_end - r) ? (int64_t)(h - off) : r_end - r);
     st.y0 += off;
     st.y1 = st.y0 + len;
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(xv[0]), "+v"(xv[1]) : : "memory");
   };
   auto xstore = [&](int slot, const qs_f4 (&xv)[2]) __attribute__((always_inline)) {
+    if (QS_ABL & 4096) { asm volatile("" : : "v"(xv[0]), "v"(xv[1])); return; }
     unsigned char* q = smem + (unsigned)slot * ROWB + x_loff;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -330,6 +335,11 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   auto clo_read = [&](int slot) __attribute__((always_inline)) -> QCoefLo {
     const unsigned char* q = smem + LDS_C + (unsigned)slot * CROWB + (unsigned)p * 16u;
     QCoefLo c;
+    if (QS_ABL & 1024) {
+      c.dg = qs_f4{0.1f, 0.1f, 0.1f, 0.1f}; c.wd = c.dg; c.gb[0] = c.gb[1] = c.gb[2] = c.gb[3] = c.dg;
+      asm volatile("" : "+v"(c.dg), "+v"(c.wd), "+v"(c.gb[0]), "+v"(c.gb[1]), "+v"(c.gb[2]), "+v"(c.gb[3]));
+      return c;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) c.gb[t] = *reinterpret_cast<const qs_f4*>(q + 1024u + (unsigned)t * 256u);
     c.dg = *reinterpret_cast<const qs_f4*>(q + 2048u);
@@ -339,6 +349,11 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   auto chi_read = [&](int slot) __attribute__((always_inline)) -> QCoefHi {
     const unsigned char* q = smem + LDS_C + (unsigned)slot * CROWB + (unsigned)p * 16u;
     QCoefHi c;
+    if (QS_ABL & 1024) {
+      c.ga[0] = qs_f4{0.1f, 0.1f, 0.1f, 0.1f}; c.ga[1] = c.ga[2] = c.ga[3] = c.ga[0];
+      asm volatile("" : "+v"(c.ga[0]), "+v"(c.ga[1]), "+v"(c.ga[2]), "+v"(c.ga[3]));
+      return c;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) c.ga[t] = *reinterpret_cast<const qs_f4*>(q + (unsigned)t * 256u);
     return c;
@@ -351,7 +366,11 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   // The MFMA chain of one level (24 MFMAs: 2 channel blocks x 2 pairs of tiles x 3 terms x 2 tiles) beside NU stencil units:
   // MFMA m is followed by the units that fall to it.  Consecutive MFMAs go to different tiles; the fragments of the next
   // (block, pair) are requested when the current one starts.  Order of the three terms: W_hi.x_lo, W_lo.x_hi, W_hi.x_hi.
+#if QS_ABL & 512
+#define QS_FRLOAD(P) (wr[0][0][0])
+#else
 #define QS_FRLOAD(P) (*reinterpret_cast<const qs_bf8*>(P))
+#endif
 #define QS_ORD_A(j) ((j) == 1 ? 1 : 0)
 #define QS_ORD_B(j) ((j) == 0 ? 1 : 0)
 #define QS_FR0(FADDR)                                                                                                     \
@@ -409,8 +428,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
     int handed = 0;
     for (int64_t tr = tape_begin; tr < tape_end;) {
       QStrip st;
-      int nq;
-      tr += locate(tr, tape_end, st, nq);
+      tr += locate(tr, tape_end, st);
+      for (int nq = map0; nq < a.N; nq += a.wg_per_piece) {
       const unsigned sXc = st_spread((unsigned)min(max(st.xs + 4 * p + oq, st.xlo), st.xhi));         // L~: pixel 4 p + oq
       const unsigned sXf = st_spread((unsigned)min(max(st.xs + 4 * xpix + xt, st.xlo), st.xhi));      // x: pixel 4 xpix + xt
       const int T3 = ((st.y1 - st.y0) + 2 * D + 1 + 3) / 3;
@@ -491,7 +510,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         QS_STAMP(4);
         // hand-over: b2[new] and the dying row of b3 -- once L has taken the previous pair
         for (int spin = 0; flag_get() <= handed && spin < (1 << 22); ++spin) {}  // (bounded: a lost partner must not hang the device)
-        {
+        if (!(QS_ABL & 2048)) {
           unsigned char* hp = smem + hand;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -517,6 +536,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
         step(std::integral_constant<int, 2>{});
+      }
       }
     }
   } else {
@@ -547,8 +567,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
     int taken = 0;
     for (int64_t tr = tape_begin; tr < tape_end;) {
       QStrip st;
-      int nq;
-      tr += locate(tr, tape_end, st, nq);
+      tr += locate(tr, tape_end, st);
+      for (int nq = map0; nq < a.N; nq += a.wg_per_piece) {
       const unsigned sXf = st_spread((unsigned)min(max(st.xs + 4 * xpix + xt, st.xlo), st.xhi));
       unsigned sXt[4];
 #pragma unroll
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         qs_f4 xv[2];
         xfetch(xmap, sXf, spread_y(ytop + 1), xv);
         // the rows H left at the end of the previous step: b2[new] -> R[0][L2] (the set that died then), b3 -> R[1][L2]
-        {
+        if (!(QS_ABL & 2048)) {
           const unsigned char* hp = smem + hand;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -669,6 +689,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
         step(std::integral_constant<int, 2>{});
+      }
       }
     }
   }

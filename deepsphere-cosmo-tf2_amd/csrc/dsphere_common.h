@@ -213,8 +213,7 @@ struct QStripLaunch {
 };
 bool qstrip_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
 size_t qstrip_wimg_bytes();
-int qstrip_grid(int num_cu, int64_t tape_rows);
-int64_t qstrip_span(int num_cu, int64_t tape_rows, int64_t mean_height);
+int64_t qstrip_split(int num_cu, int64_t tape_rows, int64_t N, int64_t mean_height, int* grid, int* pieces, int* wg_per_piece);
 int launch_cheb_qstrip(const QStripLaunch& s, hipStream_t stream);
 
 // NEST pooling (healpix_pool.hip)

@@ -467,8 +467,8 @@ class ShardedChebyshev:
         """Sum over the ranks, in place (RCCL; host-staged under a gloo group like the halo exchange)."""
         import torch.distributed as dist
 
-        if self.world == 1:
-            return t
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            return t  # (a one-rank process group still goes through the collective: the sum over one rank)
         if t.is_cuda and dist.get_backend(self.group) == "gloo":
             h = t.cpu()
             dist.all_reduce(h, group=self.group)

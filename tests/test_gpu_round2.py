@@ -178,6 +178,32 @@ def _strip_seam_rows(pairs):
     return np.unique(_interleave(np.array(xs), np.array(ys)))
 
 
+def _tape_cut_rows(pairs, N):
+    """The seams the quad-strip kernel makes at run time (csrc/cheb_qstrip_kernel.h, qstrip_split): the rows of all strips form
+    one tape per map, cut into P = G / N equal pieces (G workgroups, N of them per piece, one map each) -- so a strip is cut
+    wherever a piece ends.  Returns centres on both sides of every cut, at the first and last output column of the strip."""
+    num_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    h = (pairs[:, 7] - pairs[:, 6]).astype(np.int64)
+    prefix = np.concatenate([[0], np.cumsum(h)])
+    R = int(prefix[-1])
+    G = int(max(8, min(num_cu // 8 * 8, R * N // 64 // 8 * 8)))
+    assert N <= G, "this helper restates the cut for batches that fit the grid: w = N workgroups per piece"
+    P = G // N
+    xs, ys = [], []
+    for i in range(1, P):
+        r = R * i // P
+        s = int(np.searchsorted(prefix, r, side="right") - 1)
+        off = r - int(prefix[s])
+        if off == 0:
+            continue  # the cut falls between two strips
+        y = int(pairs[s, 6]) + off
+        for cx in (int(pairs[s, 0]), int(pairs[s, 0] + pairs[s, 2]) - 1):
+            for ry in (y - 2, y - 1, y, y + 1):
+                xs.append(cx)
+                ys.append(ry)
+    return np.unique(_interleave(np.array(xs), np.array(ys))), G
+
+
 def test_headline_config_as_benchmarked():
     """BASELINE configs[2] exactly as bench.py times it: nside 1024, K 5, 64 -> 64, BATCH 4 (element offsets beyond
     2^32 in maps 2 and 3), split-bf16 contraction, fused kernels, bias + ReLU -- the patch oracle at rows in every
@@ -196,7 +222,9 @@ def test_headline_config_as_benchmarked():
     assert pairs.shape == (216, 12), "18 quad strips (56 output columns each, the last one 40) per base pixel, uncut along y"
     seams = _strip_seam_rows(pairs)
     assert seams.size > 1500 and seams.max() < M
-    centres = np.unique(np.concatenate([_special_rows(nside, M, np.random.default_rng(3)), seams]))
+    cuts, G = _tape_cut_rows(pairs, N)
+    assert G == 256 and cuts.size > 300 and cuts.max() < M, "63 cuts of the tape of rows, four rows x two columns each"
+    centres = np.unique(np.concatenate([_special_rows(nside, M, np.random.default_rng(3)), seams, cuts]))
     ref = _patch_reference(cols, vals, x, W, K, centres, bias=b, activation="relu")
     got = y[:, torch.as_tensor(centres).cuda()].cpu().numpy()
     err = np.abs(got - ref).max(axis=(1, 2)) / s
@@ -236,7 +264,8 @@ def test_config5_partial_sky_as_benchmarked():
     # the cost rule at this size and batch (0.95 of the tile cost): the strips are taken, as bench.py --config c5 times it
     n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
     assert n_strip > 0, "C5 at batch 16 runs its rectangles on the strip kernel"
-    seams = _strip_seam_rows(plan.strip_pairs(K)[::7])  # every seventh pair of the ragged cut
+    seams = _strip_seam_rows(plan.strip_pairs(K)[::7])  # every seventh strip of the ragged cut
+    seams = np.unique(np.concatenate([seams, _tape_cut_rows(plan.strip_pairs(K), N)[0][::5]]))  # and every fifth run-time cut of the tape
     seams = seams[seams < M]
     ref2 = _patch_reference(cols, vals, x[:2], W, K, seams, bias=b, activation="relu")
     err2 = np.abs(y[:2, torch.as_tensor(seams).cuda()].cpu().numpy() - ref2).max() / s

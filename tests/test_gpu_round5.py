@@ -1,0 +1,191 @@
+"""Round-5 GPU tests (all through the C ABI): the quad-strip kernel (csrc/cheb_qstrip_kernel.h) against the float64 oracle and
+against the strip pairs of round 3; the library's own record of the packed weight images (DSPH_FWD_KEEP_WEIGHTS across batch
+sizes: ADVICE r4); dsph_plan_prepare_layer; one rank of RCCL."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from deepsphere import _native, gnn_layers
+from helpers import rel_err
+from oracle import cheb_oracle as orc
+from test_gpu_round3 import TOL, _csr, _dev, _grid_ell
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(cols, vals, K, Fin, opts=None):
+    plan = _native.LaplacianPlan(cols, vals, device=0, options=opts)
+    plan.prepare(K, Fin)
+    return plan
+
+
+@pytest.mark.parametrize("nside,N,basis,act", [
+    (256, 3, "chebyshev", "relu"),   # 224 interior columns: four strips of 56; an odd batch: the tape of rows is cut inside strips
+    (128, 5, "monomial", None),      # 96 columns: one strip of 56 and one of 40; the other basis, no epilogue
+])
+def test_quad_strips_whole_map_and_against_the_strip_pairs(nside, N, basis, act):
+    """Whole maps on the quad-strip kernel (the default form) against the float64 oracle -- every row, so every seam the
+    run-time cut of the tape makes -- and against the same plan on the strip pairs of round 3 (another order of summation
+    inside a row: rounding)."""
+    K, Fin, Fout = 5, 64, 64
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(nside + N)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    fwd = orc.chebyshev_forward if basis == "chebyshev" else orc.monomial_forward
+    ref = fwd(_csr(cols, vals), x, W, K, bias=b, activation=act)
+    B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
+    kw = dict(act=_native.ACT_RELU if act == "relu" else _native.ACT_NONE, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED, basis=B)
+    ys = {}
+    for form in (_native.STRIP_FORM_QUAD, _native.STRIP_FORM_PAIRS):
+        plan = _plan(cols, vals, K, Fin, {_native.OPT_STRIPS: _native.STRIPS_ALWAYS, _native.OPT_STRIP_FORM: form})
+        nt = nside // 16
+        assert plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N) == 12 * (nt - 2) ** 2
+        pairs = plan.strip_pairs(K)
+        if form == _native.STRIP_FORM_QUAD:
+            per_face = -(-16 * (nt - 2) // 56)
+            assert pairs.shape == (12 * per_face, 12) and np.all(pairs[:, 3] == 0), "uncut 64-column strips, one per record"
+            assert np.all(pairs[:, 2] <= 56) and np.all(pairs[:, 7] - pairs[:, 6] == 16 * (nt - 2))
+        y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, **kw)
+        y2, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, **kw)
+        assert torch.equal(y, y2), "two launches of the same inputs must agree bit for bit"
+        err = rel_err(y.cpu().numpy(), ref)
+        print(f"strip form {form} nside={nside} N={N} {basis}: rel err {err:.2e}")
+        assert err < TOL
+        ys[form] = y
+    scale = float(np.abs(ref).max())
+    assert float((ys[_native.STRIP_FORM_QUAD] - ys[_native.STRIP_FORM_PAIRS]).abs().max()) / scale < 2 * TOL
+
+
+def test_kept_weight_images_across_batch_sizes_and_kernels():
+    """ADVICE r4 (cheb_fused.hip): which weight images a forward packs depends on the batch -- strips or tiles by the cost rule,
+    maps packed four to an item or not -- and the caller's key cannot see that.  The library keeps its own record per
+    workspace block: a kept call packs what the block lacks.  One layer, the same workspace, batches that flip the choice."""
+    K, Fin, Fout = 5, 64, 64
+    cols, vals = _grid_ell(128)
+    M = cols.shape[0]
+    rng = np.random.default_rng(7)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    plan = _native.LaplacianPlan(cols, vals, device=0)  # the cost rule decides: one map on the tile kernels, 64 maps on the strips
+    plan.prepare(K, Fin)
+    assert plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=1) == 0 and plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=64) > 0
+    kw = dict(precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    xs = {n: torch.randn((n, M, Fin), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(n)) for n in (1, 64, 2)}
+    fresh = {n: _native.cheb_forward(plan, xs[n], _dev(W), None, K, **kw)[0] for n in xs}
+    ws = None
+    first = True
+    for n in (1, 64, 2, 64, 1):
+        y, ws = _native.cheb_forward(plan, xs[n], _dev(W), None, K, workspace=ws, keep_weights=not first, **kw)
+        first = False
+        assert torch.equal(y, fresh[n]), f"batch {n} on kept weight images must equal a fresh call"
+
+
+def test_kept_weight_images_of_the_chain_of_passes_across_batch_sizes():
+    """ADVICE r4 (cheb_split.hip): the K > 5 route keeps its derived matrices and per-pass images at offsets that do not depend
+    on the batch; N = 4, then 2, then 4 on one layer equals fresh layers."""
+    K, Fin, Fout = 10, 5, 7
+    cols, vals = _grid_ell(32)
+    M = cols.shape[0]
+    torch.manual_seed(3)
+    layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=Fout, device="cuda:0")
+    xs = {n: torch.randn((n, M, Fin), device="cuda:0") for n in (4, 2)}
+    with torch.no_grad():
+        layer(xs[4])  # builds
+        outs = [layer(xs[n]).clone() for n in (4, 2, 4, 2)]
+        for n, y in zip((4, 2, 4, 2), outs):
+            other = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=Fout, device="cuda:0")
+            other.build(xs[n].shape)
+            other.kernel.data.copy_(layer.kernel.data)
+            assert torch.equal(other(xs[n]), y), f"batch {n}: the kept chain of passes must equal a fresh layer"
+    ref = orc.chebyshev_forward(_csr(cols, vals), xs[2].cpu().numpy(), layer.kernel.detach().cpu().numpy(), K)
+    assert rel_err(outs[1].cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("K,Fin,Fout", [(7, 8, 8), (7, 8, 40), (10, 5, 7)])
+def test_prepare_layer_builds_what_the_forward_uses(K, Fin, Fout):
+    """dsph_plan_prepare_layer: the tables of a K > 5 layer are chosen by the forward's own rule, which looks at
+    Fout too; after it a forward can be captured into a graph (no allocation, no synchronisation inside)."""
+    cols, vals = _grid_ell(32)
+    M = cols.shape[0]
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    plan.prepare(K, Fin, Fout=Fout)
+    rng = np.random.default_rng(K + Fout)
+    x = _dev(rng.standard_normal((2, M, Fin)))
+    W = _dev(rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K))
+    y0, ws = _native.cheb_forward(plan, x, W, None, K, precision=_native.PREC_BF16X6)
+    out = torch.empty_like(y0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            _native.cheb_forward(plan, x, W, None, K, precision=_native.PREC_BF16X6, workspace=ws, out=out, keep_weights=True)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, y0)
+
+
+def _one_rank_nccl_worker(port, out):
+    import torch.distributed as dist
+
+    from deepsphere import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))  # RCCL, before any other GPU work
+    try:
+        nside, K, Fin, Fout, N = 32, 5, 16, 32, 2
+        cols, vals = _grid_ell(nside)
+        M = cols.shape[0]
+        rng = np.random.default_rng(5)
+        x = _dev(rng.standard_normal((N, M, Fin)))
+        W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+        kernel = torch.nn.Parameter(_dev(W))
+        sh = sharding.ShardedChebyshev(cols, vals, K, rank=0, world=1, device="cuda:0", precision="fp32", algo="fused", kernel=kernel)
+        y = sh(x)
+        t = torch.ones(4, device="cuda:0")
+        dist.all_reduce(t)  # (a collective on the device, whatever the layer does)
+        y.square().sum().backward()  # dkernel goes through ShardedChebyshev._all_reduce: ncclAllReduce on one rank
+        layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=Fout, device="cuda:0", precision="fp32", use_bias=False,
+                                                       initializer=lambda w: w.copy_(torch.from_numpy(W)))
+        y1 = layer(x)
+        y1.square().sum().backward()
+        out.put({"backend": dist.get_backend(), "y_equal": bool(torch.equal(y.detach(), y1.detach())),
+                 "dk_err": float((kernel.grad - layer.kernel.grad).abs().max() / layer.kernel.grad.abs().max()),
+                 "allreduce_ok": bool(torch.equal(t.cpu(), torch.ones(4)))})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_of_rccl():
+    """librccl initialised and a collective executed by this code at least once -- a one-rank `nccl` process
+    group in a child process (before any other GPU work there), ShardedChebyshev at world 1 forward and backward through it
+    (the all-reduce of dkernel is a real ncclAllReduce), against the unsharded layer."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    proc = ctx.Process(target=_one_rank_nccl_worker, args=(port, out))
+    proc.start()
+    try:
+        res = out.get(timeout=300)
+    finally:
+        proc.join(timeout=120)
+        if proc.is_alive():
+            proc.kill()  # exactly the process started above
+    assert proc.exitcode == 0
+    print(res)
+    assert res["backend"] == "nccl" and res["allreduce_ok"]
+    assert res["y_equal"], "world 1: the sharded forward is the unsharded one"
+    assert res["dk_err"] < 1e-6

@@ -9,7 +9,8 @@ SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST
       "FETCH_SIZE"
       "WRITE_SIZE"
       "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
-      "GRBM_GUI_ACTIVE")
+      "GRBM_GUI_ACTIVE"
+      "SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC")
 i=0
 for P in "${SETS[@]}"; do
   i=$((i+1))
@@ -21,7 +22,7 @@ done
 python3 - <<PY
 import csv, glob, collections, json
 res = {}
-for i in range(1, 7):
+for i in range(1, 8):
     files = glob.glob("$out/p%d/**/*counter_collection.csv" % i, recursive=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for f in files:

@@ -94,10 +94,10 @@ static double run(const Case& c, bool check, int reps) {
     ms = t / reps;
     int64_t px = 0;
     for (const QStrip& s : strips) px += (int64_t)(s.y1 - s.y0) * s.w;
-    const int grid = qstrip_grid(256, L.tape_rows * N);
-    const int64_t span = qstrip_span(256, L.tape_rows * N, L.tape_rows / (int64_t)strips.size());
-    printf("S %d N %d: %zu strips, tape of %lld rows on %d workgroups, about %lld steps each: %.3f ms per launch = %.3f us per step; %.1f Mpix-maps/s, "
-           "%.1f GB/s of x + y\n", S, N, strips.size(), (long long)(L.tape_rows * N), grid, (long long)span, ms, ms * 1e3 / span, px * N / ms * 1e-3,
+    int grid, pieces, wpp;
+    const int64_t span = qstrip_split(256, L.tape_rows, N, L.tape_rows / (int64_t)strips.size(), &grid, &pieces, &wpp);
+    printf("S %d N %d: %zu strips, tape of %lld rows in %d pieces x %d workgroups (grid %d), about %lld steps each: %.3f ms per launch = %.3f us per step; %.1f Mpix-maps/s, "
+           "%.1f GB/s of x + y\n", S, N, strips.size(), (long long)L.tape_rows, pieces, wpp, grid, (long long)span, ms, ms * 1e3 / span, px * N / ms * 1e-3,
            px * N * 512.0 / ms * 1e-6);
   }
   if (check) {
@@ -142,6 +142,10 @@ static double run(const Case& c, bool check, int reps) {
 int main(int argc, char** argv) {
   if (argc > 1 && atoi(argv[1]) == 2) {  // (ablation / stamp builds: the timed case alone)
     run({1024, 4, 16, 1 << 30, true}, false, argc > 2 ? atoi(argv[2]) : 5);
+    return 0;
+  }
+  if (argc > 1 && atoi(argv[1]) == 3) {  // (the full-chip timing alone: eight maps)
+    run({1024, 8, 16, 1 << 30, true}, false, 3);
     return 0;
   }
   run({128, 2, 16, 1 << 30, true}, true, 0);
