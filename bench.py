@@ -232,7 +232,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--precision", default=None, choices=["auto", "fp32", "bf16x3", "bf16x6"],
+    ap.add_argument("--precision", default=None, choices=["auto", "fp32", "bf16x3", "bf16x6", "f16x3"],
                     help="contraction arithmetic; default: the layers' own default (gnn_layers.DEFAULT_PRECISION = auto: bf16x3 with 16 "
                          "or more input channels, else bf16x6).  bf16x3 = 3-term split-bf16 MFMA with fp32 accumulate (error "
                          "measured in the line); bf16x6 = fp32-equivalent 6-term split; fp32 = exact fp32 MFMA")
@@ -470,6 +470,7 @@ def main():
             "vs_baseline": None,
             "dtype": ({"fp32": "f32 (recurrence and contraction exact f32: v_mfma_f32_32x32x2_f32",
                        "bf16x6": "f32 (recurrence f32; contraction fp32-equivalent: 6-term exact split on the bf16 MFMA with f32 accumulate",
+                       "f16x3": "f32 (recurrence f32; contraction fp32-equivalent: 3-term split on the f16 MFMA (11 + 11 mantissa bits) with f32 accumulate",
                        "bf16x3": "f32 (recurrence f32; contraction 3-pass split-bf16 MFMA with f32 accumulate"}[resolved]
                       + (f"; precision '{resolved}' = the layer default for {Fin} input channels" if layer_default else f"; --precision {args.precision}")
                       + (f"; {err_note})" if err_note else ")")),
@@ -511,7 +512,10 @@ def main():
             legs = {"fp32": ("fp32_exact", "contraction on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain)", "mfma_f32", f_d / 157.3e12 * 1e3),
                     "bf16x6": ("fp32_split", "fp32-equivalent six-term split on v_mfma_f32_32x32x16_bf16 (operands split exactly into "
                                              "8 + 8 + 8 mantissa bits, products down to 2^-16 kept)", "mfma_bf16 x6", 6 * f_d / 2500e12 * 1e3),
-                    "bf16x3": ("bf16_split3", "three-term split on v_mfma_f32_32x32x16_bf16", "mfma_bf16 x3", 3 * f_d / 2500e12 * 1e3)}
+                    "f16x3": ("fp32_f16x3", "fp32-equivalent three-term split on v_mfma_f32_16x16x32_f16 (operands split into 11 + 11 mantissa "
+                                            "bits; the quad strips' arithmetic, the other tiles run the six-term bf16 split)", "mfma_f16 x3",
+                              3 * f_d / 2500e12 * 1e3),
+                    "bf16x3": ("bf16_split3", "three-term split on v_mfma_f32_16x16x32_bf16 (quad strips) / 32x32x16 (tiles)", "mfma_bf16 x3", 3 * f_d / 2500e12 * 1e3)}
             out["roofline"]["bounds_ms"] = {"hbm": round(t_hbm, 3), legs[resolved][2]: round(legs[resolved][3], 3)}
             if issue.get("valu_insts_per_forward"):
                 # what the kernels of this forward ISSUE (counters of the same build, profiles/hbm_traffic.json): a wave64

@@ -1060,8 +1060,8 @@ static bool use_qstrips(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin
 }
 static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t N,
                          int32_t ld) {
-  if (!(ft.n_pairs > 0 && precision == DSPH_PREC_BF16X3 && strip_shape_ok(Fin, Fout, K) && ld % 4 == 0 &&
-        plan->n_cols * (int64_t)std::max(Fin, ld) * 4 < (1ll << 32)))
+  if (!(ft.n_pairs > 0 && (precision == DSPH_PREC_BF16X3 || (precision == DSPH_PREC_F16X3 && use_qstrips(plan, ft, Fin, Fout, K))) &&
+        strip_shape_ok(Fin, Fout, K) && ld % 4 == 0 && plan->n_cols * (int64_t)std::max(Fin, ld) * 4 < (1ll << 32)))
     return false;
   if (ft.strip_forced) return true;
   FusedPlan* fp = plan->fused;
@@ -1447,6 +1447,10 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                void* workspace, size_t workspace_bytes, hipStream_t stream, const float* dy,
                                float* dw, int32_t ld, int32_t part, int32_t Fin_w, int32_t only, bool keep_weights,
                                const FusedPool* pool) {
+  // DSPH_PREC_F16X3 is the quad strips' arithmetic; every other kernel of the forward runs the six-term split (same accuracy)
+  const bool f16 = precision == DSPH_PREC_F16X3;
+  const int32_t strip_precision = precision;
+  if (f16) precision = DSPH_PREC_BF16X6;
   if (ld <= 0) ld = Fout;
   if (Fin_w <= 0) Fin_w = Fin;  // channels of w; smaller than Fin when x is a zero-padded copy  // row stride of w, bias-less y / dy / dw: the layer's Fout when this is one column block
   const bool wgrad_mode = dy != nullptr;  // y then carries the slab workspace
@@ -1489,7 +1493,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       sl.ypool_rows = plan->n_rows / 4;
     }
     // rectangles of interior class-R tiles: the strip kernel, when it has this shape; the class-R list shrinks to the rest
-    const bool strips = strips_apply(plan, ft, Fin, Fout, K, precision, N, ld) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    const bool strips = strips_apply(plan, ft, Fin, Fout, K, strip_precision, N, ld) && Fin_w == Fin && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     if (strips && part != 2 && !dbg_only('b') && use_qstrips(plan, ft, Fin, Fout, K)) {
       QStripLaunch qs;
       qs.x = x; qs.w = w; qs.bias = bias; qs.y = y;
@@ -1504,6 +1508,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       qs.nstrips = ft.n_qstrips; qs.Fin = Fin; qs.Fout = Fout; qs.act = act; qs.ld = ld;
       qs.num_cu = plan->fused->num_cu;
       qs.cheb = sl.cheb;
+      qs.f16 = f16;
       qs.prep_weights = fused_images_claim(plan, workspace, IMG_QSTRIP);
       const int rc = launch_cheb_qstrip(qs, stream);
       if (rc != DSPH_OK) return rc;

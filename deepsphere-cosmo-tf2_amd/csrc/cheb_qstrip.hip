@@ -9,27 +9,53 @@
 
 namespace dsph {
 
-// Weight image: one 1 KiB A-operand fragment of v_mfma_f32_16x16x32_bf16 per (role, quarter oq, level of the role, 32-channel
-// block kb, hi | lo): lane l, element i <- s_j m_j w[(32 kb + 8 (l >> 4) + i) * K + j][16 oq + (l & 15)], j the level (H: 4 - lev,
-// L: 1 - lev), s_j the sign kept with the plane (qs_wsign), m_0 = 2 in the Chebyshev basis (level 0 runs doubled: the kernel
-// halves y when it stores it).  The third level of role L is a zero block.
+// Weight image: one 1 KiB A-operand fragment of v_mfma_f32_16x16x32_{bf16,f16} per (role, quarter oq, level of the role,
+// 32-channel block kb, hi | lo): lane l, element i <- s_j m_j w[(32 kb + 8 (l >> 4) + i) * K + j][16 oq + (l & 15)], j the level
+// (H: 4 - lev, L: 1 - lev), s_j the sign kept with the plane (qs_wsign), m_0 = 2 in the Chebyshev basis (level 0 runs doubled:
+// the kernel halves y when it stores it).  The third level of role L is a zero block.
+// f16 (DSPH_PREC_F16X3): hi | lo are f16 (11 + 11 mantissa bits), the weights times the power of two that puts the largest
+// one in [2048, 4096) -- lo parts stay normal numbers --; the inverse factor sits behind the fragments for the kernel's store.
 __global__ __launch_bounds__(256) void qstrip_wprep_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Fin,
-                                                           int Fout, int cheb, int ld) {
+                                                           int Fout, int cheb, int ld, int f16) {
   constexpr int K = 5;
   const int blk = blockIdx.x;  // ((role * 4 + oq) * 3 + lev) * 2 + kb
   const int kb = blk & 1, lev = (blk >> 1) % 3, oq = ((blk >> 1) / 3) & 3, role = (blk >> 1) / 12;
   const int j = role == 0 ? K - 1 - lev : 1 - lev;
   const bool have = role == 0 || lev < 2;
-  const float sc = qs_wsign(cheb != 0, j) * ((cheb != 0 && j == 0) ? 2.f : 1.f);
+  float sc = qs_wsign(cheb != 0, j) * ((cheb != 0 && j == 0) ? 2.f : 1.f);
+  if (f16) {  // (every block finds the same maximum: 20,480 values)
+    __shared__ float smax[256];
+    float m = 0.f;
+    for (int e = threadIdx.x; e < Fin * K * Fout; e += 256) m = fmaxf(m, fabsf(w[(int64_t)(e / Fout) * ld + e % Fout]));
+    smax[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + st]);
+      __syncthreads();
+    }
+    int ex = 0;
+    const float mx = smax[0];
+    float pw = 1.f;
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); pw = ldexpf(1.f, 12 - ex); }  // mx = f 2^ex, f in [0.5, 1): mx pw in [2048, 4096)
+    sc *= pw;
+    if (blk == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(out + (size_t)2 * 4 * 3 * 2 * 2 * QS_FRAG) = 1.f / pw;
+  }
   unsigned char* base = out + (size_t)blk * 2 * QS_FRAG;
   for (int e = threadIdx.x; e < 512; e += 256) {
     const int l = e >> 3, i = e & 7;
     const int ch = 32 * kb + 8 * (l >> 4) + i, col = 16 * oq + (l & 15);
     const float v = (have && ch < Fin && col < Fout) ? sc * w[((int64_t)ch * K + j) * ld + col] : 0.f;
-    const __bf16 hi = (__bf16)v;
-    const __bf16 lo = (__bf16)(v - (float)hi);
-    reinterpret_cast<__bf16*>(base)[l * 8 + i] = hi;
-    reinterpret_cast<__bf16*>(base + QS_FRAG)[l * 8 + i] = lo;
+    if (f16) {
+      const _Float16 hi = (_Float16)v;
+      const _Float16 lo = (_Float16)(v - (float)hi);
+      reinterpret_cast<_Float16*>(base)[l * 8 + i] = hi;
+      reinterpret_cast<_Float16*>(base + QS_FRAG)[l * 8 + i] = lo;
+    } else {
+      const __bf16 hi = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)hi);
+      reinterpret_cast<__bf16*>(base)[l * 8 + i] = hi;
+      reinterpret_cast<__bf16*>(base + QS_FRAG)[l * 8 + i] = lo;
+    }
   }
 }
 
@@ -60,12 +86,12 @@ int64_t qstrip_split(int num_cu, int64_t tape_rows, int64_t N, int64_t mean_heig
   return best;
 }
 
-size_t qstrip_wimg_bytes() { return (size_t)2 * 4 * 3 * 2 * 2 * QS_FRAG; }  // 96 KiB
+size_t qstrip_wimg_bytes() { return (size_t)2 * 4 * 3 * 2 * 2 * QS_FRAG + 256; }  // 96 KiB + the f16 image's factor
 
 int launch_cheb_qstrip(const QStripLaunch& s, hipStream_t stream) {
   if (s.prep_weights) {
     hipLaunchKernelGGL(qstrip_wprep_kernel, dim3(2 * 4 * 3 * 2), dim3(256), 0, stream, s.w, s.wimg, (int)s.Fin, (int)s.Fout, s.cheb ? 1 : 0,
-                       (int)s.ld);
+                       (int)s.ld, s.f16 ? 1 : 0);
     DSPH_HIP(hipGetLastError());
   }
   QStripArgs a;
@@ -87,7 +113,8 @@ int launch_cheb_qstrip(const QStripLaunch& s, hipStream_t stream) {
   a.act = s.act;
   int grid;
   (void)qstrip_split(s.num_cu, s.tape_rows, s.N, s.tape_rows / std::max(1, s.nstrips), &grid, &a.pieces, &a.wg_per_piece);
-  void (*kern)(QStripArgs) = s.cheb ? cheb_qstrip5_kernel<true> : cheb_qstrip5_kernel<false>;
+  void (*kern)(QStripArgs) = s.f16 ? (s.cheb ? cheb_qstrip5_kernel<true, true> : cheb_qstrip5_kernel<false, true>)
+                                   : (s.cheb ? cheb_qstrip5_kernel<true, false> : cheb_qstrip5_kernel<false, false>);
 #ifdef DSPH_QS_STAMPS
   static unsigned* d_stamps = nullptr;
   constexpr size_t NST = 8 * 4 * 10;

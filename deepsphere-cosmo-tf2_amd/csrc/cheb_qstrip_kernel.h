@@ -120,14 +120,17 @@ struct QStripArgs {
 #define QS_DPPR " row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #endif
 
-// one MFMA: acc (+)= wa . bb   (16 output channels x 16 pixels x 32 input channels)
-__device__ __forceinline__ void qs_m(qs_f4& acc, const qs_bf8& wa, const qs_bf8& bb) {
+// one MFMA: acc (+)= wa . bb   (16 output channels x 16 pixels x 32 input channels); F16: the operands are f16 pairs (same
+// registers, same rate), the three-term split then keeps 11 + 11 mantissa bits of both operands (DSPH_PREC_F16X3)
+template <bool F16> __device__ __forceinline__ void qs_m(qs_f4& acc, const qs_bf8& wa, const qs_bf8& bb) {
   if (QS_ABL & 2) { asm volatile("" : "+v"(acc) : "v"(wa), "v"(bb) : "memory"); return; }
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wa), "v"(bb) : "memory");
+  if (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wa), "v"(bb) : "memory");
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wa), "v"(bb) : "memory");
 }
-__device__ __forceinline__ void qs_m0(qs_f4& acc, const qs_bf8& wa, const qs_bf8& bb) {
+template <bool F16> __device__ __forceinline__ void qs_m0(qs_f4& acc, const qs_bf8& wa, const qs_bf8& bb) {
   if (QS_ABL & 2) { acc = qs_f4{0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+v"(acc) : "v"(wa), "v"(bb) : "memory"); return; }
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wa), "v"(bb) : "memory");
+  if (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wa), "v"(bb) : "memory");
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wa), "v"(bb) : "memory");
 }
 // Hazard cover (the asm statements hide their instructions from hipcc's hazard recogniser).  N = 9: the result of a chain of
 // 16x16x32 MFMAs (4 passes) before its first vector reader; N = 1: vector results before a DPP or a matrix reader.
@@ -222,7 +225,7 @@ struct QCoefHi {  // what the row y+1 needs
 // multiplier of L~ in level j and the sign kept with the planes: as in the strip kernel (sp_mult / sp_wsign)
 __host__ __device__ constexpr float qs_wsign(bool cheb, int j) { return cheb && ((j & 3) >= 2) ? -1.f : 1.f; }
 
-template <bool CHEB>
+template <bool CHEB, bool F16>
 __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs a) {
   constexpr int K = 5, D = QS_D, RING = K + 2;
   constexpr int ROWB = 2 * 2 * 4 * QS_FRAG;     // 16 KiB: one ring row of x ([32-channel block][hi | lo][tile] fragments)
@@ -299,17 +302,26 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       qs_u2 hi, lo;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float a0 = xv[i][2 * j], a1 = xv[i][2 * j + 1];
-        const bf16x2 h = __builtin_convertvector(f32x2{a0, a1}, bf16x2);
-        const unsigned hu = __builtin_bit_cast(unsigned, h);
-        const float h0 = __builtin_bit_cast(float, hu << 16), h1 = __builtin_bit_cast(float, hu & 0xffff0000u);
-        const bf16x2 l = __builtin_convertvector(f32x2{a0 - h0, a1 - h1}, bf16x2);
-        hi[j] = hu;
-        lo[j] = __builtin_bit_cast(unsigned, l);
+        if (F16) {  // (a value beyond the f16 range becomes an infinity here and a NaN row in y: loud, not wrong)
+          const f16x2 h = __builtin_convertvector(f32x2{a0, a1}, f16x2);
+          const f32x2 hf = __builtin_convertvector(h, f32x2);
+          const f16x2 l = __builtin_convertvector(f32x2{a0 - hf[0], a1 - hf[1]}, f16x2);
+          hi[j] = __builtin_bit_cast(unsigned, h);
+          lo[j] = __builtin_bit_cast(unsigned, l);
+        } else {
+          const bf16x2 h = __builtin_convertvector(f32x2{a0, a1}, bf16x2);
+          const unsigned hu = __builtin_bit_cast(unsigned, h);
+          const float h0 = __builtin_bit_cast(float, hu << 16), h1 = __builtin_bit_cast(float, hu & 0xffff0000u);
+          const bf16x2 l = __builtin_convertvector(f32x2{a0 - h0, a1 - h1}, bf16x2);
+          hi[j] = hu;
+          lo[j] = __builtin_bit_cast(unsigned, l);
+        }
       }
       *reinterpret_cast<qs_u2*>(q + (unsigned)i * (2 * 4 * QS_FRAG)) = hi;
       *reinterpret_cast<qs_u2*>(q + (unsigned)i * (2 * 4 * QS_FRAG) + 4 * QS_FRAG) = lo;
@@ -396,8 +408,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         const int tt = (s & 1) * 2 + u;                                                                                   \
         const qs_bf8& wa_ = wr[WLEV][s >> 1][QS_ORD_A(j)];                                                                \
         const qs_bf8& bb_ = fr[s & 1][u][QS_ORD_B(j)];                                                                    \
-        if ((ZERO) && s < 2 && j == 0) qs_m0((ROW).t[tt], wa_, bb_);                                                      \
-        else qs_m((ROW).t[tt], wa_, bb_);                                                                                 \
+        if ((ZERO) && s < 2 && j == 0) qs_m0<F16>((ROW).t[tt], wa_, bb_);                                                 \
+        else qs_m<F16>((ROW).t[tt], wa_, bb_);                                                                            \
         _Pragma("unroll") for (int qq = (m * (NU)) / 18; qq < ((m + 1) * (NU)) / 18 && m < 18; ++qq) { __VA_ARGS__; }     \
       }                                                                                                                   \
     }                                                                                                                     \
@@ -556,7 +568,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
           for (int h = 0; h < 2; ++h) wr[l][kb][h] = *reinterpret_cast<const qs_bf8*>(wp + ((size_t)(l * 2 + kb) * 2 + h) * QS_FRAG);
     }
     const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
-    const float ysc = CHEB ? 0.5f : 1.f;
+    // (the f16 image carries its weights times a power of two, qstrip_wprep_kernel: the store takes it out again)
+    const float ysc = (CHEB ? 0.5f : 1.f) * (F16 ? *reinterpret_cast<const float*>(a.wimg + 2 * 4 * 3 * 2 * 2 * QS_FRAG) : 1.f);
 #ifdef DSPH_QS_LPRIO  // (tuning: the L waves are the younger ones of their SIMDs and lose the issue arbitration to their H partner)
 #define QS_STR2(x) #x
 #define QS_STR(x) QS_STR2(x)
@@ -671,7 +684,11 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
             if (row_ok && c >= cfirst && c < clast) {
               qs_f4 o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaf(Y.t[t][e], ysc, bv[e]), floor_v);
+              for (int e = 0; e < 4; ++e) {
+                const float v = fmaf(Y.t[t][e], ysc, bv[e]);
+                // (f16: an input beyond the f16 range has become a NaN by now -- it must reach y, not be floored away by the ReLU)
+                o[e] = F16 ? (v < floor_v ? floor_v : v) : fmaxf(v, floor_v);
+              }
               *reinterpret_cast<qs_f4*>(ymap + (size_t)(sXt[t] | sY) * yrowb + (unsigned)(16 * oq + 4 * q4) * 4u) = o;
             }
           }

@@ -258,7 +258,8 @@ int dsph_poly_forward_pool(const dsph_plan* p, const float* x, const float* w, c
     set_error("poly_forward_pool: bad arguments (NULL pointer or non-positive size)");
     return DSPH_E_BADARG;
   }
-  if (precision != DSPH_PREC_FP32 && precision != DSPH_PREC_BF16X3 && precision != DSPH_PREC_BF16X6) { set_error("poly_forward_pool: unknown precision %d", precision); return DSPH_E_BADARG; }
+  if (precision < DSPH_PREC_FP32 || precision > DSPH_PREC_F16X3) { set_error("poly_forward_pool: unknown precision %d", precision); return DSPH_E_BADARG; }
+  if (precision == DSPH_PREC_F16X3) precision = DSPH_PREC_BF16X6;  // (the pooled store is not the quad strips')
   if (!dsph_plan_pool_fusable(p, N, Fin, Fout, K, act)) {
     set_error("poly_forward_pool: no fused pooling for this plan / shape (dsph_plan_pool_fusable)");
     return DSPH_E_UNSUPPORTED;
@@ -307,8 +308,8 @@ int dsph_cheb_contract(const float* const* planes, int64_t plane_rows, const flo
   for (int k = 0; k < K; ++k)
     if (!planes[k]) { set_error("cheb_contract: plane %d is NULL", k); return DSPH_E_BADARG; }
   DeviceGuard guard(device);
-  return launch_cheb_contract(planes, plane_rows, w, bias, y, N, rows, Fin, Fout, K, act, precision,
-                              (hipStream_t)hip_stream);
+  return launch_cheb_contract(planes, plane_rows, w, bias, y, N, rows, Fin, Fout, K, act,
+                              precision == DSPH_PREC_F16X3 ? DSPH_PREC_BF16X6 : precision, (hipStream_t)hip_stream);
 }
 
 int dsph_cheb_forward(const dsph_plan* p, const float* x, const float* w, const float* bias,
@@ -357,7 +358,7 @@ int dsph_poly_forward_ex(const dsph_plan* p, const float* x, const float* w, con
     return DSPH_E_BADARG;
   }
   if (act < DSPH_ACT_NONE || act > DSPH_ACT_TANH) { set_error("cheb_forward: unknown activation %d", act); return DSPH_E_BADARG; }
-  if (precision != DSPH_PREC_FP32 && precision != DSPH_PREC_BF16X3 && precision != DSPH_PREC_BF16X6) { set_error("cheb_forward: unknown precision %d", precision); return DSPH_E_BADARG; }
+  if (precision < DSPH_PREC_FP32 || precision > DSPH_PREC_F16X3) { set_error("cheb_forward: unknown precision %d", precision); return DSPH_E_BADARG; }
   if (!p->levels.empty() && (int)p->levels.size() < K - 1) {
     set_error("cheb_forward: plan has %d levels, K = %d needs %d", (int)p->levels.size(), K, K - 1);
     return DSPH_E_BADARG;
@@ -409,7 +410,7 @@ int dsph_poly_forward_ex(const dsph_plan* p, const float* x, const float* w, con
     if (rc != DSPH_OK) return rc;
   }
   return launch_cheb_contract(planes, p->n_cols, w, bias, y, N, out_rows(p), Fin, Fout, K, act,
-                              precision, stream);
+                              precision == DSPH_PREC_F16X3 ? DSPH_PREC_BF16X6 : precision, stream);
 }
 
 int dsph_cheb_planes(const dsph_plan* p, const float* x, float* planes, int64_t N, int32_t Fin, int32_t K,
@@ -477,7 +478,7 @@ size_t dsph_backward_weights_workspace_bytes(const dsph_plan* p, int64_t N, int3
 int dsph_cheb_backward_weights(const dsph_plan* p, const float* x, const float* dy, float* dw, int64_t N,
                                int32_t Fin, int32_t Fout, int32_t K, int32_t basis, int32_t precision, int32_t algo,
                                void* workspace, size_t workspace_bytes, void* hip_stream) {
-  if (precision == DSPH_PREC_BF16X6) precision = DSPH_PREC_FP32;  // (only the structured forward kernel has the 6-term form)
+  if (precision == DSPH_PREC_BF16X6 || precision == DSPH_PREC_F16X3) precision = DSPH_PREC_FP32;  // (only the forward kernels have those forms)
   if (precision != DSPH_PREC_FP32 && precision != DSPH_PREC_BF16X3) {
     set_error("backward_weights: unknown precision %d", precision);
     return DSPH_E_BADARG;

@@ -209,6 +209,7 @@ struct QStripLaunch {
   int64_t x_rows, y_rows, N;
   int32_t nstrips, Fin, Fout, act, ld, num_cu;
   bool cheb;
+  bool f16 = false;          // DSPH_PREC_F16X3: the three-term split on f16 pairs instead of bf16 pairs
   bool prep_weights = true;
 };
 bool qstrip_shape_ok(int32_t Fin, int32_t Fout, int32_t K);

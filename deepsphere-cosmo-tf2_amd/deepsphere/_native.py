@@ -15,7 +15,7 @@ _lib = None
 
 OK = 0
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
-PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
+PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3
 ALGO_AUTO, ALGO_UNFUSED, ALGO_FUSED = 0, 1, 2
 PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
 FWD_KEEP_WEIGHTS = 1

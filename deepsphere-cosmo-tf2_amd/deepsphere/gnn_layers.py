@@ -37,7 +37,8 @@ _ACT_BY_NAME = {
     "softmax": (lambda t: torch.softmax(t, dim=-1), None),
 }
 
-_PRECISIONS = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6, "auto": None}
+_PRECISIONS = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6, "f16x3": _native.PREC_F16X3,
+               "auto": None}
 _ALGOS = {"auto": _native.ALGO_AUTO, "unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}
 
 
@@ -70,7 +71,9 @@ def _resolve_activation(activation):
 #     split (both operands split exactly into 8 + 8 + 8 mantissa bits, the six products down to 2^-16 kept): 2-7e-7 of
 #     max|y|.  With five products per output nothing averages out -- the three-term split measured 1.02e-5 on BASELINE
 #     configs[0] -- and such layers cost next to nothing anyway.
-# "fp32" (the bitwise fp32-fma-chain MFMA), "bf16x6" and "bf16x3" can be asked for by name.
+# "fp32" (the bitwise fp32-fma-chain MFMA), "bf16x6" and "bf16x3" can be asked for by name; so can "f16x3" (round 5): the
+# fp32-equivalent three-term split on f16 pairs (11 + 11 mantissa bits) where the quad-strip kernel runs (K = 5, 64 -> 64 per
+# column block, HEALPix rectangles) and "bf16x6" everywhere else -- for inputs of magnitude below 65,504 (DSPH_PREC_F16X3).
 DEFAULT_PRECISION = "auto"
 
 
@@ -93,7 +96,7 @@ def resolve_wgrad_precision(precision, n_terms):
     kernel and runs exact fp32 (include/dsphere.h)."""
     if precision == "auto":
         return "bf16x3" if n_terms >= 4096 else "fp32"
-    return "fp32" if precision == "bf16x6" else precision
+    return "fp32" if precision in ("bf16x6", "f16x3") else precision
 
 
 class _ChebConvFunction(torch.autograd.Function):

@@ -53,6 +53,13 @@ extern "C" {
  * fp32 rounding.  A third of the matrix-pipe time of DSPH_PREC_FP32.  The structured-tile kernel implements it; every
  * other kernel (BFS tiles, unfused, weight gradient) runs DSPH_PREC_FP32 when asked for it. */
 #define DSPH_PREC_BF16X6 2
+/* fp32-equivalent at the three-term split's price, where the quad-strip kernel runs (csrc/cheb_qstrip_kernel.h: K = 5, 64 input
+ * and 64 output channels per column block, the rectangles of a HEALPix map): both operands split hi + lo into f16 (11 + 11
+ * mantissa bits), hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16, fp32 accumulate: what is dropped is 2^-22 of a product.
+ * The weights go in times a power of two (taken out again in the store), x as it is: an input of magnitude 65,504 or more
+ * does not fit an f16 and comes out as Inf / NaN rows of y -- the caller vouches for the range.  Every tile, shape and kernel
+ * the quad strips do not take runs DSPH_PREC_BF16X6 (same accuracy, no range condition). */
+#define DSPH_PREC_F16X3 3
 
 /* polynomial basis of the recurrence: T_1 = L~ x in both;
  *   Chebyshev: T_k = 2 L~ T_{k-1} - T_{k-2}   (reference gnn_layers.Chebyshev, gnn_layers.py:137-143)

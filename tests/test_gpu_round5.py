@@ -62,6 +62,51 @@ def test_quad_strips_whole_map_and_against_the_strip_pairs(nside, N, basis, act)
     assert float((ys[_native.STRIP_FORM_QUAD] - ys[_native.STRIP_FORM_PAIRS]).abs().max()) / scale < 2 * TOL
 
 
+@pytest.mark.parametrize("basis", ["chebyshev", "monomial"])
+def test_f16_three_term_split_is_fp32_equivalent(basis):
+    """DSPH_PREC_F16X3: the quad strips with both operands split into f16 hi + lo (11 + 11 mantissa bits),
+    the other tiles on the six-term bf16 split: whole map against the float64 oracle at the fp32 figure (2e-6; the bf16
+    three-term split is held to 1e-5), weights of very different sizes (the image's power-of-two factor), and an input
+    beyond the f16 range comes out as non-finite rows -- loud, not wrong."""
+    nside, N, K, Fin, Fout = 256, 2, 5, 64, 64
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(256)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    W[:, ::7] *= 1e-3  # columns a thousand times smaller than the largest weight
+    b = rng.standard_normal(Fout).astype(np.float32)
+    fwd = orc.chebyshev_forward if basis == "chebyshev" else orc.monomial_forward
+    ref = fwd(_csr(cols, vals), x, W, K, bias=b, activation="relu")
+    plan = _plan(cols, vals, K, Fin, {_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
+    assert plan.strip_tiles(Fin, Fout, K, _native.PREC_F16X3, N=N) == 12 * (nside // 16 - 2) ** 2
+    B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
+    kw = dict(act=_native.ACT_RELU, algo=_native.ALGO_FUSED, basis=B)
+    y, ws = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, precision=_native.PREC_F16X3, **kw)
+    err = rel_err(y.cpu().numpy(), ref)
+    y3, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, precision=_native.PREC_BF16X3, **kw)
+    err3 = rel_err(y3.cpu().numpy(), ref)
+    print(f"f16x3 {basis}: rel err {err:.2e} (bf16x3 on the same inputs: {err3:.2e})")
+    assert err < 2e-6 and err3 < TOL
+    # per-column error relative to the column's own size: the small columns keep their digits (the lo halves stay normal)
+    small = np.arange(0, Fout, 7)
+    yr, rr = y.cpu().numpy()[..., small], ref[..., small]
+    assert np.abs(yr - rr).max() / max(np.abs(rr).max(), 1e-30) < 1e-5
+    # the same call on kept weight images, and through the layer
+    y2, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, precision=_native.PREC_F16X3, workspace=ws, keep_weights=True, **kw)
+    assert torch.equal(y, y2)
+    # out of range: one input of 1e5 -> non-finite outputs around it (and only there), never a silently wrong finite number
+    from deepsphere.healpix import xyf2nest
+
+    xb = x.copy()
+    centre = int(xyf2nest(nside, np.array([100]), np.array([121]), np.array([5]))[0])  # inside a rectangle of the strips
+    xb[0, centre, 3] = 1.0e5
+    yb, _ = _native.cheb_forward(plan, _dev(xb), _dev(W), _dev(b), K, precision=_native.PREC_F16X3, **kw)
+    bad = ~torch.isfinite(yb[0]).all(dim=1)
+    assert bool(bad[centre]) and int(bad.sum()) <= 81, "the 9 x 9 neighbourhood a K = 5 layer spreads a pixel over"
+    assert bool(torch.isfinite(yb[1]).all())
+
+
 def test_kept_weight_images_across_batch_sizes_and_kernels():
     """ADVICE r4 (cheb_fused.hip): which weight images a forward packs depends on the batch -- strips or tiles by the cost rule,
     maps packed four to an item or not -- and the caller's key cannot see that.  The library keeps its own record per

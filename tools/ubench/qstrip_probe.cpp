@@ -27,6 +27,7 @@ static const int DX[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, DY[8] = {0, 1, 1, 1, 0, -1
 struct Case {
   int S, N, border, seg;
   bool cheb;
+  bool f16 = false;
 };
 
 static std::vector<QStrip> cut(int S, int border, int seg) {
@@ -76,7 +77,7 @@ static double run(const Case& c, bool check, int reps) {
   L.prefix = d_p; L.tape_rows = prefix.back();
   L.x = d_x; L.w = d_w; L.bias = d_b; L.y = d_y; L.wimg = d_img; L.strips = d_s; L.gvals8 = d_g8; L.gdiag = d_gd;
   L.x_rows = (int64_t)M; L.y_rows = (int64_t)M; L.N = N; L.nstrips = (int)strips.size(); L.Fin = F; L.Fout = F; L.act = DSPH_ACT_RELU;
-  L.ld = F; L.num_cu = 256; L.cheb = c.cheb; L.prep_weights = true;
+  L.ld = F; L.num_cu = 256; L.cheb = c.cheb; L.f16 = c.f16; L.prep_weights = true;
   if (launch_cheb_qstrip(L, nullptr) != DSPH_OK) exit(1);
   CK(hipDeviceSynchronize());
   double ms = 0;
@@ -133,7 +134,8 @@ static double run(const Case& c, bool check, int reps) {
           }
         }
     }
-    printf("check S %d N %d %s: max |err| %.3e of max |y| %.3e -> %.2e\n", S, N, c.cheb ? "chebyshev" : "monomial", worst, ymax, worst / ymax);
+    printf("check S %d N %d %s %s: max |err| %.3e of max |y| %.3e -> %.2e\n", S, N, c.cheb ? "chebyshev" : "monomial", c.f16 ? "f16x3" : "bf16x3", worst, ymax,
+           worst / ymax);
   }
   hipFree(d_g8); hipFree(d_gd); hipFree(d_x); hipFree(d_w); hipFree(d_b); hipFree(d_y); hipFree(d_img); hipFree(d_s);
   return ms;
@@ -150,9 +152,12 @@ int main(int argc, char** argv) {
   }
   run({128, 2, 16, 1 << 30, true}, true, 0);
   run({128, 1, 16, 40, false}, true, 0);
+  run({128, 2, 16, 1 << 30, true, true}, true, 0);
+  run({128, 1, 16, 1 << 30, false, true}, true, 0);
   if (argc > 1 && atoi(argv[1]) == 0) return 0;
   // one base pixel of nside 1024, four maps: 18 strips x 4 maps; then cut so that the items fill 256 CUs
   run({1024, 4, 16, 1 << 30, true}, false, 5);
   run({1024, 8, 16, 1 << 30, true}, false, 3);
+  run({1024, 8, 16, 1 << 30, true, true}, false, 3);
   return 0;
 }
