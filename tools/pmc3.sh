@@ -17,7 +17,7 @@ for P in "${SETS[@]}"; do
   # PMC_ONLY="3 4": just those passes (FETCH_SIZE and WRITE_SIZE)
   if [ -n "$PMC_ONLY" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then continue; fi
   echo "pass $i: $P"
-  timeout 400 rocprofv3 --pmc $P --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/tools/run_forward.py $cfg $prec ${PMC_ALGO:-fused} 2 > $out/p$i.log 2>&1
+  timeout ${PMC_TIMEOUT:-400} rocprofv3 --pmc $P --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/tools/run_forward.py $cfg $prec ${PMC_ALGO:-fused} 2 > $out/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
