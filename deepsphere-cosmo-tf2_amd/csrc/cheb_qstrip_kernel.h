@@ -25,9 +25,9 @@
 //   taking the maps j, j + w, ... -- for a batch of N <= G maps w = N and P = G / N: every workgroup gets the same number of
 //   rows whatever the strips' heights, and the N workgroups of a piece (neighbours on one XCD) walk the same rows of L~ at the
 //   same time, one map each (the host picks P and w: qstrip_split).
-// LDS (162,880 B): ring of 7 rows of x as bf16 hi | lo B-operand fragments (16 KiB per row: [32-channel block][hi | lo][tile]
-//   1 KiB fragments), hand-over 4 x 8 KiB, ring of 6 rows of L~ (2,560 B per row: directions 0-3 per [tile][p], directions
-//   4-7 per [tile][p], diagonal per [p][tile], W once more per [p][tile]), counters.
+// LDS (161,344 B): ring of 7 rows of x as bf16 hi | lo B-operand fragments (16 KiB per row: [32-channel block][hi | lo][tile]
+//   1 KiB fragments), hand-over 4 x 8 KiB, ring of 6 rows of L~ (2,304 B per row: the diagonal and the eight directions, each a
+//   [p][tile] vector: a lane reads the 16 bytes of its four pixels per direction, 9 reads per level-row), counters.
 // x: all eight waves fetch half a tile each (8 pixels x 256 B, two 16-byte loads per lane) a step ahead and split it into
 //   fragments at the end of the step.  y: straight from the accumulators, 16 pixels x 64 contiguous bytes per instruction.
 #pragma once
@@ -210,17 +210,21 @@ __device__ __forceinline__ void qs_unit(QRow& acc, const QRow& src, int e, const
 #undef QS_UE
 }
 
+// (Packed multiply-adds for the ten plain terms of two channel registers at once -- v_pk_fma_f32 with the by-tile coefficient
+// vectors as op_sel halves, natural in this layout -- were built and timed on the probe: 3.50 us per step against 3.40.
+// As in round 3 and as MI355X_MICROARCH.md says of packed f32 beside MFMAs: slower.  Not kept.)
+#define QS_UPR 4  /* units per source row */
+#define QS_UNIT qs_unit
+
 // The values of L~ of the lane's four pixels in one row, as the ring holds them (per tile t: directions 0..3 = W NW N NE,
 // directions 4..7 = E SE S SW; the diagonal and W once more as [tile] vectors), and the three coefficient vectors
 // (west, centre, east by tile) of a source row:  y-1: SW S SE;  y: W diag E;  y+1: NW N NE.
-struct QCoefLo {  // what the rows y-1 and y of a level need
-  qs_f4 gb[4];    // per tile: E SE S SW
-  qs_f4 dg, wd;   // by tile: diagonal, W
+struct QCoefLo {  // what the rows y-1 and y of a level need: six directions, each a vector by tile
+  qs_f4 sw, s, se, w, dg, e;
 };
 struct QCoefHi {  // what the row y+1 needs
-  qs_f4 ga[4];    // per tile: W NW N NE
+  qs_f4 nw, n, ne;
 };
-#define QS_BY_TILE(G, C) (qs_f4{(G)[0][C], (G)[1][C], (G)[2][C], (G)[3][C]})
 
 // multiplier of L~ in level j and the sign kept with the planes: as in the strip kernel (sp_mult / sp_wsign)
 __host__ __device__ constexpr float qs_wsign(bool cheb, int j) { return cheb && ((j & 3) >= 2) ? -1.f : 1.f; }
@@ -232,9 +236,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   constexpr int RINGB = RING * ROWB;            // 112 KiB
   constexpr int HAND1 = 2 * 4 * QS_FRAG;        // 8 KiB per quarter: [b2 row | b3 row][tile]
   constexpr int HANDB = 4 * HAND1;              // 32 KiB
-  constexpr int CROWB = 2560;                   // one ring row of L~
+  constexpr int CROWB = 2304;                   // one ring row of L~: [9: the diagonal, directions 0..7][p][tile] floats
   constexpr int CRING = K + 1;
-  constexpr int CRINGB = CRING * CROWB;         // 15,360 B
+  constexpr int CRINGB = CRING * CROWB;         // 13,824 B
   constexpr int LDS_HAND = RINGB, LDS_C = RINGB + HANDB, LDS_FLAG = LDS_C + CRINGB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_FLAG + 64];
 
@@ -366,43 +370,38 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   auto cw_wait = [&](qs_f4& cv, float& cd) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(cv), "+v"(cd) : : "memory");
   };
+  // ring row: vector v = 0 the diagonal, v = 1 + d direction d (W NW N NE E SE S SW), each [p][tile] -- what a lane reads is
+  // the 16 bytes of its four pixels of one direction
   auto cstore = [&](int slot, qs_f4 cv, float cd) __attribute__((always_inline)) {
     if (CHEB) { cv = cv + cv; cd = cd + cd; }
-    unsigned char* q = smem + LDS_C + (unsigned)slot * CROWB;
-    if (q4 < 2) *reinterpret_cast<qs_f4*>(q + (unsigned)q4 * 1024u + (unsigned)oq * 256u + (unsigned)p * 16u) = cv;
-    if (q4 == 0) *reinterpret_cast<float*>(q + 2304u + (unsigned)p * 16u + (unsigned)oq * 4u) = cv[0];
-    if (q4 == 2) *reinterpret_cast<float*>(q + 2048u + (unsigned)p * 16u + (unsigned)oq * 4u) = cd;
+    unsigned char* q = smem + LDS_C + (unsigned)slot * CROWB + (unsigned)p * 16u + (unsigned)oq * 4u;
+    if (q4 < 2) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) *reinterpret_cast<float*>(q + (unsigned)(1 + 4 * q4 + d) * 256u) = cv[d];
+    }
+    if (q4 == 2) *reinterpret_cast<float*>(q) = cd;
+  };
+  auto cvec = [&](const unsigned char* q, int v) __attribute__((always_inline)) -> qs_f4 {
+    if (QS_ABL & 1024) { qs_f4 c = qs_f4{0.1f, 0.1f, 0.1f, 0.1f}; asm volatile("" : "+v"(c)); return c; }
+    return *reinterpret_cast<const qs_f4*>(q + (unsigned)v * 256u);
   };
   auto clo_read = [&](int slot) __attribute__((always_inline)) -> QCoefLo {
     const unsigned char* q = smem + LDS_C + (unsigned)slot * CROWB + (unsigned)p * 16u;
     QCoefLo c;
-    if (QS_ABL & 1024) {
-      c.dg = qs_f4{0.1f, 0.1f, 0.1f, 0.1f}; c.wd = c.dg; c.gb[0] = c.gb[1] = c.gb[2] = c.gb[3] = c.dg;
-      asm volatile("" : "+v"(c.dg), "+v"(c.wd), "+v"(c.gb[0]), "+v"(c.gb[1]), "+v"(c.gb[2]), "+v"(c.gb[3]));
-      return c;
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) c.gb[t] = *reinterpret_cast<const qs_f4*>(q + 1024u + (unsigned)t * 256u);
-    c.dg = *reinterpret_cast<const qs_f4*>(q + 2048u);
-    c.wd = *reinterpret_cast<const qs_f4*>(q + 2304u);
+    c.sw = cvec(q, 8); c.s = cvec(q, 7); c.se = cvec(q, 6);
+    c.w = cvec(q, 1); c.dg = cvec(q, 0); c.e = cvec(q, 5);
     return c;
   };
   auto chi_read = [&](int slot) __attribute__((always_inline)) -> QCoefHi {
     const unsigned char* q = smem + LDS_C + (unsigned)slot * CROWB + (unsigned)p * 16u;
     QCoefHi c;
-    if (QS_ABL & 1024) {
-      c.ga[0] = qs_f4{0.1f, 0.1f, 0.1f, 0.1f}; c.ga[1] = c.ga[2] = c.ga[3] = c.ga[0];
-      asm volatile("" : "+v"(c.ga[0]), "+v"(c.ga[1]), "+v"(c.ga[2]), "+v"(c.ga[3]));
-      return c;
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) c.ga[t] = *reinterpret_cast<const qs_f4*>(q + (unsigned)t * 256u);
+    c.nw = cvec(q, 2); c.n = cvec(q, 3); c.ne = cvec(q, 4);
     return c;
   };
 // coefficient vectors of the three source rows
-#define QS_LO0(c) QS_BY_TILE((c).gb, 3), QS_BY_TILE((c).gb, 2), QS_BY_TILE((c).gb, 1)
-#define QS_LO1(c) (c).wd, (c).dg, QS_BY_TILE((c).gb, 0)
-#define QS_HI(c) QS_BY_TILE((c).ga, 1), QS_BY_TILE((c).ga, 2), QS_BY_TILE((c).ga, 3)
+#define QS_LO0(c) (c).sw, (c).s, (c).se
+#define QS_LO1(c) (c).w, (c).dg, (c).e
+#define QS_HI(c) (c).nw, (c).n, (c).ne
 
   // The MFMA chain of one level (24 MFMAs: 2 channel blocks x 2 pairs of tiles x 3 terms x 2 tiles) beside NU stencil units:
   // MFMA m is followed by the units that fall to it.  Consecutive MFMAs go to different tiles; the fragments of the next
@@ -527,27 +526,27 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         qs_f4 cv;
         float cd;
         // s0: z_4 -> b4[new] | b3[new] = -+ (b4[-2], b4[-1])
-        QS_CHAIN(R[0][L2], true, 0, f0, 8, { c2 = clo_read(cslot_ix(2)); QS_FR0(f1) },
-                 { if (qq < 4) qs_unit<true, N3>(R[1][L2], R[0][L0], qq, QS_LO0(c3)); else qs_unit<false, N3>(R[1][L2], R[0][L1], qq - 4, QS_LO1(c3)); })
+        QS_CHAIN(R[0][L2], true, 0, f0, 2 * QS_UPR, { c2 = clo_read(cslot_ix(2)); QS_FR0(f1) },
+                 { if (qq < QS_UPR) QS_UNIT<true, N3>(R[1][L2], R[0][L0], qq, QS_LO0(c3)); else QS_UNIT<false, N3>(R[1][L2], R[0][L1], qq - QS_UPR, QS_LO1(c3)); })
         qs_settle<9>(R[0][L2]);
         qs_settle<1>(R[1][L2]);
         QS_STAMP(1);
         // s1: z_3 -> b3[new] | b2[new] = b4[-2] + (b3[-2], b3[-1]), in place in R[0][L0]   (c2: row ytop-2, level 2)
-        QS_CHAIN(R[1][L2], false, 1, f1, 8, { c3h = chi_read(cslot_ix(1)); QS_FR0(f2) },
-                 { if (qq < 4) qs_unit<!CHEB, false>(R[0][L0], R[1][L0], qq, QS_LO0(c2)); else qs_unit<false, false>(R[0][L0], R[1][L1], qq - 4, QS_LO1(c2)); })
+        QS_CHAIN(R[1][L2], false, 1, f1, 2 * QS_UPR, { c3h = chi_read(cslot_ix(1)); QS_FR0(f2) },
+                 { if (qq < QS_UPR) QS_UNIT<!CHEB, false>(R[0][L0], R[1][L0], qq, QS_LO0(c2)); else QS_UNIT<false, false>(R[0][L0], R[1][L1], qq - QS_UPR, QS_LO1(c2)); })
         qs_settle<9>(R[1][L2]);
         qs_settle<1>(R[0][L0]);
         QS_STAMP(2);
         // s2: z_2 -> b2[new] | b3[new] += b4[new]
         // (the row ytop of L~ is requested in the tail as well: its latency is H's to wait out, H reaches the barrier before L)
-        QS_CHAIN(R[0][L0], false, 2, f2, 4, { c2h = chi_read(cslot_ix(2)); cfetch(sXc | spread_y(ytop), cv, cd); },
-                 { qs_unit<false, N3>(R[1][L2], R[0][L2], qq, QS_HI(c3h)); })
+        QS_CHAIN(R[0][L0], false, 2, f2, QS_UPR, { c2h = chi_read(cslot_ix(2)); cfetch(sXc | spread_y(ytop), cv, cd); },
+                 { QS_UNIT<false, N3>(R[1][L2], R[0][L2], qq, QS_HI(c3h)); })
         qs_settle<9>(R[0][L0]);
         qs_settle<1>(R[1][L2]);
         QS_STAMP(3);
         // s3: b2[new] += b3[new]
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) qs_unit<false, false>(R[0][L0], R[1][L2], qq, QS_HI(c2h));
+        for (int qq = 0; qq < QS_UPR; ++qq) QS_UNIT<false, false>(R[0][L0], R[1][L2], qq, QS_HI(c2h));
         QS_STAMP(4);
         // hand-over: b2[new] and the dying row of b3 -- once L has taken the previous pair
         for (int spin = 0; flag_get() <= handed && spin < (1 << 22); ++spin) {}  // (bounded: a lost partner must not hang the device)
@@ -685,21 +684,21 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
           qs_settle<1>(Y);
         }
         // s0: 2 z_0 (+ 2 b2[-1]) -> Y | b1[new] (= b3 row from H) -+= (b2[-1], b2[0], b2[+1])
-        QS_CHAIN(Y, !CHEB, 1, f0, 12, { c0 = clo_read(cslot_ix(5)); QS_FR0(f1) },
-                 { if (qq < 4) qs_unit<!CHEB, N1>(R[1][L2], R[0][L0], qq, QS_LO0(c1));
-                   else if (qq < 8) qs_unit<false, N1>(R[1][L2], R[0][L1], qq - 4, QS_LO1(c1));
-                   else qs_unit<false, N1>(R[1][L2], R[0][L2], qq - 8, QS_HI(c1h)); })
+        QS_CHAIN(Y, !CHEB, 1, f0, 3 * QS_UPR, { c0 = clo_read(cslot_ix(5)); QS_FR0(f1) },
+                 { if (qq < QS_UPR) QS_UNIT<!CHEB, N1>(R[1][L2], R[0][L0], qq, QS_LO0(c1));
+                   else if (qq < 2 * QS_UPR) QS_UNIT<false, N1>(R[1][L2], R[0][L1], qq - QS_UPR, QS_LO1(c1));
+                   else QS_UNIT<false, N1>(R[1][L2], R[0][L2], qq - 2 * QS_UPR, QS_HI(c1h)); })
         qs_settle<9>(Y);
         qs_settle<1>(R[1][L2]);
         QS_STAMP(2);
         // s1: z_1 -> b1[new] | Y += (b1[-2], b1[-1])   (c0: row ytop-5, level 0)
-        QS_CHAIN(R[1][L2], false, 0, f1, 8, { c0h = chi_read(cslot_ix(5)); },
-                 { if (qq < 4) qs_unit<false, false>(Y, R[1][L0], qq, QS_LO0(c0)); else qs_unit<false, false>(Y, R[1][L1], qq - 4, QS_LO1(c0)); })
+        QS_CHAIN(R[1][L2], false, 0, f1, 2 * QS_UPR, { c0h = chi_read(cslot_ix(5)); },
+                 { if (qq < QS_UPR) QS_UNIT<false, false>(Y, R[1][L0], qq, QS_LO0(c0)); else QS_UNIT<false, false>(Y, R[1][L1], qq - QS_UPR, QS_LO1(c0)); })
         qs_settle<9>(R[1][L2]);
         QS_STAMP(3);
         // s2: Y += b1[new]: y of row ytop - K
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) qs_unit<false, false>(Y, R[1][L2], qq, QS_HI(c0h));
+        for (int qq = 0; qq < QS_UPR; ++qq) QS_UNIT<false, false>(Y, R[1][L2], qq, QS_HI(c0h));
         QS_STAMP(4);
         if (!X_BY_H) xw_wait(xv);  // (here, in front of this step's y stores: the wait is for everything in flight)
         QS_STAMP(5);
