@@ -1,21 +1,28 @@
 #!/bin/bash
-# Round-5 measurements on the GPU box: the bench lines (c3 with both strip forms on the same box, c3 in the fp32-equivalent
-# arithmetics, c1, c2, c4, c5 and the side configs), rocprofv3 kernel stats of the default bench command, the SQ / GRBM / HBM
-# counter passes of c3 and the HBM passes of c1, c4, c5 (one --pmc set per run, the program directly behind `--`) over
-# tools/run_forward.py.  Small files into gpurun_out/measure5/; tools/fold_round5.py folds them into profiles/.
+# Round-5 measurements on the GPU box, all in one lease (one box, one clock): the bench lines (c3 with both strip forms, c3 in
+# the fp32-equivalent f16 split, c1, c2, c4, c5 and the side configs), rocprofv3 kernel stats of the default bench command, the
+# SQ / GRBM / HBM counter passes of c3 and the HBM passes of c5, c2, c1 (one --pmc set per run, the program directly behind `--`)
+# over tools/run_forward.py.  Small files into gpurun_out/measure5/; tools/fold_round5.py folds them into profiles/, and
+# tools/measure_round5c.sh then repeats the bench lines so that they carry this round's traffic entries.
+# (c4's counter passes do not finish: tools/measure_round5b.sh.)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/measure5; mkdir -p $O
 python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_c3.json
 python3 bench.py --steps 20 --warmup 5 --quick --strip-form pairs 2>/dev/null | tail -1 > $O/bench_c3_pairs.json
 python3 bench.py --steps 20 --warmup 5 --quick --precision f16x3 2>/dev/null | tail -1 > $O/bench_c3_f16x3.json
-for c in c1 c2 k10 in1 knn8 knn20; do python3 bench.py --config $c --steps 100 --warmup 20 --cpu-budget 0 2>/dev/null | tail -1 > $O/bench_$c.json; done
-for c in c4 c5; do python3 bench.py --config $c --steps 10 --warmup 3 --cpu-budget 0 2>/dev/null | tail -1 > $O/bench_$c.json; done
+if [ -z "$R5_C3_ONLY" ]; then
+  for c in c1 c2 k10 in1 knn8 knn20; do python3 bench.py --config $c --steps 100 --warmup 20 --cpu-budget 0 2>/dev/null | tail -1 > $O/bench_$c.json; done
+  for c in c4 c5; do python3 bench.py --config $c --steps 10 --warmup 3 --cpu-budget 0 2>/dev/null | tail -1 > $O/bench_$c.json; done
+fi
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 bench.py --steps 20 --warmup 5 --cpu-budget 0 --quick > $O/bench_c3_under_rocprof.log 2>&1
 f=$(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1)
 head -1 $f > $O/kernel_stats_c3.csv; grep -E "dsph" $f | cut -c1-300 >> $O/kernel_stats_c3.csv
 tools/pmc3.sh r5_c3 c3 bf16x3 > $O/pmc_c3_bf16x3.txt 2>&1
-PMC_ONLY="2 3 4" tools/pmc3.sh r5_c5 c5 bf16x3 > $O/pmc_c5_bf16x3.txt 2>&1
-PMC_ONLY="3 4" tools/pmc3.sh r5_c4 c4 bf16x3 > $O/pmc_c4_bf16x3.txt 2>&1
-PMC_ONLY="3 4" tools/pmc3.sh r5_c1 c1 bf16x6 > $O/pmc_c1_bf16x6.txt 2>&1
-for t in c3 c5 c4 c1; do cp gpurun_out/pmc_r5_$t/summary.json $O/pmc_$t.json; rm -rf gpurun_out/pmc_r5_$t/p[0-9]*; done
+cp gpurun_out/pmc_r5_c3/summary.json $O/pmc_c3.json; rm -rf gpurun_out/pmc_r5_c3/p[0-9]*
+if [ -z "$R5_C3_ONLY" ]; then
+  PMC_ONLY="2 3 4" tools/pmc3.sh r5_c5 c5 bf16x3 > $O/pmc_c5_bf16x3.txt 2>&1
+  PMC_ONLY="3 4" tools/pmc3.sh r5_c2 c2 bf16x3 > $O/pmc_c2_bf16x3.txt 2>&1
+  PMC_ONLY="3 4" tools/pmc3.sh r5_c1 c1 bf16x6 > $O/pmc_c1_bf16x6.txt 2>&1
+  for t in c5 c2 c1; do cp gpurun_out/pmc_r5_$t/summary.json $O/pmc_$t.json; rm -rf gpurun_out/pmc_r5_$t/p[0-9]*; done
+fi
 ls -la $O
