@@ -1148,6 +1148,17 @@ int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_
   return n;
 }
 
+// how a quad-strip forward of N maps on the K = 5 tables cuts its work (qstrip_split)
+bool fused_strip_split(const dsph_plan* plan, int64_t N, int32_t* grid, int32_t* pieces, int32_t* wg_per_piece, int64_t* tape_rows) {
+  if (!plan->fused || N < 1) return false;
+  const FusedTiles& ft = get_tiles(plan, QS_D, false);
+  if (!ft.ok || ft.n_qstrips == 0) return false;
+  int g = 0, p = 0, w = 0;
+  (void)qstrip_split(plan->fused->num_cu, ft.qtape_rows, N, ft.qtape_rows / std::max(1, ft.n_qstrips), &g, &p, &w);
+  *grid = g; *pieces = p; *wg_per_piece = w; *tape_rows = ft.qtape_rows;
+  return true;
+}
+
 // two fragment layouts: the BFS-tile kernel's and, behind it, the structured-tile kernel's
 // (one fragment area per 64-column block of the layer, so that the packed images of ALL blocks survive the call:
 // DSPH_FWD_KEEP_WEIGHTS)

@@ -181,6 +181,15 @@ int dsph_plan_strip_pairs(const dsph_plan* p, int32_t K, int32_t* out, int64_t c
 
 static bool use_split(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo, int32_t part);
 
+int dsph_plan_strip_split(const dsph_plan* p, int64_t N, int32_t* grid, int32_t* pieces, int32_t* wg_per_piece, int64_t* tape_rows) {
+  if (!p || !grid || !pieces || !wg_per_piece || !tape_rows) { set_error("plan_strip_split: NULL argument"); return DSPH_E_BADARG; }
+  *grid = *pieces = *wg_per_piece = 0;
+  *tape_rows = 0;
+  DeviceGuard guard(p->device);
+  if (!fused_strip_split(p, N, grid, pieces, wg_per_piece, tape_rows)) { set_error("plan_strip_split: the plan holds no quad strips"); return DSPH_E_UNSUPPORTED; }
+  return DSPH_OK;
+}
+
 int dsph_plan_prepare_layer(dsph_plan* p, int32_t K, int32_t Fin, int32_t Fout, int32_t flags) {
   if (!p || K <= 0 || Fin <= 0 || Fout <= 0 || (flags & ~(DSPH_PREPARE_BACKWARD | DSPH_PREPARE_RELEASE_HOST))) {
     set_error("plan_prepare: bad arguments (plan %p, K %d, Fin %d, Fout %d, flags %d)", (void*)p, K, Fin, Fout, flags);

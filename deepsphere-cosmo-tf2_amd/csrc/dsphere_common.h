@@ -101,6 +101,7 @@ bool fused_weights_resident(const dsph_plan* plan, int32_t Fin, int32_t Fout, in
 bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
 int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision);
 int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_t cap);
+bool fused_strip_split(const dsph_plan* plan, int64_t N, int32_t* grid, int32_t* pieces, int32_t* wg_per_piece, int64_t* tape_rows);
 // conv + HealpyPool(p = 1) in one forward: the pooled map (N, n_rows / 4, Fout) and the kind of reduction (1 max, 2 mean)
 struct FusedPool {
   float* y;

@@ -44,6 +44,8 @@ SIGNATURES = {
     "dsph_plan_set_levels": (ctypes.c_int, [_c_vp, _c_i32, _c_vp]),
     "dsph_plan_set_option": (ctypes.c_int, [_c_vp, _c_i32, _c_i64]),
     "dsph_plan_strip_pairs": (ctypes.c_int, [_c_vp, _c_i32, _c_vp, _c_i64, ctypes.POINTER(_c_i64)]),
+    "dsph_plan_strip_split": (ctypes.c_int, [_c_vp, _c_i64, ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i32),
+                                             ctypes.POINTER(_c_i64)]),
     "dsph_plan_rows": (_c_i64, [_c_vp]),
     "dsph_plan_cols": (_c_i64, [_c_vp]),
     "dsph_plan_ell_width": (_c_i32, [_c_vp]),
@@ -234,6 +236,14 @@ class LaplacianPlan:
             check(lib().dsph_plan_strip_pairs(self.handle, int(K), out.ctypes.data, int(n.value), ctypes.byref(n)),
                   "dsph_plan_strip_pairs")
         return out
+
+    def strip_split(self, N):
+        """How a quad-strip forward of ``N`` maps cuts its work (``dsph_plan_strip_split``): (grid, pieces, workgroups per piece,
+        rows of the tape of one map)."""
+        g, p, w, r = _c_i32(0), _c_i32(0), _c_i32(0), _c_i64(0)
+        check(lib().dsph_plan_strip_split(self.handle, int(N), ctypes.byref(g), ctypes.byref(p), ctypes.byref(w), ctypes.byref(r)),
+              "dsph_plan_strip_split")
+        return int(g.value), int(p.value), int(w.value), int(r.value)
 
     def workspace_bytes(self, N, Fin, Fout, K, precision=PREC_FP32, algo=ALGO_AUTO):
         return int(lib().dsph_workspace_bytes(self.handle, int(N), int(Fin), int(Fout), int(K), int(precision),

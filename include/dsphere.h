@@ -200,6 +200,11 @@ int dsph_plan_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t
  * rows [y0, y1)), xlo, xhi, ylo, yhi (the clamp rectangle) -- in the virtual Z-order plane of the row index (x = even bits,
  * y = odd bits of the row number); *n_pairs the number of pairs the plan holds (also when capacity is smaller). */
 int dsph_plan_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_t capacity, int64_t* n_pairs);
+/* (With the quad strips -- DSPH_OPT_STRIP_FORM 0, K = 5 -- a record is ONE 64-column strip, uncut along y: x0[0], w[0], xs[0] and
+ * w[1] = 0.  The kernel cuts the rows at run time: the rows of all strips laid end to end form one tape per map, cut into
+ * `pieces` equal pieces, `wg_per_piece` workgroups per piece each taking every wg_per_piece-th map of the batch; a strip is cut
+ * wherever a piece ends.  This call reports that split for a batch of N maps -- for tests and tools that want to look at the seams.) */
+int dsph_plan_strip_split(const dsph_plan* plan, int64_t N, int32_t* grid, int32_t* pieces, int32_t* wg_per_piece, int64_t* tape_rows);
 
 /* Bytes of scratch dsph_cheb_forward needs for this call shape (0 is possible). */
 size_t dsph_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout,

@@ -178,17 +178,14 @@ def _strip_seam_rows(pairs):
     return np.unique(_interleave(np.array(xs), np.array(ys)))
 
 
-def _tape_cut_rows(pairs, N):
-    """The seams the quad-strip kernel makes at run time (csrc/cheb_qstrip_kernel.h, qstrip_split): the rows of all strips form
-    one tape per map, cut into P = G / N equal pieces (G workgroups, N of them per piece, one map each) -- so a strip is cut
-    wherever a piece ends.  Returns centres on both sides of every cut, at the first and last output column of the strip."""
-    num_cu = torch.cuda.get_device_properties(0).multi_processor_count
+def _tape_cut_rows(plan, pairs, N):
+    """The seams the quad-strip kernel makes at run time (csrc/cheb_qstrip_kernel.h): the rows of all strips form one tape per
+    map, cut into P equal pieces (``dsph_plan_strip_split`` reports P for this batch) -- so a strip is cut wherever a piece ends.
+    Returns centres on both sides of every cut, at the first and last output column of the strip."""
+    G, P, w, R = plan.strip_split(N)
     h = (pairs[:, 7] - pairs[:, 6]).astype(np.int64)
     prefix = np.concatenate([[0], np.cumsum(h)])
-    R = int(prefix[-1])
-    G = int(max(8, min(num_cu // 8 * 8, R * N // 64 // 8 * 8)))
-    assert N <= G, "this helper restates the cut for batches that fit the grid: w = N workgroups per piece"
-    P = G // N
+    assert R == int(prefix[-1]) and P * w <= G and (w == N or N > G)
     xs, ys = [], []
     for i in range(1, P):
         r = R * i // P
@@ -222,7 +219,7 @@ def test_headline_config_as_benchmarked():
     assert pairs.shape == (216, 12), "18 quad strips (56 output columns each, the last one 40) per base pixel, uncut along y"
     seams = _strip_seam_rows(pairs)
     assert seams.size > 1500 and seams.max() < M
-    cuts, G = _tape_cut_rows(pairs, N)
+    cuts, G = _tape_cut_rows(plan, pairs, N)
     assert G == 256 and cuts.size > 300 and cuts.max() < M, "63 cuts of the tape of rows, four rows x two columns each"
     centres = np.unique(np.concatenate([_special_rows(nside, M, np.random.default_rng(3)), seams, cuts]))
     ref = _patch_reference(cols, vals, x, W, K, centres, bias=b, activation="relu")
@@ -265,7 +262,7 @@ def test_config5_partial_sky_as_benchmarked():
     n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
     assert n_strip > 0, "C5 at batch 16 runs its rectangles on the strip kernel"
     seams = _strip_seam_rows(plan.strip_pairs(K)[::7])  # every seventh strip of the ragged cut
-    seams = np.unique(np.concatenate([seams, _tape_cut_rows(plan.strip_pairs(K), N)[0][::5]]))  # and every fifth run-time cut of the tape
+    seams = np.unique(np.concatenate([seams, _tape_cut_rows(plan, plan.strip_pairs(K), N)[0][::5]]))  # and every fifth run-time cut of the tape
     seams = seams[seams < M]
     ref2 = _patch_reference(cols, vals, x[:2], W, K, seams, bias=b, activation="relu")
     err2 = np.abs(y[:2, torch.as_tensor(seams).cuda()].cpu().numpy() - ref2).max() / s
