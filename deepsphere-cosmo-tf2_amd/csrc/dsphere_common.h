@@ -218,6 +218,23 @@ size_t qstrip_wimg_bytes();
 int64_t qstrip_split(int num_cu, int64_t tape_rows, int64_t N, int64_t mean_height, int* grid, int* pieces, int* wg_per_piece);
 int launch_cheb_qstrip(const QStripLaunch& s, hipStream_t stream);
 
+// quad-strip weight gradient (cheb_qwgrad.hip, round 5): dW of a K = 5, 64 -> 64 layer on the strips of the quad-strip kernel
+struct QWgradLaunch {
+  const float* x; const float* dy;
+  float* dw;                 // [64 * 5][lddw]
+  float* slabs;              // workspace: qwgrad_slab_bytes(num_cu)
+  const QStrip* strips; const int32_t* prefix;
+  int64_t tape_rows;
+  const float* gvals8; const float* gdiag;
+  int64_t x_rows, dy_rows, N;
+  int32_t nstrips, lddy, lddw, num_cu;
+  bool cheb;
+  bool accumulate = false;   // dw += (the other tiles' share is already there)
+};
+bool qwgrad_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
+size_t qwgrad_slab_bytes(int num_cu);
+int launch_cheb_qwgrad(const QWgradLaunch& s, hipStream_t stream);
+
 // NEST pooling (healpix_pool.hip)
 int launch_healpix_pool(const float* x, float* y, int64_t rows_out, int32_t F, int32_t group, bool maxp, hipStream_t stream);
 int launch_healpix_pool_backward(const float* x, const float* dy, float* dx, int64_t rows_out, int32_t F, int32_t group, bool maxp,
