@@ -98,6 +98,10 @@ struct FusedTiles {
   int n_all = 0, n_all_interior = 0;
   int32_t* d_rrest = nullptr;
   int n_rrest = 0, n_rrest_interior = 0;
+  // every tile the strips leave over, whatever its class (class R rest, T, G): what the BFS-tile kernel's weight-gradient mode
+  // runs next to the quad-strip weight gradient (cheb_qwgrad.hip)
+  int32_t* d_nonq = nullptr;
+  int n_nonq = 0;
 };
 
 struct FusedPlan {
@@ -112,6 +116,7 @@ struct FusedPlan {
   unsigned char* d_rowflag = nullptr;
   bool rows_tried = false;
   bool host_released = false;  // DSPH_PREPARE_RELEASE_HOST: no tables for further depths
+  int symmetric = -1;          // L~ == L~^T entry for entry (fused_symmetric; -1: not looked at yet)
   bool wide = false;           // ELL wider than the fused kernels' templates: only the depth-1 tables of the tiled step exist
   // The BFS-tile launch of a forward writes tiles of y that the structured launches do not touch: it runs on this side stream,
   // forked from and joined back into the caller's stream by the two events (a few dozen face-corner tiles would otherwise
@@ -185,6 +190,7 @@ static void free_tiles(FusedTiles& ft) {
   if (ft.d_qstrips) (void)hipFree(ft.d_qstrips);
   if (ft.d_qprefix) (void)hipFree(ft.d_qprefix);
   if (ft.d_rrest) (void)hipFree(ft.d_rrest);
+  if (ft.d_nonq) (void)hipFree(ft.d_nonq);
   if (ft.d_all) (void)hipFree(ft.d_all);
   if (ft.d_ipairs) (void)hipFree(ft.d_ipairs);
   ft = FusedTiles();
@@ -885,6 +891,12 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   ft.n_rrest_interior = (int)rrest.size();
   rrest.insert(rrest.end(), r_boundary.begin(), r_boundary.end());
   ft.n_rrest = (int)rrest.size();
+  std::vector<int32_t> nonq(rrest);
+  nonq.insert(nonq.end(), t_interior.begin(), t_interior.end());
+  nonq.insert(nonq.end(), t_boundary.begin(), t_boundary.end());
+  nonq.insert(nonq.end(), interior.begin(), interior.begin() + ft.n_part);
+  ft.n_nonq = (int)nonq.size();
+  if (nonq.empty()) nonq.push_back(0);
   if (rrest.empty()) rrest.push_back(0);
   if (pairs.empty()) pairs.push_back(StripPair());
   ft.n_r_interior = (int)r_interior.size();
@@ -909,6 +921,7 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
               up((void**)&ft.d_part, interior.data(), interior.size() * 4) &&
               up((void**)&ft.d_rlist, r_interior.data(), r_interior.size() * 4) &&
               up((void**)&ft.d_rrest, rrest.data(), rrest.size() * 4) &&
+              up((void**)&ft.d_nonq, nonq.data(), nonq.size() * 4) &&
               up((void**)&ft.d_all, all_tiles.data(), all_tiles.size() * 4) &&
               up((void**)&ft.d_pairs, pairs.data(), pairs.size() * sizeof(StripPair)) &&
               up((void**)&ft.d_qstrips, qstrips.data(), qstrips.size() * sizeof(QStrip)) &&
@@ -1006,6 +1019,7 @@ bool fused_weights_resident(const dsph_plan* plan, int32_t Fin, int32_t Fout, in
   return (size_t)2 * pr * FUSED_CH * 4 + wfrag_bytes(Fp, std::min(Fout, 64), K) + FUSED_BIAS_BYTES <= (size_t)LDS_BYTES;
 }
 
+static bool fused_symmetric(const dsph_plan* plan);
 int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags) {
   if (plan->fused && plan->fused->wide) {  // the tiled step's tables, so that the first forward does not build them
     TStepTables tb;
@@ -1025,7 +1039,10 @@ int fused_prepare(const dsph_plan* plan, int32_t K, int32_t Fin, int32_t flags) 
     std::lock_guard<std::mutex> lock(plan->fused->fork_mu);
     (void)side_stream_ready(plan, plan->fused, nullptr, true);
   }
-  if (flags & DSPH_PREPARE_BACKWARD) (void)get_tiles(plan, K - 1, true);
+  if (flags & DSPH_PREPARE_BACKWARD) {
+    (void)get_tiles(plan, K - 1, true);
+    (void)fused_symmetric(plan);  // (what the quad-strip weight gradient asks; the host arrays may be released below)
+  }
   if (flags & DSPH_PREPARE_RELEASE_HOST) {
     FusedPlan* fp = plan->fused;
     std::lock_guard<std::mutex> lock(fp->mu);
@@ -1240,7 +1257,8 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
                                const float* dy = nullptr, float* dw = nullptr, int32_t ld = 0, int32_t part = 0,
                                int32_t Fin_w = 0, int32_t only = 0,  // only: 0 every launch, 1 the structured ones, 2 the BFS-tile one
                                bool keep_weights = false,            // the weight images in the workspace are those of an earlier call
-                               const FusedPool* pool = nullptr);     // conv + pool: the strips store the pooled map (launch_cheb_fused)
+                               const FusedPool* pool = nullptr,      // conv + pool: the strips store the pooled map (launch_cheb_fused)
+                               const int32_t* wg_tiles = nullptr, int wg_ntiles = -1);  // weight-gradient mode on these tiles only
 
 int launch_cheb_fused(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                       float* y, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t act,
@@ -1452,12 +1470,83 @@ int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* 
   return DSPH_OK;
 }
 
+// ---- quad-strip weight gradient (cheb_qwgrad.hip) -----------------------------------------------------------------------
+// L~ equal to its transpose, entry for entry (to fp32 rounding): the product rule the quad-strip weight gradient stands on
+// moves T_j from x to dy.
+static bool fused_symmetric(const dsph_plan* plan) {
+  FusedPlan* fp = plan->fused;
+  std::lock_guard<std::mutex> lock(fp->mu);
+  if (fp->symmetric >= 0) return fp->symmetric == 1;
+  if (fp->host_released || plan->n_rows != plan->n_cols) return false;  // (not cached: unknown, or not a square operator)
+  const int W = plan->width;
+  const int64_t n = plan->n_rows;
+  const int32_t* cols = fp->h_cols.data();
+  const float* vals = fp->h_vals.data();
+  bool sym = true;
+  for (int64_t r = 0; r < n && sym; ++r)
+    for (int j = 0; j < W; ++j) {
+      const int64_t c = cols[r * W + j];
+      const float v = vals[r * W + j];
+      if (v == 0.f || c == r) continue;  // (padding entries carry zeros)
+      if (c < 0 || c >= n) { sym = false; break; }
+      // the entry (c, r) must hold the same value (every off-diagonal entry is checked from its own side)
+      float back = 0.f;
+      for (int i = 0; i < W; ++i)
+        if (cols[c * W + i] == r) back += vals[c * W + i];
+      // (to the last bits of fp32: a normalised Laplacian D^-1/2 A D^-1/2 evaluated in float64 and rounded may differ by one
+      // unit in the last place between (r, c) and (c, r); that moves dW by 1e-7 of itself, far below the arithmetic's 4e-6)
+      if (fabsf(back - v) > 2.4e-7f * fmaxf(fabsf(back), fabsf(v))) { sym = false; break; }
+    }
+  fp->symmetric = sym ? 1 : 0;
+  return sym;
+}
+
+// The quad-strip weight gradient takes the strips' pixels of a K = 5, 64 -> 64 j layer in the three-term bf16 arithmetic when
+// the forward of that shape would run on the quad strips (same tables, same cost rule) and L~ is symmetric; the BFS-tile
+// kernel's weight-gradient mode takes the tiles the strips leave over.
+bool fused_qwgrad_applies(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision) {
+  if (precision != DSPH_PREC_BF16X3 || !qwgrad_shape_ok(Fin, 64, K) || Fout % 64 != 0) return false;
+  if (!plan->fused || plan->fused->wide || plan->n_rows != plan->n_cols || !plan->levels.empty()) return false;
+  if (!fused_wgrad_supported(plan, Fin, Fout, K)) return false;
+  const FusedTiles& ft = get_tiles(plan, K - 1, false);
+  if (!ft.ok || !use_qstrips(plan, ft, Fin, 64, K) || !strips_apply(plan, ft, Fin, 64, K, DSPH_PREC_BF16X3, N, Fout)) return false;
+  return fused_symmetric(plan);
+}
+
+size_t fused_qwgrad_workspace_bytes(const dsph_plan* plan) { return qwgrad_slab_bytes(plan->fused ? plan->fused->num_cu : 256); }
+
+// workspace: [the BFS-tile kernel's slabs (fused_wgrad_workspace_bytes, 256-aligned) | the quad strips' slabs]
+int launch_cheb_fused_qwgrad(const dsph_plan* plan, const float* x, const float* dy, float* dw, int64_t N, int32_t Fin, int32_t Fout,
+                             int32_t K, float alpha_rest, float beta_rest, void* workspace, size_t bfs_slab_bytes, hipStream_t stream) {
+  const FusedTiles& ft = get_tiles(plan, K - 1, false);
+  for (int32_t cb = 0; cb < Fout; cb += 64) {
+    if (ft.n_nonq > 0) {
+      const int rc = launch_fused_common(plan, x, nullptr, nullptr, static_cast<float*>(workspace), nullptr, N, Fin, 64, K, DSPH_ACT_NONE,
+                                         DSPH_PREC_BF16X3, alpha_rest, beta_rest, nullptr, 0, stream, dy + cb, dw + cb, Fout, 0, Fin, 0, false,
+                                         nullptr, ft.d_nonq, ft.n_nonq);
+      if (rc != DSPH_OK) return rc;
+    }
+    QWgradLaunch q;
+    q.x = x; q.dy = dy + cb; q.dw = dw + cb;
+    q.slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + bfs_slab_bytes);
+    q.strips = ft.d_qstrips; q.prefix = ft.d_qprefix; q.tape_rows = ft.qtape_rows;
+    q.gvals8 = plan->fused->d_gvals8; q.gdiag = plan->fused->d_gdiag;
+    q.x_rows = plan->n_cols; q.dy_rows = plan->n_rows; q.N = N;
+    q.nstrips = ft.n_qstrips; q.lddy = Fout; q.lddw = Fout; q.num_cu = plan->fused->num_cu;
+    q.cheb = beta_rest != 0.f;
+    q.accumulate = ft.n_nonq > 0;
+    const int rc = launch_cheb_qwgrad(q, stream);
+    if (rc != DSPH_OK) return rc;
+  }
+  return DSPH_OK;
+}
+
 static int launch_fused_common(const dsph_plan* plan, const float* x, const float* w, const float* bias,
                                float* y, float* planes_out, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                                int32_t act, int32_t precision, float alpha_rest, float beta_rest,
                                void* workspace, size_t workspace_bytes, hipStream_t stream, const float* dy,
                                float* dw, int32_t ld, int32_t part, int32_t Fin_w, int32_t only, bool keep_weights,
-                               const FusedPool* pool) {
+                               const FusedPool* pool, const int32_t* wg_tiles, int wg_ntiles) {
   // DSPH_PREC_F16X3 is the quad strips' arithmetic; every other kernel of the forward runs the six-term split (same accuracy)
   const bool f16 = precision == DSPH_PREC_F16X3;
   const int32_t strip_precision = precision;
@@ -1639,6 +1728,10 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   // the BFS-tile kernel handles the tiles of d_part (every tile of a full table, the class-G ones otherwise)
   args.tile_list = part == 0 ? (ft.n_part == ft.ntiles ? nullptr : ft.d_part) : (part == 1 ? ft.d_part : ft.d_part + ft.n_interior);
   args.ntiles = part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior);
+  if (wgrad_mode && wg_ntiles >= 0) {  // (the strips' pixels go to cheb_qwgrad.hip: launch_cheb_fused_qwgrad)
+    args.tile_list = wg_tiles;
+    args.ntiles = wg_ntiles;
+  }
   if (args.ntiles == 0) return DSPH_OK;
   args.nchunks = C;
   args.act = act;
@@ -1653,7 +1746,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
 #endif
   const int pr = plane_rows_for(ft.rmax, ft.emax);
   const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wb;
-  const int grid = wgrad_mode ? fused_grid(plan, ft) : fused_grid(plan, ft, args.ntiles);
+  const int grid = (wgrad_mode && wg_ntiles < 0) ? fused_grid(plan, ft) : fused_grid(plan, ft, args.ntiles);
   if (wgrad_mode) {
     // as many slices per launch as fit the wave's WG_TILES accumulator tiles; every launch runs the
     // recurrence for its own slices only, so the split costs nothing but a second read of dy

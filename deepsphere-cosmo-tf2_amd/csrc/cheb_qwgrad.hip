@@ -14,9 +14,12 @@ __global__ __launch_bounds__(256) void qwgrad_reduce_kernel(const float* __restr
   const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int e = blockIdx.x * 16 + el;  // f * 64 + o
   float s[QW_PAIRS] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int i = q; i < nslabs; i += 16)
+  for (int i = q; i < nslabs; i += 16) {
+    // (workgroup i of the kernel: its place `ord` in the XCD-wise order; the odd ones ran on -dy)
+    const float sg = (((i & 7) * (nslabs >> 3) + (i >> 3)) & 1) ? -1.f : 1.f;
 #pragma unroll
-    for (int pr = 0; pr < QW_PAIRS; ++pr) s[pr] += slabs[(size_t)i * QW_SLAB + (size_t)pr * 4096 + e];
+    for (int pr = 0; pr < QW_PAIRS; ++pr) s[pr] = fmaf(sg, slabs[(size_t)i * QW_SLAB + (size_t)pr * 4096 + e], s[pr]);
+  }
 #pragma unroll
   for (int pr = 0; pr < QW_PAIRS; ++pr) part[pr][q][el] = s[pr];
   __syncthreads();

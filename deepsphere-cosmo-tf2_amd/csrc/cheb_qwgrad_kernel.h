@@ -27,7 +27,8 @@
 //   conflict-free.  The inner index of a 32-pixel block is k = 4 (p & 7) + tile, the same on both operands.
 // Matrix work: wave (og = w & 3, fh = w >> 2) owns the output tiles (pair, f-group 2 fh + {0, 1}, o-group og): ten 16 x 16
 //   accumulators (40 registers) that live for the whole kernel; three terms per product (hi.hi + hi.lo + lo.hi).
-// Output: one slab [5][64][64] per workgroup; qwgrad_reduce_kernel adds the slabs in a fixed order and applies the rule above.
+// Output: one slab [5][64][64] per workgroup (of every second workgroup: the slab of -dy, see `sgn`); qwgrad_reduce_kernel adds
+//   the slabs in a fixed order and applies the rule above.
 #pragma once
 
 #include "cheb_qstrip_kernel.h"
@@ -74,6 +75,12 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
   const int G = gridDim.x, ord = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   const int piece = ord / a.wg_per_piece, map0 = ord - piece * a.wg_per_piece;
   float* __restrict__ slab = a.slabs + (size_t)blockIdx.x * QW_SLAB;
+  // Every second workgroup runs on -dy and hands in -G (qwgrad_reduce_kernel subtracts its slab).  Why: the matrix pipe adds
+  // the 32 products of an instruction to an accumulator hundreds of times their size, and what it drops when it aligns them
+  // is dropped towards minus infinity -- measured at the headline size (tools/check_dw_c3.py): every element of dW low by the
+  // same 2e-5 of max |dW| whatever its sign, growing with the length of the sum (the same in the BFS-tile kernel's bf16 mode).
+  // A bias that does not depend on the sign of the data cancels between a workgroup and its mirror.
+  const float sgn = (ord & 1) ? -1.f : 1.f;
   qs_f4 acc[QW_PAIRS][2];
 #pragma unroll
   for (int i = 0; i < QW_PAIRS; ++i)
@@ -168,7 +175,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
       const int cfirst = st.x0 - st.xs, clast = cfirst + st.w;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        voff[t] = st_spread((unsigned)min(max(st.xs + 4 * p + t, st.xlo), st.xhi)) * srowb + (unsigned)(16 * cq + 4 * q4) * 4u;
+        // (dy is read on the output pixels only -- elsewhere it is zeroed, and its halo may not exist: the load stays inside)
+        voff[t] = st_spread((unsigned)min(max(st.xs + 4 * p + t, sideQ ? st.x0 : st.xlo), sideQ ? st.x0 + st.w - 1 : st.xhi)) * srowb +
+                  (unsigned)(16 * cq + 4 * q4) * 4u;
         colk[t] = 4 * p + t >= cfirst && 4 * p + t < clast;
       }
       const unsigned sXc = st_spread((unsigned)min(max(st.xs + 4 * p + cq, st.xlo), st.xhi));
@@ -177,8 +186,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
       auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
         return st_spread((unsigned)min(max(yrow, st.ylo), st.yhi)) << 1;
       };
+      const int rlo = sideQ ? st.y0 : st.ylo, rhi = sideQ ? st.y1 - 1 : st.yhi;
       auto row_fetch = [&](int yrow, QRow& R) __attribute__((always_inline)) {
-        const char* rb = smap + (size_t)spread_y(yrow) * srowb;
+        const char* rb = smap + (size_t)(st_spread((unsigned)min(max(yrow, rlo), rhi)) << 1) * srowb;
         const char *p0 = rb + voff[0], *p1 = rb + voff[1], *p2 = rb + voff[2], *p3 = rb + voff[3];
         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
                      "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"
@@ -227,9 +237,11 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
               asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0[L2].t[0]), "+v"(S0[L2].t[1]), "+v"(S0[L2].t[2]), "+v"(S0[L2].t[3]) : : "memory");
               const bool rowk = ytop >= st.y0 && ytop < st.y1;  // dy counts on the output pixels of this work item only
 #pragma unroll
-              for (int t = 0; t < 4; ++t)
+              for (int t = 0; t < 4; ++t) {
+                const float mk = (rowk && colk[t]) ? sgn : 0.f;  // (what is multiplied by 0 is dy inside the item too: the loads are clamped to it)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) S0[L2].t[t][e] = (rowk && colk[t]) ? S0[L2].t[t][e] : 0.f;
+                for (int e = 0; e < 4; ++e) S0[L2].t[t][e] *= mk;
+              }
             } else asm volatile("s_waitcnt vmcnt(2)" : "+v"(S0[L2].t[0]), "+v"(S0[L2].t[1]), "+v"(S0[L2].t[2]), "+v"(S0[L2].t[3]) : : "memory");
           }
           if (u == 19) qs_settle<1>(S1[L2]);

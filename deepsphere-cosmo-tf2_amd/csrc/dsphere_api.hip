@@ -479,7 +479,8 @@ size_t dsph_backward_weights_workspace_bytes(const dsph_plan* p, int64_t N, int3
   // channel count, 13.5 ms for the 5 x 16 numbers of a 1 -> 16 layer at nside 512)
   const int32_t Fp = (Fin + 3) & ~3;
   if (algo != DSPH_ALGO_UNFUSED && fused_wgrad_supported(p, Fp, Fout, K))
-    return align_up(fused_wgrad_workspace_bytes(p, Fp, Fout, K), 256) + (Fp != Fin ? (size_t)N * (size_t)p->n_cols * (size_t)Fp * 4 : 0);
+    return align_up(fused_wgrad_workspace_bytes(p, Fp, Fout, K), 256) + (Fp != Fin ? (size_t)N * (size_t)p->n_cols * (size_t)Fp * 4 : 0) +
+           (qwgrad_shape_ok(Fin, 64, K) && Fout % 64 == 0 ? align_up(fused_qwgrad_workspace_bytes(p), 256) : 0);  // (the quad strips' slabs)
   if (algo == DSPH_ALGO_FUSED) return 0;
   return planes_bytes(p, N, Fin, K) + wgrad_workspace_bytes(N, out_rows(p), Fin, Fout, K);
 }
@@ -532,6 +533,10 @@ int dsph_cheb_backward_weights(const dsph_plan* p, const float* x, const float* 
       if (rc != DSPH_OK) return rc;
       x = xp;
     }
+    // K = 5, 64 -> 64 j in the three-term arithmetic on a map the forward runs on the quad strips: their pixels on the
+    // quad-strip weight-gradient kernel (cheb_qwgrad.hip), the other tiles on the BFS-tile kernel
+    if (Fp == Fin && fused_qwgrad_applies(p, N, Fin, Fout, K, precision))
+      return launch_cheb_fused_qwgrad(p, x, dy, dw, N, Fin, Fout, K, alpha_rest, beta_rest, workspace, slab_bytes, stream);
     return launch_cheb_fused_wgrad(p, x, dy, dw, N, Fp, Fout, K, precision, alpha_rest, beta_rest, workspace, slab_bytes, stream, Fin);
   }
   // any L, any shape: K-1 gather launches into workspace planes, then the split-over-pixels MFMA kernel

@@ -119,6 +119,11 @@ int launch_cheb_fused_planes(const dsph_plan* plan, const float* x, float* plane
 bool fused_wgrad_supported(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 size_t fused_wgrad_workspace_bytes(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 int launch_fused_pad(const float* x, float* xp, int64_t rows, int32_t Fin, int32_t Fp, hipStream_t stream);  // zero-padded copy, Fp = 4 ceil(Fin / 4)
+// the strips' share of dW on the quad-strip weight-gradient kernel, the other tiles' on the BFS-tile kernel (cheb_fused.hip)
+bool fused_qwgrad_applies(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision);
+size_t fused_qwgrad_workspace_bytes(const dsph_plan* plan);
+int launch_cheb_fused_qwgrad(const dsph_plan* plan, const float* x, const float* dy, float* dw, int64_t N, int32_t Fin, int32_t Fout,
+                             int32_t K, float alpha_rest, float beta_rest, void* workspace, size_t bfs_slab_bytes, hipStream_t stream);
 int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* dy, float* dw, int64_t N,
                             int32_t Fin, int32_t Fout, int32_t K, int32_t precision, float alpha_rest, float beta_rest,
                             void* workspace, size_t workspace_bytes, hipStream_t stream, int32_t Fin_w = 0);  // Fin_w: real channels (rows of dw) when x is a zero-padded copy

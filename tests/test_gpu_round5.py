@@ -265,3 +265,105 @@ def test_one_rank_of_rccl():
     assert res["backend"] == "nccl" and res["allreduce_ok"]
     assert res["y_equal"], "world 1: the sharded forward is the unsharded one"
     assert res["dk_err"] < 1e-6
+
+
+# the quad-strip weight gradient runs the three-term bf16 arithmetic on both operands and forms orders 3 and 4 from products of
+# order-2 planes (2 G - G': twice the rounding of one product): measured 4 - 8e-6 of max |dW|, held to 2e-5; the layers'
+# default for dW stays exact fp32 (gnn_layers.resolve_wgrad_precision)
+TOL_QWGRAD = 2e-5
+
+
+@pytest.mark.parametrize("nside,N,Fout,basis", [
+    (128, 3, 64, "chebyshev"),   # strips of 56 and 40 columns, 96 rows; an odd batch: the tape of rows is cut inside strips
+    (128, 2, 128, "monomial"),   # two column blocks of dy, the other basis
+    (256, 1, 64, "chebyshev"),   # four strips of 56 columns per face; one map: a workgroup per piece of the tape
+])
+def test_quad_strip_weight_gradient(nside, N, Fout, basis):
+    """dsph_cheb_backward_weights on the quad-strip weight-gradient kernel (csrc/cheb_qwgrad_kernel.h: the strips' pixels; the
+    other tiles on the BFS-tile kernel) against the float64 oracle dW[f K + k, o] = sum T_k(x)[n, m, f] dy[n, m, o], against the
+    exact-fp32 route of the same plan, and bit for bit against itself."""
+    K, Fin = 5, 64
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(nside + N + Fout)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    dy = rng.standard_normal((N, M, Fout)).astype(np.float32)
+    Lc = _csr(cols, vals)
+    assert abs(Lc - Lc.T).max() <= 1e-7, "the test's operator is symmetric (what the kernel's product rule needs)"
+    planes = orc.chebyshev_planes(Lc, x, K) if basis == "chebyshev" else orc.monomial_planes(Lc, x, K)
+    ref = np.einsum("knmf,nmo->fko", planes, dy.astype(np.float64)).reshape(Fin * K, Fout)
+    del planes
+    B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
+    plan = _plan(cols, vals, K, Fin, {_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
+    nt = nside // 16
+    assert plan.strip_tiles(Fin, 64, K, _native.PREC_BF16X3, N=N) == 12 * (nt - 2) ** 2, "the strips this test is about exist"
+    dw, ws = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, basis=B, algo=_native.ALGO_FUSED, precision=_native.PREC_BF16X3)
+    err = rel_err(dw.cpu().numpy(), ref)
+    print(f"quad-strip dW nside={nside} N={N} Fout={Fout} {basis}: rel err {err:.2e}")
+    assert err < TOL_QWGRAD
+    again, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, basis=B, algo=_native.ALGO_FUSED, precision=_native.PREC_BF16X3,
+                                             workspace=ws)
+    assert torch.equal(dw, again), "fixed-order sums: two launches agree bit for bit"
+    exact, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, basis=B, algo=_native.ALGO_FUSED)
+    assert rel_err(exact.cpu().numpy(), ref) < 1e-5
+    # the same call on a plan without strips: the BFS-tile kernel alone, same arithmetic class
+    plain = _plan(cols, vals, K, Fin, {_native.OPT_STRIPS: _native.STRIPS_NEVER})
+    other, _ = _native.cheb_backward_weights(plain, _dev(x), _dev(dy), K, basis=B, algo=_native.ALGO_FUSED, precision=_native.PREC_BF16X3)
+    assert rel_err(other.cpu().numpy(), ref) < 1e-5
+    assert not torch.equal(other, dw), "the two plans run different kernels (else this test exercises nothing)"
+
+
+def test_quad_strip_weight_gradient_needs_a_symmetric_operator():
+    """The product rule behind the quad-strip weight gradient (T_3 = 2 T_2 T_1 - T_1, T_4 = 2 T_2 T_2 - T_0 moved onto dy) holds
+    for a symmetric L~ only: the library checks the plan's matrix and keeps every tile of a non-symmetric one on the BFS-tile
+    kernel -- same answer as the float64 oracle either way."""
+    nside, N, K, Fin, Fout = 128, 2, 5, 64, 64
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(7)
+    vals = (vals * (1.0 + 0.2 * rng.random((M, 1)))).astype(np.float32)  # rows scaled differently: L~ != L~^T
+    Lc = _csr(cols, vals)
+    assert abs(Lc - Lc.T).max() > 1e-3
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    dy = rng.standard_normal((N, M, Fout)).astype(np.float32)
+    ref = np.einsum("knmf,nmo->fko", orc.chebyshev_planes(Lc, x, K), dy.astype(np.float64)).reshape(Fin * K, Fout)
+    plan = _plan(cols, vals, K, Fin, {_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
+    dw, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, algo=_native.ALGO_FUSED, precision=_native.PREC_BF16X3)
+    assert rel_err(dw.cpu().numpy(), ref) < 1e-5
+
+
+def test_quad_strip_weight_gradient_at_the_benchmarked_size():
+    """BASELINE configs[2] (nside 1024, 64 -> 64, K = 5, batch 4: what tools/bench_backward.py times): rows of dW against the
+    float64 oracle -- the oracle's planes of three input channels of the whole batch (the recurrence on one channel of a
+    12.6 Mpixel map is seconds of scipy), contracted with eight columns of dy --, the whole of dW against the exact-fp32 weight
+    gradient of the BFS-tile kernel, and additivity over the batch (a size-independent property: dW of the batch is the sum of
+    the dW of its maps, to the arithmetic's rounding)."""
+    nside, N, K, Fin, Fout = 1024, 4, 5, 64, 64
+    cols, vals = _grid_ell(nside)
+    plan = _plan(cols, vals, K, Fin)
+    assert plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N) > 0, "the headline forward runs on the quad strips"
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((N, cols.shape[0], Fin), device="cuda", generator=g)
+    dy = torch.randn((N, cols.shape[0], Fout), device="cuda", generator=g)
+    dw, ws = _native.cheb_backward_weights(plan, x, dy, K, algo=_native.ALGO_FUSED, precision=_native.PREC_BF16X3)
+    exact, _ = _native.cheb_backward_weights(plan, x, dy, K, algo=_native.ALGO_FUSED, precision=_native.PREC_FP32)
+    scale = float(exact.abs().max())
+    Lc = _csr(cols, vals)
+    fs, osub = (0, 29, 63), slice(8, 16)
+    dy_h = dy[:, :, osub].cpu().numpy().astype(np.float64)
+    worst = {"quad": 0.0, "fp32": 0.0}
+    for f in fs:
+        planes = orc.chebyshev_planes(Lc, x[:, :, f:f + 1].cpu().numpy(), K)  # [K, N, M, 1] float64
+        ref = np.einsum("knm,nmo->ko", planes[..., 0], dy_h)
+        for name, got in (("quad", dw), ("fp32", exact)):
+            worst[name] = max(worst[name], float(np.abs(got[f * K:(f + 1) * K, osub].cpu().numpy() - ref).max()) / scale)
+    print(f"dW at nside 1024, batch 4, rows of {len(fs)} input channels x 8 columns against the float64 oracle: quad strips "
+          f"{worst['quad']:.2e}, exact-fp32 BFS tiles {worst['fp32']:.2e} of max |dW|; "
+          f"the two routes differ by {float((dw - exact).abs().max()) / scale:.2e}")
+    assert worst["quad"] < TOL_QWGRAD and worst["fp32"] < TOL_QWGRAD
+    parts = torch.zeros_like(dw)
+    for n in range(N):
+        one, ws = _native.cheb_backward_weights(plan, x[n:n + 1], dy[n:n + 1], K, algo=_native.ALGO_FUSED, precision=_native.PREC_BF16X3,
+                                                workspace=ws)
+        parts += one
+    assert float((parts - dw).abs().max()) / scale < TOL_QWGRAD
