@@ -1415,8 +1415,10 @@ size_t fused_wgrad_workspace_bytes(const dsph_plan* plan, int32_t Fin, int32_t F
 // dw[(f*K + k)*Fout + o] = sum over slabs, in a fixed order (deterministic): sixteen lanes per element, lane p sums the slabs
 // p, p + 16, ... in ascending order, the sixteen partial sums are added pairwise in a fixed tree.  (One thread per element with
 // a serial loop over 512 slabs took 0.14 ms at 16 -> 32: more than a seventh of that layer's weight gradient.)
+// mirror_grid > 0 (the bf16 arithmetic): the slabs of the odd workgroups blockIdx.x of a grid of that many hold -dW
+// (cheb_fused_kernel.h, weight-gradient mode) and are subtracted.
 __global__ __launch_bounds__(256) void fused_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                                 int nslabs, int Fin, int Fout, int K, int C, int ld) {
+                                                                 int nslabs, int Fin, int Fout, int K, int C, int ld, int mirror_grid) {
   __shared__ float part[16][17];
   const int el = threadIdx.x & 15, p = threadIdx.x >> 4;
   const int e = blockIdx.x * 16 + el;
@@ -1426,7 +1428,10 @@ __global__ __launch_bounds__(256) void fused_wgrad_reduce_kernel(const float* __
   const size_t off = ((size_t)((f >> 4) * K + k) * 16 + (f & 15)) * 64 + o;
   float s = 0.f;
   if (live)
-    for (int i = p; i < nslabs; i += 16) s += slabs[(size_t)i * slab + off];
+    for (int i = p; i < nslabs; i += 16) {
+      const float v = slabs[(size_t)i * slab + off];
+      s += (mirror_grid > 0 && (((i >> 1) % mirror_grid) & 1)) ? -v : v;
+    }
   part[p][el] = s;
   __syncthreads();
   if (p == 0 && live) {
@@ -1776,7 +1781,8 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     // (Fin_w < Fin: x is a zero-padded copy, only the rows of the real channels exist in dw)
     const int total = Fin_w * K * Fout;
     hipLaunchKernelGGL(fused_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, stream, args.slabs, dw,
-                       2 * grid * fused_wgrad_gy(args.N, grid, args.num_cu), (int)Fin_w, (int)Fout, (int)K, C, (int)ld);
+                       2 * grid * fused_wgrad_gy(args.N, grid, args.num_cu), (int)Fin_w, (int)Fout, (int)K, C, (int)ld,
+                       precision == DSPH_PREC_BF16X3 ? grid : 0);
     DSPH_HIP(hipGetLastError());
     return DSPH_OK;
   }

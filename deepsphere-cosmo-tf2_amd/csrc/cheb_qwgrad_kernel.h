@@ -21,10 +21,11 @@
 // Step with top row t:  S0[t] arrives (global -> registers, requested a step ahead), S1[t-1] = L~ S0, S2[t-2] = 2 L~ S1 - S0
 //   (12 + 12 stencil units), while the matrix pipe contracts the row staged by the previous step; barrier; the planes of row
 //   t-2 are split hi + lo into bf16 and staged; barrier.
-// Staging (5 plane rows x 18,432 B): [plane][hi | lo][16-channel group][32-pixel block][k-group kg][channel m][8 pixels x 2 B]
-//   with 272-byte k-groups and 1,152-byte blocks: the writers' ds_write_b64 (lane = (pixel group p, channel group q4)) and the
-//   readers' ds_read_b128 (lane = (channel m, k-group): an A or B operand of v_mfma_f32_16x16x32_bf16 as it stands) are both
-//   conflict-free.  The inner index of a 32-pixel block is k = 4 (p & 7) + tile, the same on both operands.
+// Staging (5 plane rows x 19,456 B): [plane][hi | lo][16-channel group][32-pixel block][k-group kg][channel m][8 pixels x 2 B]
+//   with 272-byte k-groups and 1,216-byte blocks: the writers' ds_write_b64 (lane = (pixel group p, channel group q4); groups of
+//   16 lanes, banks of a store = address / 4 mod 32) are conflict-free; the readers' ds_read_b128 (lane = (channel m, k-group):
+//   an A or B operand of v_mfma_f32_16x16x32_bf16 as it stands) pay one two-way conflict per instruction for the padding (the
+//   read's lane groups want contiguous 1 KiB fragments, which would put the four k-groups of a store on the same banks).  The inner index of a 32-pixel block is k = 4 (p & 7) + tile, the same on both operands.
 // Matrix work: wave (og = w & 3, fh = w >> 2) owns the output tiles (pair, f-group 2 fh + {0, 1}, o-group og): ten 16 x 16
 //   accumulators (40 registers) that live for the whole kernel; three terms per product (hi.hi + hi.lo + lo.hi).
 // Output: one slab [5][64][64] per workgroup (of every second workgroup: the slab of -dy, see `sgn`); qwgrad_reduce_kernel adds
@@ -36,10 +37,14 @@
 namespace dsph {
 
 constexpr int QW_SK = 272;               // bytes of one k-group: 16 channels x 16 B, + 16
-constexpr int QW_SB = 1152;              // one 32-pixel block of a 16-channel group: 4 k-groups, + 64
+#ifdef DSPH_QW_SB
+constexpr int QW_SB = DSPH_QW_SB;        // (tuning)
+#else
+constexpr int QW_SB = 1216;              // one 32-pixel block of a 16-channel group: 4 k-groups, + 128 (= 64 mod 128)
+#endif
 constexpr int QW_CG = 2 * QW_SB;         // a 16-channel group: two blocks
 constexpr int QW_HL = 4 * QW_CG;         // hi or lo of a plane row
-constexpr int QW_PLANE = 2 * QW_HL;      // 18,432 B
+constexpr int QW_PLANE = 2 * QW_HL;      // 19,456 B
 constexpr int QW_P0 = 0, QW_P2 = 1, QW_Q0 = 2, QW_Q1 = 3, QW_Q2 = 4, QW_NPLANES = 5;
 constexpr int QW_PAIRS = 5;              // G00 G01 G20 G21 G22
 constexpr int QW_SLAB = QW_PAIRS * 64 * 64;  // floats per workgroup
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
   // is dropped towards minus infinity -- measured at the headline size (tools/check_dw_c3.py): every element of dW low by the
   // same 2e-5 of max |dW| whatever its sign, growing with the length of the sum (the same in the BFS-tile kernel's bf16 mode).
   // A bias that does not depend on the sign of the data cancels between a workgroup and its mirror.
-  const float sgn = (ord & 1) ? -1.f : 1.f;
+  const float sgn = (sideQ && (ord & 1)) ? -1.f : 1.f;
   qs_f4 acc[QW_PAIRS][2];
 #pragma unroll
   for (int i = 0; i < QW_PAIRS; ++i)
@@ -113,8 +118,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
   const unsigned rd_off = (unsigned)(lane >> 4) * QW_SK + (unsigned)(lane & 15) * 16u;
 
   // ---- L~ (waves 0..3): the row's values of the pixels 4 p + cq, filed as cheb_qstrip_kernel.h files them ---------------
-  auto cfetch = [&](const char* pv, const char* pd, qs_f4& cv, float& cd) __attribute__((always_inline)) {
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(cv), "=&v"(cd) : "v"(pv), "v"(pd) : "memory");
+  auto cfetch = [&](const char* gv, const char* gd, unsigned offv, unsigned offd, qs_f4& cv, float& cd) __attribute__((always_inline)) {
+    cv = *reinterpret_cast<const qs_f4*>(gv + offv);
+    cd = *reinterpret_cast<const float*>(gd + offd);
   };
   auto cstore = [&](int slot, qs_f4 cv, float cd) __attribute__((always_inline)) {
     unsigned char* q = smem + LDS_C + (unsigned)slot * CROWB + (unsigned)p * 16u + (unsigned)cq * 4u;
@@ -141,6 +147,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   auto stage = [&](int plane, const QRow& R) __attribute__((always_inline)) {
+    if (QS_ABL & 8192) { asm volatile("" : : "v"(R.t[0]), "v"(R.t[1]), "v"(R.t[2]), "v"(R.t[3])); return; }  // (tuning builds: QS_ABL)
     unsigned char* q = smem + (unsigned)plane * QW_PLANE + wr_off;
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
@@ -160,6 +167,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
     }
   };
   auto frag = [&](int plane, int hl, int cg, int blk) __attribute__((always_inline)) -> qs_bf8 {
+    if (QS_ABL & 16384) { qs_bf8 z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
     return *reinterpret_cast<const qs_bf8*>(smem + (unsigned)plane * QW_PLANE + (unsigned)hl * QW_HL + (unsigned)cg * QW_CG + (unsigned)blk * QW_SB + rd_off);
   };
 
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
         // (dy is read on the output pixels only -- elsewhere it is zeroed, and its halo may not exist: the load stays inside)
         voff[t] = st_spread((unsigned)min(max(st.xs + 4 * p + t, sideQ ? st.x0 : st.xlo), sideQ ? st.x0 + st.w - 1 : st.xhi)) * srowb +
                   (unsigned)(16 * cq + 4 * q4) * 4u;
-        colk[t] = 4 * p + t >= cfirst && 4 * p + t < clast;
+        colk[t] = !sideQ || (4 * p + t >= cfirst && 4 * p + t < clast);
       }
       const unsigned sXc = st_spread((unsigned)min(max(st.xs + 4 * p + cq, st.xlo), st.xhi));
       const unsigned coffv = sXc * 32u + (unsigned)(q4 & 1) * 16u, coffd = sXc * 4u;
@@ -187,14 +195,13 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
         return st_spread((unsigned)min(max(yrow, st.ylo), st.yhi)) << 1;
       };
       const int rlo = sideQ ? st.y0 : st.ylo, rhi = sideQ ? st.y1 - 1 : st.yhi;
+      // Plain loads, not asm: the compiler then knows the data is in flight -- it keeps the registers out of other use until
+      // the first reader and counts vmcnt itself.  (With the loads in asm statements it took their results for present and
+      // moved them through registers it reused meanwhile: wrong rows.)  The asm statements around keep the requests in place.
       auto row_fetch = [&](int yrow, QRow& R) __attribute__((always_inline)) {
         const char* rb = smap + (size_t)(st_spread((unsigned)min(max(yrow, rlo), rhi)) << 1) * srowb;
-        const char *p0 = rb + voff[0], *p1 = rb + voff[1], *p2 = rb + voff[2], *p3 = rb + voff[3];
-        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
-                     "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"
-                     : "=&v"(R.t[0]), "=&v"(R.t[1]), "=&v"(R.t[2]), "=&v"(R.t[3])
-                     : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-                     : "memory");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) R.t[t] = *reinterpret_cast<const qs_f4*>(rb + voff[t]);
       };
       const int T3 = ((st.y1 - st.y0) + 2 * D + 1 + 2) / 3;
       QRow S0[3], S1[3];
@@ -203,18 +210,21 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
 #pragma unroll
         for (int t = 0; t < 4; ++t) { S0[s].t[t] = qs_f4{0.f, 0.f, 0.f, 0.f}; S1[s].t[t] = qs_f4{0.f, 0.f, 0.f, 0.f}; }
       int ytop = st.y0 - D, cs = 0;  // cs: ring slot of the row ytop of L~
-      row_fetch(ytop, S0[2]);
+      QRow nx;  // the row in flight
+      row_fetch(ytop, nx);
+      // the row of L~ travels like the row of the operand: requested at the end of a step, filed at the end of the next
+      qs_f4 cv = qs_f4{0.f, 0.f, 0.f, 0.f};
+      float cd = 0.f;
+      auto coef_fetch = [&](int yrow) __attribute__((always_inline)) {
+        const size_t sy = spread_y(yrow);
+        cfetch(reinterpret_cast<const char*>(a.gvals8) + sy * 32u, reinterpret_cast<const char*>(a.gdiag) + sy * 4u, coffv, coffd, cv, cd);
+      };
+      if (!sideQ) coef_fetch(ytop);
 
       auto step = [&](auto ph_c) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_c)::value;
         constexpr int L0 = PH % 3, L1 = (PH + 1) % 3, L2 = (PH + 2) % 3;
         const int cs1 = cs == 0 ? 2 : cs - 1, cs2 = cs1 == 0 ? 2 : cs1 - 1;  // slots of the rows ytop-1, ytop-2
-        qs_f4 cv;
-        float cd;
-        if (!sideQ) {
-          const size_t sy = spread_y(ytop);
-          cfetch(reinterpret_cast<const char*>(a.gvals8) + sy * 32u + coffv, reinterpret_cast<const char*>(a.gdiag) + sy * 4u + coffd, cv, cd);
-        }
         QRow A2;  // L~ S1 at row ytop-2
         // -------- the stencil units, in the order their sources become available ------------------------------------------
         C3 ca = crow(cs2, 0), cb = crow(cs2, 1);
@@ -232,55 +242,57 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
           if (u == 11) ca = crow(cs1, 2);
           if (u == 15) {
             cb = crow(cs2, 2);
-            // the row ytop of the operand: requested by the previous step (the first: before the loop)
-            if (sideQ) {
-              asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0[L2].t[0]), "+v"(S0[L2].t[1]), "+v"(S0[L2].t[2]), "+v"(S0[L2].t[3]) : : "memory");
-              const bool rowk = ytop >= st.y0 && ytop < st.y1;  // dy counts on the output pixels of this work item only
+            // The row ytop of the operand, requested by the previous step (the first: before the loop), is needed from here on.
+            // It arrives in `nx` and enters the rotation through this product: dy counts on the output pixels of this work
+            // item only (times the workgroup's sign), x everywhere.  (A row loaded straight into its place in the rotation
+            // was copied about by the compiler at the top of the step, each copy a wait for the row.)
+            const bool rowk = !sideQ || (ytop >= st.y0 && ytop < st.y1);
+            float one = sgn;
+            asm volatile("" : "+v"(one));  // (pins the products below to this place: they wait for the row)
 #pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                const float mk = (rowk && colk[t]) ? sgn : 0.f;  // (what is multiplied by 0 is dy inside the item too: the loads are clamped to it)
+            for (int t = 0; t < 4; ++t) {
+              const float mk = (rowk && colk[t]) ? one : 0.f;  // (what is multiplied by 0 is dy inside the item too: the loads are clamped to it)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) S0[L2].t[t][e] *= mk;
-              }
-            } else asm volatile("s_waitcnt vmcnt(2)" : "+v"(S0[L2].t[0]), "+v"(S0[L2].t[1]), "+v"(S0[L2].t[2]), "+v"(S0[L2].t[3]) : : "memory");
+              for (int e = 0; e < 4; ++e) S0[L2].t[t][e] = nx.t[t][e] * mk;
+            }
           }
           if (u == 19) qs_settle<1>(S1[L2]);
         };
         // -------- the matrix work on the row staged by the previous step, ten groups of six, the 24 units spread over them ---
-        qs_bf8 fa[2][2][2], fb[2][2];  // [buffer][f-group][hi | lo], [buffer][hi | lo]
+        qs_bf8 fa[2][2], fb[2][2];  // [f-group][hi | lo] of one P plane, [buffer][hi | lo] of two Q planes
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) fa[0][g][h] = frag(QW_P0, h, 2 * fh + g, 0);
+          for (int h = 0; h < 2; ++h) fa[g][h] = frag(QW_P0, h, 2 * fh + g, 0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) fb[0][h] = frag(QW_Q0, h, og, 0);
         auto group = [&](auto gi_c) __attribute__((always_inline)) {
           constexpr int gi = decltype(gi_c)::value, blk = gi / 5, g = gi % 5;
           constexpr int pair = g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 3 : g == 3 ? 2 : 4;
-          constexpr int ab = (2 * blk + (g >= 2 ? 1 : 0)) & 1;
           // b buffers by group: Q0 -> 0, Q1 -> 1, (Q1 stays), Q0 -> 0, Q2 -> 1
           constexpr int bb = (g == 0 || g == 3) ? 0 : 1;
-          // requests for what comes next
+          // requests for what comes next (the P plane has one set of registers: its successor is requested when the last
+          // instruction that reads it has been issued -- the data takes longer to arrive than that instruction to read)
           if (g == 0) { fb[1][0] = frag(QW_Q1, 0, og, blk); fb[1][1] = frag(QW_Q1, 1, og, blk); }
-          if (g == 1) {
+          if (g == 1) { fb[0][0] = frag(QW_Q0, 0, og, blk); fb[0][1] = frag(QW_Q0, 1, og, blk); }
+          if (g == 2) {
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
-              for (int h = 0; h < 2; ++h) fa[ab ^ 1][gg][h] = frag(QW_P2, h, 2 * fh + gg, blk);
-            fb[0][0] = frag(QW_Q0, 0, og, blk); fb[0][1] = frag(QW_Q0, 1, og, blk);
+              for (int h = 0; h < 2; ++h) fa[gg][h] = frag(QW_P2, h, 2 * fh + gg, blk);
           }
           if (g == 3) { fb[1][0] = frag(QW_Q2, 0, og, blk); fb[1][1] = frag(QW_Q2, 1, og, blk); }
-          if (g == 4 && blk == 0) {
+          if (g == 0 && blk == 1) {
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
-              for (int h = 0; h < 2; ++h) fa[ab ^ 1][gg][h] = frag(QW_P0, h, 2 * fh + gg, 1);
-            fb[0][0] = frag(QW_Q0, 0, og, 1); fb[0][1] = frag(QW_Q0, 1, og, 1);
+              for (int h = 0; h < 2; ++h) fa[gg][h] = frag(QW_P0, h, 2 * fh + gg, 1);
           }
+          if (g == 4 && blk == 0) { fb[0][0] = frag(QW_Q0, 0, og, 1); fb[0][1] = frag(QW_Q0, 1, og, 1); }
           // hi.lo, lo.hi, hi.hi; consecutive instructions go to different accumulators; two stencil units per five of them
           auto mf = [&](auto i_c) __attribute__((always_inline)) {
             constexpr int i = decltype(i_c)::value, j = i >> 1, fg = i & 1, m = gi * 6 + i;  // m = 0 .. 59
-            qs_m<false>(acc[pair][fg], fa[ab][fg][j == 1 ? 1 : 0], fb[bb][j == 0 ? 1 : 0]);
+            qs_m<false>(acc[pair][fg], fa[fg][j == 1 ? 1 : 0], fb[bb][j == 0 ? 1 : 0]);
             if constexpr (m % 5 == 1 || m % 5 == 3) unit(std::integral_constant<int, 2 * (m / 5) + (m % 5 == 3 ? 1 : 0)>{});
           };
           mf(std::integral_constant<int, 0>{}); mf(std::integral_constant<int, 1>{}); mf(std::integral_constant<int, 2>{});
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
         step_barrier();  // every wave has read the staged row
         // (the operands of the last group stay allocated until here: the compiler does not know the asm statements above are
         // matrix instructions, and a vector instruction that reuses an operand register right behind one corrupts it -- seen)
-        asm volatile("" : : "v"(fa[1][0][0]), "v"(fa[1][0][1]), "v"(fa[1][1][0]), "v"(fa[1][1][1]), "v"(fb[1][0]), "v"(fb[1][1]));
+        asm volatile("" : : "v"(fa[0][0]), "v"(fa[0][1]), "v"(fa[1][0]), "v"(fa[1][1]), "v"(fb[1][0]), "v"(fb[1][1]));
         if (!sideQ) {
           stage(QW_P0, S0[L0]);
           stage(QW_P2, S2);
@@ -308,11 +320,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
           stage(QW_Q1, S1[L1]);
           stage(QW_Q2, S2);
         }
-        row_fetch(ytop + 1, S0[L0]);  // (S0[L0] is the next step's S0[L2])
-        if (!sideQ) {
-          asm volatile("s_waitcnt vmcnt(4)" : "+v"(cv), "+v"(cd) : : "memory");
-          cstore(cs, cv, cd);
-        }
+        if (!sideQ) cstore(cs, cv, cd);  // (the row ytop of L~, requested a step ago)
+        row_fetch(ytop + 1, nx);
+        if (!sideQ) coef_fetch(ytop + 1);
         cs = cs == 2 ? 0 : cs + 1;
         ++ytop;
         step_barrier();
@@ -322,8 +332,6 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
         step(std::integral_constant<int, 1>{});
         step(std::integral_constant<int, 2>{});
       }
-      // (the request left in flight belongs to no row anyone reads: wait it out before the registers are reused)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0[2].t[0]), "+v"(S0[2].t[1]), "+v"(S0[2].t[2]), "+v"(S0[2].t[3]) : : "memory");
     }
   }
   // the accumulators: lane (n = lane & 15, mg = lane >> 4), element i <-> (f = 16 (2 fh + fg) + 4 mg + i, o = 16 og + n)

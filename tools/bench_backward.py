@@ -50,6 +50,8 @@ fwd = float(np.mean([a.elapsed_time(b) for a, b, _ in evs]))
 bwd = float(np.mean([b.elapsed_time(c) for _, b, c in evs]))
 print(json.dumps({"config": cfg, "workload": f"nside={nside} K={K} Fin={Fin} Fout={Fout} batch={N}", "steps": steps,
                   "forward_ms": round(fwd, 3), "backward_ms": round(bwd, 3), "fwd_bwd_ms": round(fwd + bwd, 3),
-                  "note": "dx: fused forward kernel on dy (transposed plan, re-indexed weights; contraction 3xbf16); "
-                          "dkernel: dsph_cheb_backward_weights = fused tile kernel in weight-gradient mode "
-                          "(planes stay in LDS, exact-fp32 MFMA against dy, fixed-order slab reduction)"}))
+                  "note": "dx: the fused forward kernels on dy (transposed plan, re-indexed weights); dkernel: "
+                          "dsph_cheb_backward_weights -- K = 5, 64 -> 64 j on a symmetric L~ in the three-term bf16 arithmetic: the "
+                          "strips' pixels on the quad-strip weight-gradient kernel (cheb_qwgrad_kernel.h), the other tiles on the "
+                          "BFS-tile kernel's weight-gradient mode; otherwise that mode on every tile (planes stay in LDS, fixed-order "
+                          "sums of per-workgroup slabs)"}))

@@ -146,6 +146,10 @@ int main(int argc, char** argv) {
     run({1024, 4, 16, 1 << 30, true}, false, argc > 2 ? atoi(argv[2]) : 5);
     return 0;
   }
+  if (argc > 1 && atoi(argv[1]) == 3) {  // (the full-chip timing alone: eight maps)
+    run({1024, 8, 16, 1 << 30, true}, false, 3);
+    return 0;
+  }
   run({128, 2, 16, 1 << 30, true}, true, 0);
   run({128, 1, 16, 40, false}, true, 0);
   run({128, 1, 16, 40, true}, true, 0);
