@@ -320,7 +320,16 @@ int dsph_cheb_planes(const dsph_plan* plan, const float* x, float* planes, int64
  * is contracted over its pixels against dy -- `precision` DSPH_PREC_FP32: exact-fp32 MFMAs; DSPH_PREC_BF16X3: both
  * operands split hi + lo, three bf16 MFMAs per product term, fp32 accumulate (fused path only) -- and the
  * per-workgroup partial sums are reduced in a fixed order (deterministic).  Otherwise: dsph_cheb_planes into `workspace`, then
- * dsph_cheb_wgrad.  `algo` as in dsph_cheb_forward. */
+ * dsph_cheb_wgrad.  `algo` as in dsph_cheb_forward.
+ * K = 5, Fin = 64, Fout a multiple of 64, DSPH_PREC_BF16X3, on a whole-graph plan whose forward of that shape runs on the quad
+ * strips and whose matrix equals its transpose (checked entry for entry, to fp32 rounding): the strips' pixels go through the
+ * quad-strip weight-gradient kernel (csrc/cheb_qwgrad_kernel.h: the recurrence to order two on x AND on dy, orders 3 and 4 from
+ * the product rule of the polynomials), the other tiles through the tile kernel; same result to the arithmetic's rounding
+ * (measured 4 - 7e-6 of max |dw| against float64), 2.2 x faster at BASELINE configs[2].  A non-symmetric matrix, another shape
+ * or DSPH_PREC_FP32 keep every tile on the tile kernel.
+ * In the bf16 arithmetic every second workgroup of both kernels contracts against -dy and its partial sum is subtracted: the
+ * matrix pipe's fp32 accumulation of long sums is biased towards minus infinity (1 - 2e-5 of max |dw| at configs[2]) and the
+ * mirror cancels it. */
 size_t dsph_backward_weights_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout,
                                              int32_t K, int32_t algo);
 int dsph_cheb_backward_weights(const dsph_plan* plan, const float* x, const float* dy, float* dw, int64_t N,

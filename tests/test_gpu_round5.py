@@ -367,3 +367,27 @@ def test_quad_strip_weight_gradient_at_the_benchmarked_size():
                                                 workspace=ws)
         parts += one
     assert float((parts - dw).abs().max()) / scale < TOL_QWGRAD
+
+
+def test_quad_strip_weight_gradient_partial_sky():
+    """A cap of the sphere (bench.build_laplacian_masked at nside 256, BASELINE configs[4]'s kind of map): ragged rectangles,
+    strips of every width, a third of the tiles left to the BFS-tile kernel -- dW of the whole masked map against the oracle."""
+    import bench
+
+    nside, K, Fin, Fout, N = 256, 5, 64, 64, 2
+    cols, vals, _ = bench.build_laplacian_masked(nside, torch.device("cuda", 0))
+    M = cols.shape[0]
+    Lc = _csr(cols, vals)
+    assert abs(Lc - Lc.T).max() <= 1e-7
+    plan = _plan(cols, vals, K, Fin, {_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
+    n_struct, n_bfs = plan.tile_counts(K)
+    n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
+    assert 0 < n_strip < n_struct
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    dy = rng.standard_normal((N, M, Fout)).astype(np.float32)
+    ref = np.einsum("knmf,nmo->fko", orc.chebyshev_planes(Lc, x, K), dy.astype(np.float64)).reshape(Fin * K, Fout)
+    dw, _ = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, algo=_native.ALGO_FUSED, precision=_native.PREC_BF16X3)
+    err = rel_err(dw.cpu().numpy(), ref)
+    print(f"quad-strip dW on a cap at nside {nside} ({M} pixels, {n_strip} strip tiles, {n_struct - n_strip} + {n_bfs} others): rel err {err:.2e}")
+    assert err < TOL_QWGRAD
