@@ -94,7 +94,7 @@ for it in range(cases):
             raise
     loose = 5.0 if act == _native.ACT_TANH else 1.0
     t_exact, t_x3 = 2e-6 * loose, (1e-5 if Fin >= 16 else 2e-5) * loose * (2.0 if K > 9 else 1.0)
-    ok = e1 < t_exact and e6 < t_exact and e2 < t_x3 and same and e3 < 2e-5 and e4 < 1e-4
+    ok = e1 < t_exact and e6 < t_exact and e2 < t_x3 and same and e3 < 2e-5 and e4 < (2e-5 if Fin >= 16 else 1e-4)  # (dW in the three-term split: DESIGN 4.1)
     n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3)
     with_strips += n_strip > 0
     bad += not ok
