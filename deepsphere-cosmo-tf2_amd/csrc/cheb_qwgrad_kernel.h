@@ -28,6 +28,9 @@
 //   read's lane groups want contiguous 1 KiB fragments, which would put the four k-groups of a store on the same banks).  The inner index of a 32-pixel block is k = 4 (p & 7) + tile, the same on both operands.
 // Matrix work: wave (og = w & 3, fh = w >> 2) owns the output tiles (pair, f-group 2 fh + {0, 1}, o-group og): ten 16 x 16
 //   accumulators (40 registers) that live for the whole kernel; three terms per product (hi.hi + hi.lo + lo.hi).
+// (Tried: P0, Q0, Q1 of a row exist when the step begins; staged among the step's matrix instructions into a second set of
+//   buffers (154 KiB) they leave one plane per side behind the barrier -- 3.90 us per step against 3.81: the stores and the
+//   fragment reads share the LDS, and the LDS is what the step waits for.  Not kept.)
 // Output: one slab [5][64][64] per workgroup (of every second workgroup: the slab of -dy, see `sgn`); qwgrad_reduce_kernel adds
 //   the slabs in a fixed order and applies the rule above.
 #pragma once
