@@ -213,6 +213,38 @@ def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1, split="auto"):
     return " + ".join(parts)
 
 
+def training_step_leg(cols, vals, K, lmax, Fout, device, args, plan_options, w_np, x, steps):
+    """Forward + backward of the layer (no bias, no activation) on the bench's input: ms by HIP events, split at the backward."""
+    from deepsphere import gnn_layers
+
+    layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, lmax=lmax, Fout=Fout, device=device, precision=args.precision,
+                                                   algo=args.algo, initializer=lambda t: t.copy_(torch.from_numpy(w_np)),
+                                                   plan_options=plan_options)
+    xg = x.detach().requires_grad_(True)
+    dy = torch.randn((x.shape[0], x.shape[1], Fout), device=device)
+
+    def one():
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        y = layer(xg)
+        e[1].record()
+        y.backward(dy)
+        e[2].record()
+        xg.grad = None
+        layer.kernel.grad = None
+        return e
+
+    for _ in range(2):
+        one()
+    evs = [one() for _ in range(steps)]
+    torch.cuda.synchronize()
+    fwd = float(np.mean([a.elapsed_time(b) for a, b, _ in evs]))
+    bwd = float(np.mean([b.elapsed_time(c) for _, b, c in evs]))
+    return {"forward_ms": round(fwd, 3), "backward_ms": round(bwd, 3), "ms_per_step": round(fwd + bwd, 3), "steps": steps,
+            "note": "autograd of the layer: dx = the forward kernels on dy, dkernel = dsph_cheb_backward_weights at the layer's "
+                    "weight-gradient precision (three-term bf16 from 49,152 pixels up, exact fp32 below)"}
+
+
 def timed_ms(run, steps, warm=3):
     """Mean HIP-event time of `steps` forwards on the current stream, after `warm` untimed ones."""
     for _ in range(warm):
@@ -565,6 +597,13 @@ def main():
             layer.bias = torch.nn.Parameter(torch.randn(1, 1, Fout, device=device))
             layer.activation, layer._act_code = gnn_layers._resolve_activation("relu")
             out["bias_relu"] = {"ms_per_step": round(timed_ms(run, max(args.steps, 20)), 4)}
+        if world == 1 and not args.quick:
+            # SURVEY 8 (f1), for the record: the layer's training step through autograd -- dx on the forward kernels, dkernel by
+            # dsph_cheb_backward_weights (K = 5, 64 -> 64 j: the quad-strip weight-gradient kernel) -- HIP events, not the metric
+            try:
+                out["training_step"] = training_step_leg(cols, vals, K, lmax, Fout, device, args, plan_options, w_np, x, max(3, min(args.steps, 10)))
+            except Exception as exc:  # noqa: BLE001  (a side leg must not take the headline down: out of memory on a small box)
+                out["training_step"] = {"error": repr(exc)[:200]}
         if world == 1 and args.cpu_budget > 0 and not args.quick:
             out["cpu_baseline"] = cpu_baseline(K, Fin, Fout, device, args.cpu_budget)
         print(json.dumps(out), flush=True)
