@@ -645,7 +645,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
               // Every second workgroup contracts against -dy and hands in -dW (fused_wgrad_reduce_kernel subtracts its slabs):
               // what the matrix pipe drops when it aligns 32 products to an accumulator hundreds of times their size is dropped
               // towards minus infinity -- at BASELINE configs[2] every element of dW came out low by the same 1.3e-5 of max |dW|
-              // whatever its sign (tools/check_dw_c3.py).  A bias that ignores the data's sign cancels against the mirror.
+              // whatever its sign (tests/diag_dw_by_order.py).  A bias that ignores the data's sign cancels against the mirror.
               const float sg = (blockIdx.x & 1) ? -1.f : 1.f;
               const float v8[8] = {sg * dyv[8 * st], sg * dyv[8 * st + 1], sg * dyv[8 * st + 2], sg * dyv[8 * st + 3],
                                    sg * dyv[8 * st + 4], sg * dyv[8 * st + 5], sg * dyv[8 * st + 6], sg * dyv[8 * st + 7]};

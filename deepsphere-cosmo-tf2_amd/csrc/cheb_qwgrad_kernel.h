@@ -85,7 +85,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
   float* __restrict__ slab = a.slabs + (size_t)blockIdx.x * QW_SLAB;
   // Every second workgroup runs on -dy and hands in -G (qwgrad_reduce_kernel subtracts its slab).  Why: the matrix pipe adds
   // the 32 products of an instruction to an accumulator hundreds of times their size, and what it drops when it aligns them
-  // is dropped towards minus infinity -- measured at the headline size (tools/check_dw_c3.py): every element of dW low by the
+  // is dropped towards minus infinity -- measured at the headline size (tests/diag_dw_by_order.py): every element of dW low by the
   // same 2e-5 of max |dW| whatever its sign, growing with the length of the sum (the same in the BFS-tile kernel's bf16 mode).
   // A bias that does not depend on the sign of the data cancels between a workgroup and its mirror.
   const float sgn = (sideQ && (ord & 1)) ? -1.f : 1.f;

@@ -104,7 +104,9 @@ int dsph_plan_set_levels(dsph_plan* plan, int32_t n_levels, const int64_t* rows_
  * instead of inside the first forward: the direction-ordered copy of L~ and the per-row / per-tile verification
  * of the 2-D stencil structure (structured-tile kernel), and the breadth-first ring tables of the remaining
  * tiles (BFS-tile kernel).  Allocates device memory, launches set-up kernels and synchronises.
- *   flags  DSPH_PREPARE_BACKWARD      also the tables of dsph_cheb_planes / dsph_cheb_backward_weights
+ *   flags  DSPH_PREPARE_BACKWARD      also the tables of dsph_cheb_planes / dsph_cheb_backward_weights, and the look at the
+ *                                     matrix that dsph_cheb_backward_weights otherwise takes on its first call (is it
+ *                                     symmetric: one host pass over the ELL arrays, about a second at 12.6 M rows)
  *          DSPH_PREPARE_RELEASE_HOST  afterwards drop the plan's host copy of the ELL arrays (kept by
  *                                     dsph_plan_create to build tables for further K); preparing another K
  *                                     later then fails with DSPH_E_UNSUPPORTED and forwards with that K take

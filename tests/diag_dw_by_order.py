@@ -1,5 +1,7 @@
-"""Diagnostic (GPU box): rows of dW at a large size against the float64 oracle, by order k, for the three weight-gradient routes.
-    python tools/check_dw_c3.py [nside] [N]
+"""Diagnostic, not a test (pytest does not collect it; it lives here because it checks against oracle/): rows of dW at a large
+size against the float64 oracle, by order k, for the three weight-gradient routes -- max and mean SIGNED error, which is how the
+matrix pipe's accumulation bias was found (profiles/r5_dw_error_by_order.txt).
+    python tests/diag_dw_by_order.py [nside] [N]
 """
 import os
 import sys
@@ -9,7 +11,6 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "deepsphere-cosmo-tf2_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import bench  # noqa: E402
 from deepsphere import _native  # noqa: E402
 from oracle import cheb_oracle as orc  # noqa: E402
