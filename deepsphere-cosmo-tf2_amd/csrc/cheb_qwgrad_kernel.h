@@ -25,7 +25,8 @@
 //   with 272-byte k-groups and 1,216-byte blocks: the writers' ds_write_b64 (lane = (pixel group p, channel group q4); groups of
 //   16 lanes, banks of a store = address / 4 mod 32) are conflict-free; the readers' ds_read_b128 (lane = (channel m, k-group):
 //   an A or B operand of v_mfma_f32_16x16x32_bf16 as it stands) pay one two-way conflict per instruction for the padding (the
-//   read's lane groups want contiguous 1 KiB fragments, which would put the four k-groups of a store on the same banks).  The inner index of a 32-pixel block is k = 4 (p & 7) + tile, the same on both operands.
+//   read's lane groups want contiguous 1 KiB fragments, which would put the four k-groups of a store on the same banks).
+//   The inner index of a 32-pixel block is k = 4 (p & 7) + tile, the same on both operands.
 // Matrix work: wave (og = w & 3, fh = w >> 2) owns the output tiles (pair, f-group 2 fh + {0, 1}, o-group og): ten 16 x 16
 //   accumulators (40 registers) that live for the whole kernel; three terms per product (hi.hi + hi.lo + lo.hi).
 // (Tried: P0, Q0, Q1 of a row exist when the step begins; staged among the step's matrix instructions into a second set of
