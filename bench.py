@@ -597,7 +597,7 @@ def main():
             layer.bias = torch.nn.Parameter(torch.randn(1, 1, Fout, device=device))
             layer.activation, layer._act_code = gnn_layers._resolve_activation("relu")
             out["bias_relu"] = {"ms_per_step": round(timed_ms(run, max(args.steps, 20)), 4)}
-        if world == 1 and not args.quick:
+        if world == 1 and not args.quick and K <= 5:  # (K > 5: the weight gradient goes through planes in memory: tens of GB at c4)
             # SURVEY 8 (f1), for the record: the layer's training step through autograd -- dx on the forward kernels, dkernel by
             # dsph_cheb_backward_weights (K = 5, 64 -> 64 j: the quad-strip weight-gradient kernel) -- HIP events, not the metric
             try:
