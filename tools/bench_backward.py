@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Forward + backward of the layer at a benchmark config (SURVEY 8 f1 measurement).
 
-    python tools/bench_backward.py [c3|c2] [steps] [bf16x3|bf16x6|fp32]
+    python tools/bench_backward.py [c3|c2|c5|...] [steps] [bf16x3|bf16x6|fp32]
 Prints one JSON line: ms per forward+backward step (HIP events), and its split."""
 import json
 import os
@@ -20,7 +20,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 nside, K, Fin, Fout, N = bench.CONFIGS[cfg]
 dev = torch.device("cuda", 0)
-cols, vals, lmax = bench.build_laplacian(nside, dev)
+cols, vals, lmax = bench.build_laplacian_masked(nside, dev) if cfg in bench.MASKED else bench.build_laplacian(nside, dev)
 M = cols.shape[0]
 w_np = (np.random.default_rng(13).standard_normal((Fin * K, Fout)) / np.sqrt(Fin * (K + 0.5) / 2)).astype(np.float32)
 prec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
