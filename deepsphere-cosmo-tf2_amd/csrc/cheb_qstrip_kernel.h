@@ -311,17 +311,17 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       for (int i = 0; i < XN; ++i) xv[i] = qs_f4{0.f, 0.f, 0.f, 0.f};
       return;
     }
+    // (plain loads: the compiler knows the data is in flight, keeps the registers out of other use and counts vmcnt itself;
+    // the asm statements around them keep the requests where they are written -- see cheb_qwgrad_kernel.h for what loads
+    // inside asm statements did there)
     const char* src = xmap + (size_t)((sXf | sY) * xrowb + x_goff);
-    if (X_BY_H)
-      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
-                   "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
-                   : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[XN - 2]), "=&v"(xv[XN - 1]) : "v"(src) : "memory");
-    else
-      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:128" : "=&v"(xv[0]), "=&v"(xv[1]) : "v"(src) : "memory");
+#pragma unroll
+    for (int i = 0; i < XN; ++i) xv[i] = *reinterpret_cast<const qs_f4*>(src + (X_BY_H ? 64 : 128) * i);
   };
+  // the point where the row is needed: the compiler waits for it here, not earlier (everything below depends on this statement)
   auto xw_wait = [&](qs_f4 (&xv)[XN]) __attribute__((always_inline)) {
-    if (X_BY_H) asm volatile("s_waitcnt vmcnt(0)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[XN - 2]), "+v"(xv[XN - 1]) : : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xv[0]), "+v"(xv[1]) : : "memory");
+    if (X_BY_H) asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[XN - 2]), "+v"(xv[XN - 1]) : : "memory");
+    else asm volatile("" : "+v"(xv[0]), "+v"(xv[1]) : : "memory");
   };
   auto xstore = [&](int slot, const qs_f4 (&xv)[XN]) __attribute__((always_inline)) {
     if (QS_ABL & 4096) {
@@ -365,10 +365,11 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   auto cfetch = [&](unsigned rid, qs_f4& cv, float& cd) __attribute__((always_inline)) {
     const char* pv = reinterpret_cast<const char*>(a.gvals8) + (size_t)rid * 32u + (unsigned)(q4 & 1) * 16u;
     const char* pd = reinterpret_cast<const char*>(a.gdiag) + (size_t)rid * 4u;
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(cv), "=&v"(cd) : "v"(pv), "v"(pd) : "memory");
+    cv = *reinterpret_cast<const qs_f4*>(pv);
+    cd = *reinterpret_cast<const float*>(pd);
   };
   auto cw_wait = [&](qs_f4& cv, float& cd) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cv), "+v"(cd) : : "memory");
+    asm volatile("" : "+v"(cv), "+v"(cd) : : "memory");
   };
   // ring row: vector v = 0 the diagonal, v = 1 + d direction d (W NW N NE E SE S SW), each [p][tile] -- what a lane reads is
   // the 16 bytes of its four pixels of one direction
