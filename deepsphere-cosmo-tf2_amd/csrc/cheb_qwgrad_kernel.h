@@ -21,11 +21,11 @@
 // Step with top row t:  S0[t] arrives (global -> registers, requested a step ahead), S1[t-1] = L~ S0, S2[t-2] = 2 L~ S1 - S0
 //   (12 + 12 stencil units), while the matrix pipe contracts the row staged by the previous step; barrier; the planes of row
 //   t-2 are split hi + lo into bf16 and staged; barrier.
-// Staging (5 plane rows x 19,456 B): [plane][hi | lo][16-channel group][32-pixel block][k-group kg][channel m][8 pixels x 2 B]
-//   with 272-byte k-groups and 1,216-byte blocks: the writers' ds_write_b64 (lane = (pixel group p, channel group q4); groups of
-//   16 lanes, banks of a store = address / 4 mod 32) are conflict-free; the readers' ds_read_b128 (lane = (channel m, k-group):
-//   an A or B operand of v_mfma_f32_16x16x32_bf16 as it stands) pay one two-way conflict per instruction for the padding (the
-//   read's lane groups want contiguous 1 KiB fragments, which would put the four k-groups of a store on the same banks).
+// Staging (5 plane rows x 16,640 B): [plane][hi | lo][16-channel group][32-pixel block][k-group kg][chunk][8 pixels x 2 B],
+//   the 16-byte chunk of channel m in k-group kg at chunk index m ^ 2 kg (256-byte k-groups, 1,040-byte blocks): the writers'
+//   ds_write2_b64 (lane = (pixel group p, channel group q4)) and the readers' ds_read_b128 (lane = (channel m, k-group): an A or
+//   B operand of v_mfma_f32_16x16x32_bf16 as it stands) are both free of bank conflicts -- see `rd_off` / `wr_a` below.  (The
+//   first layout padded the k-groups to 272 bytes instead: a third of the LDS cycles were conflicts, profiles/r5_qwgrad_pmc.json.)
 //   The inner index of a 32-pixel block is k = 4 (p & 7) + tile, the same on both operands.
 // Matrix work: wave (og = w & 3, fh = w >> 2) owns the output tiles (pair, f-group 2 fh + {0, 1}, o-group og): ten 16 x 16
 //   accumulators (40 registers) that live for the whole kernel; three terms per product (hi.hi + hi.lo + lo.hi).
@@ -40,11 +40,13 @@
 
 namespace dsph {
 
-constexpr int QW_SK = 272;               // bytes of one k-group: 16 channels x 16 B, + 16
-#ifdef DSPH_QW_SB
-constexpr int QW_SB = DSPH_QW_SB;        // (tuning)
+#ifdef DSPH_QW_PAD  // (tuning: the padded layout this kernel started with: 272-byte k-groups, 1,216-byte blocks, no swizzle)
+constexpr bool QW_SWZ = false;
+constexpr int QW_SK = 272, QW_SB = 1216;
 #else
-constexpr int QW_SB = 1216;              // one 32-pixel block of a 16-channel group: 4 k-groups, + 128 (= 64 mod 128)
+constexpr bool QW_SWZ = true;
+constexpr int QW_SK = 256;               // bytes of one k-group: 16 channels x 16 B
+constexpr int QW_SB = 1040;              // one 32-pixel block of a 16-channel group: 4 k-groups, + 16
 #endif
 constexpr int QW_CG = 2 * QW_SB;         // a 16-channel group: two blocks
 constexpr int QW_HL = 4 * QW_CG;         // hi or lo of a plane row
@@ -118,8 +120,17 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
   const int64_t srows = sideQ ? a.dy_rows : a.x_rows;
   const char* sbase = reinterpret_cast<const char*>(sideQ ? a.dy : a.x);
   // staging: where this lane writes (per plane, hi | lo, channel cc: + cc 16) and reads (per plane, hi | lo, group, block)
-  const unsigned wr_off = (unsigned)cq * QW_CG + (unsigned)(p >> 3) * QW_SB + (unsigned)((p >> 1) & 3) * QW_SK + (unsigned)(4 * q4) * 16u + (unsigned)(p & 1) * 8u;
-  const unsigned rd_off = (unsigned)(lane >> 4) * QW_SK + (unsigned)(lane & 15) * 16u;
+  // Swizzle: the 16-byte chunk of channel m in k-group kg sits at chunk index m ^ 2 kg.  A reader's lane groups (ds_read_b128:
+  // {0-3, 12-15, 20-27}, ...) then still cover sixteen different chunks of 256 bytes, and the four k-groups a store's lane group
+  // touches (ds_write2_b64: eight lanes = four k-groups x two halves, two chunks each) fall on four different 32-byte blocks of
+  // the 128 bytes a store's banks span: no conflicts on either side with contiguous 1 KiB fragments (counters of the padded
+  // layout: a third of the LDS cycles were conflicts, profiles/r5_qwgrad_pmc.json).
+  const int kgw = (p >> 1) & 3;  // k-group this lane writes
+  const unsigned wr_com = (unsigned)cq * QW_CG + (unsigned)(p >> 3) * QW_SB + (unsigned)kgw * QW_SK + (unsigned)(p & 1) * 8u +
+                          (unsigned)(4 * (QW_SWZ ? (q4 ^ (kgw >> 1)) : q4)) * 16u;
+  // channels 4 q4 + {0, 1} go to wr_a (+ 0, + 16), channels 4 q4 + {2, 3} to wr_b: swapped in the odd k-groups (cc ^ 2 (kg & 1))
+  const unsigned wr_a = wr_com + ((QW_SWZ && (kgw & 1)) ? 32u : 0u), wr_b = wr_com + ((QW_SWZ && (kgw & 1)) ? 0u : 32u);
+  const unsigned rd_off = (unsigned)(lane >> 4) * QW_SK + (unsigned)((lane & 15) ^ (QW_SWZ ? 2 * (lane >> 4) : 0)) * 16u;
 
   // ---- L~ (waves 0..3): the row's values of the pixels 4 p + cq, filed as cheb_qstrip_kernel.h files them ---------------
   auto cfetch = [&](const char* gv, const char* gd, unsigned offv, unsigned offd, qs_f4& cv, float& cd) __attribute__((always_inline)) {
@@ -152,9 +163,11 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   auto stage = [&](int plane, const QRow& R) __attribute__((always_inline)) {
     if (QS_ABL & 8192) { asm volatile("" : : "v"(R.t[0]), "v"(R.t[1]), "v"(R.t[2]), "v"(R.t[3])); return; }  // (tuning builds: QS_ABL)
-    unsigned char* q = smem + (unsigned)plane * QW_PLANE + wr_off;
+    unsigned char* qa = smem + (unsigned)plane * QW_PLANE + wr_a;
+    unsigned char* qb = smem + (unsigned)plane * QW_PLANE + wr_b;
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
+      unsigned char* q = (cc < 2 ? qa : qb) + (cc & 1) * 16;
       qs_u2 hi, lo;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -166,8 +179,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
         hi[j] = hu;
         lo[j] = __builtin_bit_cast(unsigned, l);
       }
-      *reinterpret_cast<qs_u2*>(q + cc * 16) = hi;
-      *reinterpret_cast<qs_u2*>(q + cc * 16 + QW_HL) = lo;
+      *reinterpret_cast<qs_u2*>(q) = hi;
+      *reinterpret_cast<qs_u2*>(q + QW_HL) = lo;
     }
   };
   auto frag = [&](int plane, int hl, int cg, int blk) __attribute__((always_inline)) -> qs_bf8 {
