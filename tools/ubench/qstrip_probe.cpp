@@ -77,7 +77,7 @@ static double run(const Case& c, bool check, int reps) {
   L.prefix = d_p; L.tape_rows = prefix.back();
   L.x = d_x; L.w = d_w; L.bias = d_b; L.y = d_y; L.wimg = d_img; L.strips = d_s; L.gvals8 = d_g8; L.gdiag = d_gd;
   L.x_rows = (int64_t)M; L.y_rows = (int64_t)M; L.N = N; L.nstrips = (int)strips.size(); L.Fin = F; L.Fout = F; L.act = DSPH_ACT_RELU;
-  L.ld = F; L.num_cu = 256; L.cheb = c.cheb; L.f16 = c.f16; L.prep_weights = true;
+  L.ld = F; L.num_cu = getenv("QS_NUM_CU") ? atoi(getenv("QS_NUM_CU")) : 256;  // (tuning: fewer workgroups than CUs) L.cheb = c.cheb; L.f16 = c.f16; L.prep_weights = true;
   if (launch_cheb_qstrip(L, nullptr) != DSPH_OK) exit(1);
   CK(hipDeviceSynchronize());
   double ms = 0;
@@ -96,7 +96,7 @@ static double run(const Case& c, bool check, int reps) {
     int64_t px = 0;
     for (const QStrip& s : strips) px += (int64_t)(s.y1 - s.y0) * s.w;
     int grid, pieces, wpp;
-    const int64_t span = qstrip_split(256, L.tape_rows, N, L.tape_rows / (int64_t)strips.size(), &grid, &pieces, &wpp);
+    const int64_t span = qstrip_split(L.num_cu, L.tape_rows, N, L.tape_rows / (int64_t)strips.size(), &grid, &pieces, &wpp);
     printf("S %d N %d: %zu strips, tape of %lld rows in %d pieces x %d workgroups (grid %d), about %lld steps each: %.3f ms per launch = %.3f us per step; %.1f Mpix-maps/s, "
            "%.1f GB/s of x + y\n", S, N, strips.size(), (long long)L.tape_rows, pieces, wpp, grid, (long long)span, ms, ms * 1e3 / span, px * N / ms * 1e-3,
            px * N * 512.0 / ms * 1e-6);
