@@ -77,7 +77,7 @@ static double run(const Case& c, bool check, int reps) {
   L.prefix = d_p; L.tape_rows = prefix.back();
   L.x = d_x; L.w = d_w; L.bias = d_b; L.y = d_y; L.wimg = d_img; L.strips = d_s; L.gvals8 = d_g8; L.gdiag = d_gd;
   L.x_rows = (int64_t)M; L.y_rows = (int64_t)M; L.N = N; L.nstrips = (int)strips.size(); L.Fin = F; L.Fout = F; L.act = DSPH_ACT_RELU;
-  L.ld = F; L.num_cu = getenv("QS_NUM_CU") ? atoi(getenv("QS_NUM_CU")) : 256;  // (tuning: fewer workgroups than CUs) L.cheb = c.cheb; L.f16 = c.f16; L.prep_weights = true;
+  L.ld = F; L.num_cu = getenv("QS_NUM_CU") ? atoi(getenv("QS_NUM_CU")) : 256; /* (tuning: fewer workgroups than CUs) */ L.cheb = c.cheb; L.f16 = c.f16; L.prep_weights = true;
   // (tuning: QS_ALIAS=1: every map reads map 0's x and writes map 0's y -- the same instructions and the same data toggling with
   // an eighth of the memory traffic; QS_ZERO=1: x = 0 -- the same instructions and traffic, no toggling in the x operands)
   if (getenv("QS_ALIAS")) { L.x_rows = 0; L.y_rows = 0; }
