@@ -19,7 +19,8 @@
 // Work split (one workgroup = one strip = eight waves, waves w and w + 4 share a SIMD):
 //   wave = (role H | L) x (output-channel quarter oq).  H: levels 4, 3, 2; L: levels 1, 0 one step later, b2 and the dying b3
 //   row crossing through LDS under a counter as in the strip kernel.  Every wave keeps the weights of its levels and quarter
-//   in registers (H 48, L 32 VGPRs).
+//   in registers.  In the Chebyshev basis the matrix instructions of level 1 run on H as well (`H1` in the kernel: z_1 rides
+//   the b3 row of the hand-over), which leaves L one chain of matrix instructions and H four (H 64, L 16 VGPRs of weights).
 // Work items: the rows of all strips laid end to end form one tape per map; it is cut into P equal pieces (a piece = a few runs
 //   of rows of consecutive strips, each run with its own 9 run-in steps), and w workgroups share a piece, workgroup j of them
 //   taking the maps j, j + w, ... -- for a batch of N <= G maps w = N and P = G / N: every workgroup gets the same number of
@@ -232,9 +233,11 @@ __host__ __device__ constexpr float qs_wsign(bool cheb, int j) { return cheb && 
 template <bool CHEB, bool F16>
 __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs a) {
   constexpr int K = 5, D = QS_D, RING = K + 2;
-  // H1: half of level 1's matrix work (channel block 0 of z_1) runs on the H wave, which otherwise reaches the step's barrier a
-  // fifth of a step before its L partner (stamps in profiles/r5_qstrip_probe.txt): it adds it to the dying b3 row it hands over,
-  // from which L starts b1 anyway.  Chebyshev basis only (the monomial recurrence hands no b3 row over).
+  // H1: level 1's matrix work (z_1 = x W_1) runs on the H wave, which otherwise reaches the step's barrier a fifth of a step
+  // before its L partner (stamps in profiles/r5_qstrip_probe.txt): H adds z_1 to the dying b3 row it hands over, from which L
+  // starts b1 anyway (b1 = z_1 + 2 L~ b2 - b3), with L's own weights of that level (same sign convention).  To make room for them
+  // H asks for the next row of x behind slot s1 instead of at the top of the step.  3.36 us per step against 3.47 (probe, same
+  // lease; half of z_1: 3.44).  Chebyshev basis only: the monomial recurrence hands no b3 row over.
 #ifdef DSPH_QS_NOH1
   constexpr bool H1 = false;
 #else
@@ -430,11 +433,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
 // (fr[0] holds set 0 on entry -- QS_FR0, issued in the tail of the chain before or at the top of the step; the units fall to
 // MFMAs 0 .. 17; TAIL runs behind MFMA 17, when the units' coefficients and fr[0] are dead: the next slot's requests go out
 // under the last six MFMAs)
-// QS_SETSX: the sets S0 .. S1-1; the fragments of set s + 1 are requested while set s runs if s + 1 < SL; the NU units fall to
-// the MFMAs MB .. MB + MN - 1 (numbered over the whole chain of four sets)
-#define QS_SETSX(S0, S1, SL, MB, MN, ROW, ZERO, WLEV, FADDR, NU, ...)                                                     \
+#define QS_SETS(S0, S1, ROW, ZERO, WLEV, FADDR, NU, ...)                                                                  \
   _Pragma("unroll") for (int s = (S0); s < (S1); ++s) { /* set s = (block kb = s >> 1, pair tp = s & 1) */                \
-    if (s + 1 < (SL)) {                                                                                                   \
+    if (s + 1 < 4) {                                                                                                      \
       _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                     \
         const unsigned fo = (unsigned)(((s + 1) >> 1) * 8 + ((s + 1) & 1) * 2 + u) * QS_FRAG;                             \
         fr[(s + 1) & 1][u][0] = QS_FRLOAD(smem + (FADDR) + fo);                                                           \
@@ -443,22 +444,15 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
     }                                                                                                                     \
     _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                       \
       _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                     \
-        const int m = (s * 3 + j) * 2 + u - (MB);                                                                         \
+        const int m = (s * 3 + j) * 2 + u;                                                                                \
         const int tt = (s & 1) * 2 + u;                                                                                   \
         const qs_bf8& wa_ = wr[WLEV][s >> 1][QS_ORD_A(j)];                                                                \
         const qs_bf8& bb_ = fr[s & 1][u][QS_ORD_B(j)];                                                                    \
         if ((ZERO) && s < 2 && j == 0) qs_m0<F16>((ROW).t[tt], wa_, bb_);                                                 \
         else qs_m<F16>((ROW).t[tt], wa_, bb_);                                                                            \
-        _Pragma("unroll") for (int qq = (m * (NU)) / (MN); qq < ((m + 1) * (NU)) / (MN) && m < (MN); ++qq) { __VA_ARGS__; } \
+        _Pragma("unroll") for (int qq = (m * (NU)) / 18; qq < ((m + 1) * (NU)) / 18 && m < 18; ++qq) { __VA_ARGS__; }     \
       }                                                                                                                   \
     }                                                                                                                     \
-  }
-#define QS_SETS(S0, S1, ROW, ZERO, WLEV, FADDR, NU, ...) QS_SETSX(S0, S1, 4, 0, 18, ROW, ZERO, WLEV, FADDR, NU, __VA_ARGS__)
-// the fragments of set 2 (channel block 1, first tile pair) into fr[0]: the entry of a chain that runs the sets 2 and 3 only
-#define QS_FR2(FADDR)                                                                                                     \
-  _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                         \
-    fr[0][u][0] = QS_FRLOAD(smem + (FADDR) + (unsigned)(8 + u) * QS_FRAG);                                                \
-    fr[0][u][1] = QS_FRLOAD(smem + (FADDR) + (unsigned)(12 + u) * QS_FRAG);                                               \
   }
 #define QS_CHAIN(ROW, ZERO, WLEV, FADDR, NU, TAIL, ...)                                                                   \
   {                                                                                                                       \
@@ -473,12 +467,13 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
     // =================================================================================================================
     // H: levels 4, 3, 2.  R[0] = b4 rows, R[1] = b3 rows; logical row s of a plane in phase PH = R[.][(s + PH) % 3].
     // =================================================================================================================
-    // (wr[3][0]: level 1, channel block 0 -- that half of z_1 runs here, see H1 above; from L's part of the image)
-    qs_bf8 wr[4][2][2];
+    qs_bf8 wr[4][2][2];  // (wr[3]: level 1, from L's part of the image -- H1)
     if (H1) {
       const unsigned char* wp1 = a.wimg + ((size_t)(1 * 4 + oq) * 3) * (2 * 2 * QS_FRAG) + lane16;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) wr[3][0][h] = *reinterpret_cast<const qs_bf8*>(wp1 + (size_t)h * QS_FRAG);
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) wr[3][kb][h] = *reinterpret_cast<const qs_bf8*>(wp1 + (size_t)(kb * 2 + h) * QS_FRAG);
     }
     {
       const unsigned char* wp = a.wimg + ((size_t)(0 * 4 + oq) * 3) * (2 * 2 * QS_FRAG) + lane16;
@@ -539,8 +534,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         QS_STAMP_DECL
         QS_STAMP(0);
         qs_f4 xv[XN];
-        xfetch(xmap, sXf, spread_y(ytop + 1), xv);
+        if (!H1) xfetch(xmap, sXf, spread_y(ytop + 1), xv);
         const unsigned f0 = (unsigned)slot_top * ROWB + lane16, f1 = (unsigned)slot_ix(1) * ROWB + lane16, f2 = (unsigned)slot_ix(2) * ROWB + lane16;
+        const unsigned f3 = (unsigned)slot_ix(3) * ROWB + lane16;
         constexpr bool N3 = CHEB;  // level 3 enters with -2 L~ (Chebyshev), level 2 with +2 L~
         qs_bf8 fr[2][2][2];  // [buffer][tile of the pair][hi | lo]: the B fragments of the MFMA chains, two sets in flight
         QCoefLo c3 = clo_read(cslot_ix(1));  // row ytop-1: level 3
@@ -560,18 +556,18 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
                  { if (qq < QS_UPR) QS_UNIT<!CHEB, false>(R[0][L0], R[1][L0], qq, QS_LO0(c2)); else QS_UNIT<false, false>(R[0][L0], R[1][L1], qq - QS_UPR, QS_LO1(c2)); })
         qs_settle<9>(R[1][L2]);
         qs_settle<1>(R[0][L0]);
+        if (H1) xfetch(xmap, sXf, spread_y(ytop + 1), xv);  // (two thirds of a step ahead of its use: still more than the memory's latency)
         QS_STAMP(2);
         // s2: z_2 -> b2[new] | b3[new] += b4[new]
         // (the row ytop of L~ is requested in the tail as well: its latency is H's to wait out, H reaches the barrier before L)
-        const unsigned f3 = (unsigned)slot_ix(3) * ROWB + lane16;
         QS_CHAIN(R[0][L0], false, 2, f2, QS_UPR, { c2h = chi_read(cslot_ix(2)); cfetch(sXc | spread_y(ytop), cv, cd); if (H1) { QS_FR0(f3) } },
                  { QS_UNIT<false, N3>(R[1][L2], R[0][L2], qq, QS_HI(c3h)); })
         qs_settle<9>(R[0][L0]);
         qs_settle<1>(R[1][L2]);
         QS_STAMP(3);
-        // s3: b2[new] += b3[new] | H1: the channel block 0 of z_1 onto the dying b3 row, which L starts b1[new] from
+        // s3: b2[new] += b3[new] | H1: z_1 onto the dying b3 row
         if (H1) {
-          QS_SETSX(0, 2, 2, 0, 12, R[1][L0], false, 3, f3, QS_UPR, { QS_UNIT<false, false>(R[0][L0], R[1][L2], qq, QS_HI(c2h)); })
+          QS_CHAIN(R[1][L0], false, 3, f3, QS_UPR, {}, { QS_UNIT<false, false>(R[0][L0], R[1][L2], qq, QS_HI(c2h)); })
           qs_settle<9>(R[1][L0]);
         } else {
 #pragma unroll
@@ -714,7 +710,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
           qs_settle<1>(Y);
         }
         // s0: 2 z_0 (+ 2 b2[-1]) -> Y | b1[new] (= b3 row from H) -+= (b2[-1], b2[0], b2[+1])
-        QS_CHAIN(Y, !CHEB, 1, f0, 3 * QS_UPR, { c0 = clo_read(cslot_ix(5)); if (H1) { QS_FR2(f1) } else { QS_FR0(f1) } },
+        QS_CHAIN(Y, !CHEB, 1, f0, 3 * QS_UPR, { c0 = clo_read(cslot_ix(5)); if (!H1) { QS_FR0(f1) } },
                  { if (qq < QS_UPR) QS_UNIT<!CHEB, N1>(R[1][L2], R[0][L0], qq, QS_LO0(c1));
                    else if (qq < 2 * QS_UPR) QS_UNIT<false, N1>(R[1][L2], R[0][L1], qq - QS_UPR, QS_LO1(c1));
                    else QS_UNIT<false, N1>(R[1][L2], R[0][L2], qq - 2 * QS_UPR, QS_HI(c1h)); })
@@ -722,12 +718,12 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         qs_settle<1>(R[1][L2]);
         QS_STAMP(2);
         // s1: z_1 -> b1[new] | Y += (b1[-2], b1[-1])   (c0: row ytop-5, level 0)
-        if (H1) {  // (channel block 1 only: H has added block 0's half of z_1 to the row it handed over)
-          QS_SETSX(2, 3, 4, 12, 9, R[1][L2], false, 0, f1, 2 * QS_UPR,
-                   { if (qq < QS_UPR) QS_UNIT<false, false>(Y, R[1][L0], qq, QS_LO0(c0)); else QS_UNIT<false, false>(Y, R[1][L1], qq - QS_UPR, QS_LO1(c0)); })
+        if (H1) {  // (z_1 is in the row H handed over)
           c0h = chi_read(cslot_ix(5));
-          QS_SETSX(3, 4, 4, 12, 9, R[1][L2], false, 0, f1, 2 * QS_UPR,
-                   { if (qq < QS_UPR) QS_UNIT<false, false>(Y, R[1][L0], qq, QS_LO0(c0)); else QS_UNIT<false, false>(Y, R[1][L1], qq - QS_UPR, QS_LO1(c0)); })
+#pragma unroll
+          for (int qq = 0; qq < 2 * QS_UPR; ++qq) {
+            if (qq < QS_UPR) QS_UNIT<false, false>(Y, R[1][L0], qq, QS_LO0(c0)); else QS_UNIT<false, false>(Y, R[1][L1], qq - QS_UPR, QS_LO1(c0));
+          }
         } else {
           QS_CHAIN(R[1][L2], false, 0, f1, 2 * QS_UPR, { c0h = chi_read(cslot_ix(5)); },
                    { if (qq < QS_UPR) QS_UNIT<false, false>(Y, R[1][L0], qq, QS_LO0(c0)); else QS_UNIT<false, false>(Y, R[1][L1], qq - QS_UPR, QS_LO1(c0)); })
@@ -778,8 +774,6 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   }
 #undef QS_CHAIN
 #undef QS_SETS
-#undef QS_SETSX
-#undef QS_FR2
 #undef QS_FR0
 #undef QS_FRLOAD
 }
