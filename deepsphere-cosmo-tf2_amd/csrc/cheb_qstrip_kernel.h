@@ -300,10 +300,15 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   // wave w: tile xt = w & 3, pixels p8 + 8 (w >> 2) of it; lane: half h = lane & 1, pixel p8 = (lane >> 1) & 7,
   // qh = (lane >> 4) & 1, kk = lane >> 5; instruction i = 0, 1: the 16 bytes at offset (2 i + kk) 64 + (2 qh + h) 16 of the
   // pixel's 256: channels 32 i + 16 kk + 8 qh + 4 h ..+3 -> fragment (block i, tile xt), lane slot (pixel, 2 kk + qh), half h.
-#ifdef DSPH_QS_XALL  // (tuning: all eight waves fetch half a tile each; measured slower than the H waves alone)
+  // Who fetches x: the four H waves a tile each (X_BY_H), or all eight waves half a tile each.  With level 1's matrix work on H
+  // (H1) the H wave no longer has the time to spare: all eight is 2.4 % faster there (3.28 against 3.36 us per step on the
+  // probe); without H1 (monomial basis) the H waves alone are 0.6 % faster.  (-DDSPH_QS_XALL / -DDSPH_QS_XBYH: tuning)
+#if defined(DSPH_QS_XALL)
   constexpr bool X_BY_H = false;
-#else
+#elif defined(DSPH_QS_XBYH)
   constexpr bool X_BY_H = true;
+#else
+  constexpr bool X_BY_H = !H1;
 #endif
   constexpr int XN = X_BY_H ? 4 : 2;  // 16-byte loads per lane and row
   // X_BY_H: the H wave of quarter q fetches tile q: lane: half h = lane & 1, pixel (lane >> 1) & 15, qh = lane >> 5;
@@ -534,7 +539,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         QS_STAMP_DECL
         QS_STAMP(0);
         qs_f4 xv[XN];
-        if (!H1) xfetch(xmap, sXf, spread_y(ytop + 1), xv);
+        constexpr bool XLATE = H1;  // (the row's registers are H1's weights' in the slots s0, s1: requested behind s1 instead)
+        if (!XLATE) xfetch(xmap, sXf, spread_y(ytop + 1), xv);
         const unsigned f0 = (unsigned)slot_top * ROWB + lane16, f1 = (unsigned)slot_ix(1) * ROWB + lane16, f2 = (unsigned)slot_ix(2) * ROWB + lane16;
         const unsigned f3 = (unsigned)slot_ix(3) * ROWB + lane16;
         constexpr bool N3 = CHEB;  // level 3 enters with -2 L~ (Chebyshev), level 2 with +2 L~
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
                  { if (qq < QS_UPR) QS_UNIT<!CHEB, false>(R[0][L0], R[1][L0], qq, QS_LO0(c2)); else QS_UNIT<false, false>(R[0][L0], R[1][L1], qq - QS_UPR, QS_LO1(c2)); })
         qs_settle<9>(R[1][L2]);
         qs_settle<1>(R[0][L0]);
-        if (H1) xfetch(xmap, sXf, spread_y(ytop + 1), xv);  // (two thirds of a step ahead of its use: still more than the memory's latency)
+        if (XLATE) xfetch(xmap, sXf, spread_y(ytop + 1), xv);  // (two thirds of a step ahead of its use: still more than the memory's latency)
         QS_STAMP(2);
         // s2: z_2 -> b2[new] | b3[new] += b4[new]
         // (the row ytop of L~ is requested in the tail as well: its latency is H's to wait out, H reaches the barrier before L)
