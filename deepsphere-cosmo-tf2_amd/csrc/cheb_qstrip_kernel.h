@@ -29,8 +29,8 @@
 // LDS (161,344 B): ring of 7 rows of x as bf16 hi | lo B-operand fragments (16 KiB per row: [32-channel block][hi | lo][tile]
 //   1 KiB fragments), hand-over 4 x 8 KiB, ring of 6 rows of L~ (2,304 B per row: the diagonal and the eight directions, each a
 //   [p][tile] vector: a lane reads the 16 bytes of its four pixels per direction, 9 reads per level-row), counters.
-// x: the H wave of quarter q fetches tile q (16 pixels x 256 B, four 16-byte loads per lane) a step ahead and splits it into
-//   fragments at the end of the step.  y: straight from the accumulators, 16 pixels x 64 contiguous bytes per instruction.
+// x: fetched a step ahead and split into fragments at the end of the step -- by all eight waves, half a tile each (two 16-byte
+//   loads per lane), when level 1's matrix work runs on H (Chebyshev basis); else by the H wave of quarter q, tile q (four loads).  y: straight from the accumulators, 16 pixels x 64 contiguous bytes per instruction.
 #pragma once
 
 #include <type_traits>
