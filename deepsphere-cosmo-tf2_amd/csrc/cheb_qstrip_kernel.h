@@ -237,7 +237,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
   // before its L partner (stamps in profiles/r5_qstrip_probe.txt): H adds z_1 to the dying b3 row it hands over, from which L
   // starts b1 anyway (b1 = z_1 + 2 L~ b2 - b3), with L's own weights of that level (same sign convention).  To make room for them
   // H asks for the next row of x behind slot s1 instead of at the top of the step.  3.36 us per step against 3.47 (probe, same
-  // lease; half of z_1: 3.44).  Chebyshev basis only: the monomial recurrence hands no b3 row over.
+  // lease; half of z_1: 3.44).  Chebyshev basis only: the monomial recurrence hands no b3 row over (with z_1 alone in that slot of
+  // the hand-over the monomial kernel gained 0.4 %: 3.32 against 3.33 -- its L wave has less to do to begin with; not kept).
 #ifdef DSPH_QS_NOH1
   constexpr bool H1 = false;
 #else

@@ -154,6 +154,10 @@ int main(int argc, char** argv) {
     run({1024, 8, 16, 1 << 30, true}, false, 3);
     return 0;
   }
+  if (argc > 1 && atoi(argv[1]) == 4) {  // (the full-chip timing in the monomial basis)
+    run({1024, 8, 16, 1 << 30, false}, false, 3);
+    return 0;
+  }
   run({128, 2, 16, 1 << 30, true}, true, 0);
   run({128, 1, 16, 40, false}, true, 0);
   run({128, 2, 16, 1 << 30, true, true}, true, 0);
