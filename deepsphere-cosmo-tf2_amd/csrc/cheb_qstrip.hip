@@ -1,4 +1,5 @@
 // Host side of the quad-strip kernel (cheb_qstrip_kernel.h): weight image and launch.
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -111,6 +112,8 @@ int launch_cheb_qstrip(const QStripLaunch& s, hipStream_t stream) {
   a.Fout = s.Fout;
   a.ld = s.ld;
   a.act = s.act;
+  a.xsc = s.f16 ? ldexpf(1.f, s.f16_xexp) : 1.f;
+  a.xsc_inv = s.f16 ? ldexpf(1.f, -s.f16_xexp) : 1.f;
   int grid;
   (void)qstrip_split(s.num_cu, s.tape_rows, s.N, s.tape_rows / std::max(1, s.nstrips), &grid, &a.pieces, &a.wg_per_piece);
   void (*kern)(QStripArgs) = s.f16 ? (s.cheb ? cheb_qstrip5_kernel<true, true> : cheb_qstrip5_kernel<false, true>)

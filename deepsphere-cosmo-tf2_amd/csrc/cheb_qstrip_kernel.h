@@ -77,6 +77,7 @@ struct QStripArgs {
   int64_t x_rows, y_rows;
   int nstrips, N, Fin, Fout, ld, act;
   int pieces, wg_per_piece;   // the tape is cut into `pieces`; `wg_per_piece` workgroups share a piece, each taking every wg_per_piece-th map
+  float xsc, xsc_inv;         // f16 arithmetic: x is split as x * xsc (a power of two, DSPH_OPT_F16_XEXP), the store multiplies by xsc_inv
 #ifdef DSPH_QS_STAMPS
   unsigned* stamps;
 #endif
@@ -357,7 +358,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       qs_u2 hi, lo;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float a0 = xv[i][2 * j], a1 = xv[i][2 * j + 1];
+        // (f16: times the caller's power of two -- an f16 pair keeps 22 bits only where hi AND lo are normal numbers, i.e. for
+        // |x xsc| from 2^-3 up; the store divides it out again, all exact)
+        const float a0 = F16 ? xv[i][2 * j] * a.xsc : xv[i][2 * j], a1 = F16 ? xv[i][2 * j + 1] * a.xsc : xv[i][2 * j + 1];
         if (F16) {  // (a value beyond the f16 range becomes an infinity here and a NaN row in y: loud, not wrong)
           const f16x2 h = __builtin_convertvector(f32x2{a0, a1}, f16x2);
           const f32x2 hf = __builtin_convertvector(h, f32x2);
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
     }
     const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
     // (the f16 image carries its weights times a power of two, qstrip_wprep_kernel: the store takes it out again)
-    const float ysc = (CHEB ? 0.5f : 1.f) * (F16 ? *reinterpret_cast<const float*>(a.wimg + 2 * 4 * 3 * 2 * 2 * QS_FRAG) : 1.f);
+    const float ysc = (CHEB ? 0.5f : 1.f) * (F16 ? *reinterpret_cast<const float*>(a.wimg + 2 * 4 * 3 * 2 * 2 * QS_FRAG) * a.xsc_inv : 1.f);
 #ifdef DSPH_QS_LPRIO  // (tuning: the L waves are the younger ones of their SIMDs and lose the issue arbitration to their H partner)
 #define QS_STR2(x) #x
 #define QS_STR(x) QS_STR2(x)

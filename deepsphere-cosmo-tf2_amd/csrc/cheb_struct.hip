@@ -16,17 +16,14 @@
 
 namespace dsph {
 
-// canonical direction index (0 = the row itself, 1..8 = kDirX / kDirY order) by (dy + 1) * 3 + (dx + 1)
-__device__ constexpr int kDirIndex[9] = {8, 7, 6, 1, 0, 5, 2, 3, 4};
-
-// One thread per row of L~: gdiag[r], gvals8[r][8] and flag[r] (1 = regular).  Rows r >= n_rows (columns that
-// are not rows of this plan: halo rows of a shard) get zeros and flag 0.
-__global__ __launch_bounds__(256) void struct_rows_kernel(const int32_t* __restrict__ cols, const float* __restrict__ vals,
-                                                          int W, int64_t n_rows, int64_t n_cols,
-                                                          float* __restrict__ gvals8, float* __restrict__ gdiag,
-                                                          unsigned char* __restrict__ flag) {
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= n_cols) return;
+// One row of L~: gdiag[r], gvals8[r][8] and flag[r] (1 = regular).  Rows r >= n_rows (columns that are not rows of this
+// plan: halo rows of a shard) get zeros and flag 0.  (__host__ too: the sanitizer build of the plan builders, `make asan`,
+// runs these two set-up passes on the host -- tools/asan/)
+__host__ __device__ inline void struct_row_body(int64_t r, const int32_t* __restrict__ cols, const float* __restrict__ vals, int W,
+                                                int64_t n_rows, float* __restrict__ gvals8, float* __restrict__ gdiag,
+                                                unsigned char* __restrict__ flag) {
+  // canonical direction index (0 = the row itself, 1..8 = kDirX / kDirY order) by (dy + 1) * 3 + (dx + 1)
+  constexpr int kDirIndex[9] = {8, 7, 6, 1, 0, 5, 2, 3, 4};
   float out[9];
 #pragma unroll
   for (int d = 0; d < 9; ++d) out[d] = 0.f;
@@ -53,14 +50,19 @@ __global__ __launch_bounds__(256) void struct_rows_kernel(const int32_t* __restr
   for (int d = 0; d < 8; ++d) gvals8[r * 8 + d] = out[d + 1];
   flag[r] = ok ? 1 : 0;
 }
+__global__ __launch_bounds__(256) void struct_rows_kernel(const int32_t* __restrict__ cols, const float* __restrict__ vals,
+                                                          int W, int64_t n_rows, int64_t n_cols,
+                                                          float* __restrict__ gvals8, float* __restrict__ gdiag,
+                                                          unsigned char* __restrict__ flag) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_cols) return;
+  struct_row_body(r, cols, vals, W, n_rows, gvals8, gdiag, flag);
+}
 
-// One thread per 256-row tile: cls[t] bit 0 = class R for depth D, bit 1 = interior (every region cell is an
+// One 256-row tile: cls[t] bit 0 = class R for depth D, bit 1 = interior (every region cell is an
 // output row of the plan, i.e. no halo row of another rank is read).
-__global__ __launch_bounds__(256) void struct_tiles_kernel(const unsigned char* __restrict__ flag, int ntiles, int D,
-                                                           int64_t n_rows, int64_t n_cols, int64_t out_rows,
-                                                           unsigned char* __restrict__ cls) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= ntiles) return;
+__host__ __device__ inline unsigned char struct_tile_body(int t, const unsigned char* __restrict__ flag, int D, int64_t n_rows,
+                                                          int64_t n_cols, int64_t out_rows) {
   const int64_t row0 = (int64_t)t * 256;
   bool ok = D >= 1 && D <= ST_DMAX && row0 + 256 <= out_rows && row0 + 256 <= 0xffffffffLL;
   bool interior = true;
@@ -69,14 +71,22 @@ __global__ __launch_bounds__(256) void struct_tiles_kernel(const unsigned char* 
     if (X0 - D < 0 || Y0 - D < 0 || X0 + ST_TILE + D > 65535 || Y0 + ST_TILE + D > 65535) ok = false;
     for (int gy = -D; ok && gy < ST_TILE + D; ++gy)
       for (int gx = -D; gx < ST_TILE + D; ++gx) {
-        const int ring = max(max(-gx, gx - (ST_TILE - 1)), max(max(-gy, gy - (ST_TILE - 1)), 0));
+        const int a = -gx > gx - (ST_TILE - 1) ? -gx : gx - (ST_TILE - 1), b = -gy > gy - (ST_TILE - 1) ? -gy : gy - (ST_TILE - 1);
+        const int ring = (a > b ? a : b) > 0 ? (a > b ? a : b) : 0;
         const int64_t rid = (int64_t)st_morton((unsigned)(X0 + gx), (unsigned)(Y0 + gy));
         if (rid >= n_cols) { ok = false; break; }
         if (ring < D && (rid >= n_rows || !flag[rid])) { ok = false; break; }
         if (rid >= out_rows) interior = false;
       }
   }
-  cls[t] = (ok ? 1 : 0) | (interior ? 2 : 0);
+  return (unsigned char)((ok ? 1 : 0) | (interior ? 2 : 0));
+}
+__global__ __launch_bounds__(256) void struct_tiles_kernel(const unsigned char* __restrict__ flag, int ntiles, int D,
+                                                           int64_t n_rows, int64_t n_cols, int64_t out_rows,
+                                                           unsigned char* __restrict__ cls) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  cls[t] = struct_tile_body(t, flag, D, n_rows, n_cols, out_rows);
 }
 
 // Weight fragments of the structured kernel, one 2 KiB block per (slice c, order k, column block nb), a slice
@@ -122,8 +132,12 @@ int struct_build_rows(const dsph_plan* plan, float** gvals8, float** gdiag, unsi
   DSPH_HIP(hipMalloc((void**)gvals8, (size_t)n * 8 * sizeof(float)));
   DSPH_HIP(hipMalloc((void**)gdiag, (size_t)n * sizeof(float)));
   DSPH_HIP(hipMalloc((void**)flag, (size_t)n));
+#ifdef DSPH_HOST_EMU  // (`make asan`: "device" memory is host memory there, tools/asan/hip_stub.cpp)
+  for (int64_t r = 0; r < n; ++r) struct_row_body(r, plan->d_cols, plan->d_vals, (int)plan->width, plan->n_rows, *gvals8, *gdiag, *flag);
+#else
   hipLaunchKernelGGL(struct_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, plan->d_cols, plan->d_vals,
                      (int)plan->width, plan->n_rows, plan->n_cols, *gvals8, *gdiag, *flag);
+#endif
   DSPH_HIP(hipGetLastError());
   DSPH_HIP(hipDeviceSynchronize());
   return DSPH_OK;
@@ -134,8 +148,12 @@ int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, in
                           unsigned char* h_cls) {
   unsigned char* d_cls = nullptr;
   DSPH_HIP(hipMalloc((void**)&d_cls, (size_t)ntiles));
+#ifdef DSPH_HOST_EMU
+  for (int t = 0; t < ntiles; ++t) d_cls[t] = struct_tile_body(t, d_flag, D, plan->n_rows, plan->n_cols, out_rows);
+#else
   hipLaunchKernelGGL(struct_tiles_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, 0, d_flag, ntiles, D, plan->n_rows,
                      plan->n_cols, out_rows, d_cls);
+#endif
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(h_cls, d_cls, (size_t)ntiles, hipMemcpyDeviceToHost);
   (void)hipFree(d_cls);

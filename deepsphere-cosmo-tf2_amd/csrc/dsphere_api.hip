@@ -157,6 +157,11 @@ int dsph_plan_set_option(dsph_plan* p, int32_t option, int64_t value) {
       if (value < 0 || value > 1) { set_error("plan_set_option: DSPH_OPT_STRIP_FORM takes 0 (quad strips) or 1 (strip pairs)"); return DSPH_E_BADARG; }
       o.strip_form = (int)value;
       break;
+    case DSPH_OPT_F16_XEXP:
+      if (value < -100 || value > 100) { set_error("plan_set_option: DSPH_OPT_F16_XEXP takes a binary exponent in [-100, 100]"); return DSPH_E_BADARG; }
+      o.f16_xexp = (int)value;
+      tables = false;
+      break;
     default: set_error("plan_set_option: unknown option %d", (int)option); return DSPH_E_BADARG;
   }
   if (tables && p->fused) {

@@ -49,6 +49,7 @@ struct PlanOptions {
   bool tstep = true;         // DSPH_OPT_TSTEP: wide graphs step through LDS tiles (cheb_tstep.hip) instead of the gather kernel
   int strip_form = 0;        // DSPH_OPT_STRIP_FORM: 0 quad strips (cheb_qstrip_kernel.h), 1 strip pairs (cheb_strip_kernel.h)
   bool pack = true;          // DSPH_OPT_PACK: narrow layers run several maps per item / wave when the batch has more than one
+  int f16_xexp = 0;          // DSPH_OPT_F16_XEXP: x enters the f16 split of DSPH_PREC_F16X3 times 2^f16_xexp (y times 2^-f16_xexp)
 };
 
 }  // namespace dsph
@@ -216,6 +217,7 @@ struct QStripLaunch {
   int32_t nstrips, Fin, Fout, act, ld, num_cu;
   bool cheb;
   bool f16 = false;          // DSPH_PREC_F16X3: the three-term split on f16 pairs instead of bf16 pairs
+  int f16_xexp = 0;          // f16: x is split as x 2^f16_xexp, the store takes the factor out again (DSPH_OPT_F16_XEXP)
   bool prep_weights = true;
 };
 bool qstrip_shape_ok(int32_t Fin, int32_t Fout, int32_t K);

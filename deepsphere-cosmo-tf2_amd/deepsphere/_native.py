@@ -19,7 +19,7 @@ PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3
 ALGO_AUTO, ALGO_UNFUSED, ALGO_FUSED = 0, 1, 2
 PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
 FWD_KEEP_WEIGHTS = 1
-ABI_VERSION = 2  # DSPH_ABI_VERSION of include/dsphere.h this binding was written against
+ABI_VERSION = 3  # DSPH_ABI_VERSION of include/dsphere.h this binding was written against
 POOL_MAX, POOL_AVG = 0, 1
 PREPARE_BACKWARD, PREPARE_RELEASE_HOST = 1, 2
 BASIS_CHEBYSHEV, BASIS_MONOMIAL = 0, 1
@@ -27,6 +27,7 @@ BASIS_CHEBYSHEV, BASIS_MONOMIAL = 0, 1
 OPT_STRIPS, OPT_STRUCT, OPT_TABLES, OPT_FORK, OPT_STRIP_SEG, OPT_STRIP_MINROWS, OPT_STRIP_GENERIC, OPT_SPLIT, OPT_TSTEP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_PACK = 10
 OPT_STRIP_FORM = 11
+OPT_F16_XEXP = 12
 STRIP_FORM_QUAD, STRIP_FORM_PAIRS = 0, 1
 STRIPS_AUTO, STRIPS_ALWAYS, STRIPS_NEVER = 0, 1, 2
 SPLIT_AUTO, SPLIT_ALWAYS, SPLIT_NEVER = 0, 1, 2

@@ -73,7 +73,9 @@ def _resolve_activation(activation):
 #     configs[0] -- and such layers cost next to nothing anyway.
 # "fp32" (the bitwise fp32-fma-chain MFMA), "bf16x6" and "bf16x3" can be asked for by name; so can "f16x3" (round 5): the
 # fp32-equivalent three-term split on f16 pairs (11 + 11 mantissa bits) where the quad-strip kernel runs (K = 5, 64 -> 64 per
-# column block, HEALPix rectangles) and "bf16x6" everywhere else -- for inputs of magnitude below 65,504 (DSPH_PREC_F16X3).
+# column block, HEALPix rectangles) and "bf16x6" everywhere else; x enters the f16 split times a power of two chosen from
+# max|x| (the layer's ``x_absmax`` or a reduction over x: Chebyshev._set_f16_scale, DSPH_OPT_F16_XEXP), so the arithmetic is
+# fp32-equivalent at every input scale.  Its backward: dx on "bf16x6" (dy has no known scale), dW exact fp32.
 DEFAULT_PRECISION = "auto"
 
 
@@ -89,13 +91,29 @@ def resolve_precision(precision, Fin, K=None):
     return precision
 
 
+def resolve_dx_precision(precision, Fout, K=None):
+    """The arithmetic of the input gradient -- the forward of the transposed layer on dy, a contraction over ``Fout`` channels.
+    As ``resolve_precision`` except for "f16x3": the quad strips split their x operand (here dy) into f16 pairs as it is, and
+    upstream gradients are routinely far below the f16 range (a mean loss over 12.6 M pixels gives dy ~ 1e-8, the smallest f16
+    subnormal is 6e-8) -- dx would come out zero or a few bits wide on the strips' pixels.  dy has no caller-known scale, so
+    "f16x3" runs its dx on the six-term bf16 split (same accuracy, the exponent range of fp32)."""
+    if precision == "f16x3":
+        return "bf16x6"
+    return resolve_precision(precision, Fout, K)
+
+
+# the weight gradient takes the three-term split from this many pixels (N * M) on; the one statement of the rule -- DESIGN.md 4.1,
+# INTEGRATION.md 3, bench.py and tests/test_gpu_round5.py quote this constant
+WGRAD_SPLIT_MIN_PIXELS = 4096
+
+
 def resolve_wgrad_precision(precision, n_terms):
     """The arithmetic of the weight gradient: its contraction runs over the ``n_terms`` = N * M pixels of the batch, so the
-    three-term split's per-product error (<= 1.15e-5) averages out over thousands of terms -- "auto" takes it from 4,096
-    pixels on (measured 4-7e-6 of max|dW| at nside 16 and above) and exact fp32 below; "bf16x6" has no weight-gradient
-    kernel and runs exact fp32 (include/dsphere.h)."""
+    three-term split's per-product error (<= 1.15e-5) averages out over thousands of terms -- "auto" takes it from
+    ``WGRAD_SPLIT_MIN_PIXELS`` = 4,096 pixels on (measured 4-7e-6 of max|dW| at nside 16 and above, held to 2e-5) and exact fp32
+    below; "bf16x6" and "f16x3" have no weight-gradient kernel and run exact fp32 (include/dsphere.h)."""
     if precision == "auto":
-        return "bf16x3" if n_terms >= 4096 else "fp32"
+        return "bf16x3" if n_terms >= WGRAD_SPLIT_MIN_PIXELS else "fp32"
     return "fp32" if precision in ("bf16x6", "f16x3") else precision
 
 
@@ -119,6 +137,7 @@ class _ChebConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, layer):
         plan = layer._get_plan()
+        layer._set_f16_scale(plan, x)
         y, layer._workspace = _native.cheb_forward(
             plan, x, kernel.detach(), None, layer.K, act=_native.ACT_NONE,
             precision=layer._prec_code(), algo=_ALGOS[layer.algo], workspace=layer._workspace,
@@ -142,7 +161,7 @@ class _ChebConvFunction(torch.autograd.Function):
             kernel_t = kernel.detach().reshape(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()
             dx, layer._workspace_t = _native.cheb_forward(
                 plan_t, dy, kernel_t, None, K, act=_native.ACT_NONE,
-                precision=_PRECISIONS[resolve_precision(layer.precision, Fout, K)],
+                precision=_PRECISIONS[resolve_dx_precision(layer.precision, Fout, K)],
                 algo=_ALGOS[layer.algo], workspace=layer._workspace_t, basis=layer._basis)
         if ctx.needs_input_grad[1]:
             plan = layer._get_plan()
@@ -195,7 +214,9 @@ class Chebyshev(torch.nn.Module):
             default: current CUDA device), ``precision`` ("auto", the default: "bf16x3" -- the three-term bf16 split, 2-6e-6 of
             max|y| from the float64 oracle -- for 16 or more input channels, else "bf16x6" | "bf16x6": fp32-equivalent six-term
             split, 2-7e-7 | "fp32": exact-fp32 MFMA, bitwise an fp32 fma chain; the recurrence is fp32 in all of them; see
-            DEFAULT_PRECISION), ``algo`` ("auto" | "unfused" | "fused") and ``plan_options`` (a dict of
+            DEFAULT_PRECISION; "f16x3": the fp32-equivalent three-term split on f16 pairs where the quad strips run -- takes
+            ``x_absmax``, a bound on |x| known to the caller, for its power-of-two input scale; without one the layer reduces
+            max|x| on the device and synchronises once per forward), ``algo`` ("auto" | "unfused" | "fused") and ``plan_options`` (a dict of
             ``_native.OPT_*`` -> value handed to ``dsph_plan_set_option``, e.g. ``{OPT_STRIPS: STRIPS_NEVER}`` for results
             that do not depend on the batch size).  ``graph=True`` (inference only): the prepared forward is captured into
             a HIP graph on first use and replayed while the input buffer, the weights and the shapes stay the same -- one
@@ -219,6 +240,7 @@ class Chebyshev(torch.nn.Module):
         algo = kwargs.pop("algo", "auto")
         self._plan_options = dict(kwargs.pop("plan_options", None) or {})
         self._use_graph = bool(kwargs.pop("graph", False))
+        self.x_absmax = kwargs.pop("x_absmax", None)
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         if algo not in _ALGOS:
@@ -333,12 +355,16 @@ class Chebyshev(torch.nn.Module):
         if Fin != self._Fin:
             raise ValueError(f"layer was built for Fin = {self._Fin}, got {Fin}")
         plan = self._get_plan()
-        if getattr(self, "_prepared", None) != (self.K, Fin):
-            # tile tables now, not inside the first kernel launch (allocation + synchronisation: dsph_plan_prepare_layer)
-            plan.prepare(self.K, Fin, Fout=self.Fout)
-            self._prepared = (self.K, Fin)
         wants_grad = torch.is_grad_enabled() and (
             self.kernel.requires_grad or input_tensor.requires_grad or (self.use_bias and self.bias.requires_grad))
+        prepared = getattr(self, "_prepared", None)
+        if prepared is None or prepared[:2] != (self.K, Fin) or (wants_grad and not prepared[2]):
+            # tile tables now, not inside the first kernel launch (allocation + synchronisation: dsph_plan_prepare_layer); with
+            # autograd on also what the backward needs (DSPH_PREPARE_BACKWARD: the weight-gradient tables and the one-second host
+            # pass that decides whether L~ is symmetric) -- otherwise the first training step would stall inside
+            # dsph_cheb_backward_weights, mid-capture under a HIP graph
+            plan.prepare(self.K, Fin, Fout=self.Fout, backward=wants_grad)
+            self._prepared = (self.K, Fin, bool(wants_grad) or bool(prepared and prepared[:2] == (self.K, Fin) and prepared[2]))
         if wants_grad:
             # differentiable path: the linear part through the autograd function above, the epilogue
             # (BN -> bias -> activation, gnn_layers.py:152-159) as ordinary torch ops
@@ -356,27 +382,37 @@ class Chebyshev(torch.nn.Module):
             return y
         x = input_tensor.detach().to(device=self._device, dtype=torch.float32).contiguous()
         bias = self.bias.detach().reshape(-1).contiguous() if self.use_bias else None
+        kernel = self.kernel.detach()
+        kver = self.kernel._version
 
-        fuse_epilogue = not self.use_bn
+        # Batch norm with the moving statistics (the reference's default call, training=False) is a per-channel scale and
+        # shift between the contraction and the bias (gnn_layers.py:152-159: BN -> bias -> activation; center=False,
+        # scale=False): folded into the weights and the bias, the whole epilogue runs inside the kernel -- no transposed
+        # copies, no elementwise pass.  With batch statistics (training=True) the host framework normalises, as before.
+        bn_training = self.use_bn and (self.training if training is None else bool(training))
+        if self.use_bn and not bn_training:
+            kernel, bias, kver = self._folded_bn()
+        fuse_epilogue = not bn_training
         act_code = self._act_code if (fuse_epilogue and self._act_code is not None) else _native.ACT_NONE
+        self._set_f16_scale(plan, x)
         # Inference steady state: the packed weight images of the previous forward are still in the workspace -- same kernel
         # tensor at the same version (torch bumps it on every in-place write: optimiser step, copy_, load_state_dict), same
         # arithmetic, same workspace -- so the call launches no weight-preparation kernel (DSPH_FWD_KEEP_WEIGHTS).
         # (and same batch class: the tile kernels pack four maps of a narrow layer into one item when there is more than one map)
-        wkey = (self.kernel.data_ptr(), self.kernel._version, self._prec_code(), (self.algo, N > 1),
+        wkey = (kernel.data_ptr(), kver, self._prec_code(), (self.algo, N > 1),
                 None if self._workspace is None else self._workspace.data_ptr())
         if getattr(self, "_use_graph", False):
-            y = self._graph_forward(plan, x, bias if fuse_epilogue else None, act_code, wkey[:4])
+            y = self._graph_forward(plan, x, bias if fuse_epilogue else None, act_code, wkey[:4], kernel)
         else:
             y, self._workspace = _native.cheb_forward(
-                plan, x, self.kernel.detach(), bias if fuse_epilogue else None, self.K, act=act_code,
+                plan, x, kernel, bias if fuse_epilogue else None, self.K, act=act_code,
                 precision=self._prec_code(), algo=_ALGOS[self.algo], workspace=self._workspace,
                 basis=self._basis, keep_weights=getattr(self, "_wkey", None) == wkey,
             )
             self._wkey = wkey[:4] + (self._workspace.data_ptr() if self._workspace is not None else None,)
-        if self.use_bn:  # BN -> bias -> activation, the reference's order (gnn_layers.py:152-159)
+        if bn_training:  # BN -> bias -> activation, the reference's order (gnn_layers.py:152-159)
             was_training = self.bn.training
-            self.bn.train(self.training if training is None else bool(training))
+            self.bn.train(True)
             y = self.bn(y.transpose(1, 2)).transpose(1, 2).contiguous()
             self.bn.train(was_training)
             if bias is not None:
@@ -386,6 +422,53 @@ class Chebyshev(torch.nn.Module):
         elif self.activation is not None and self._act_code is None:
             y = self.activation(y)
         return y
+
+    def _folded_bn(self):
+        """Inference batch norm folded into the layer's parameters: ``(kernel * s, bias - mean * s, version)`` with
+        ``s = 1 / sqrt(running_var + eps)`` per output channel, so that ``act(BN(conv(x)) + bias)`` is one kernel call with the
+        epilogue fused (reference order BN -> bias -> activation, gnn_layers.py:152-159).  Cached: rebuilt (three tiny torch ops
+        on [K*Fin, Fout]) only when the kernel, the bias or the moving statistics change -- their version counters move on every
+        in-place write (optimiser step, ``load_state_dict``; a training-mode BN call moves ``num_batches_tracked``) -- and written into the SAME tensors, so the
+        kept weight images of the steady state are keyed on a stable pointer and a fold counter."""
+        bn = self.bn
+        # (a training-mode call updates the moving statistics inside the framework's native batch norm WITHOUT moving their
+        # version counters; it does bump num_batches_tracked, in Python)
+        key = (self.kernel.data_ptr(), self.kernel._version, bn.running_mean._version, bn.running_var._version,
+               bn.num_batches_tracked._version if bn.num_batches_tracked is not None else None,
+               None if not self.use_bias else (self.bias.data_ptr(), self.bias._version))
+        fold = getattr(self, "_bn_fold", None)
+        if fold is None or fold["key"] != key:
+            with torch.no_grad():
+                s = torch.rsqrt(bn.running_var.to(torch.float32) + bn.eps)
+                kf = self.kernel.detach() * s
+                bf = -bn.running_mean.to(torch.float32) * s
+                if self.use_bias:
+                    bf = bf + self.bias.detach().reshape(-1)
+                if fold is None:
+                    fold = {"kernel": kf.contiguous(), "bias": bf.contiguous(), "count": 0}
+                else:
+                    fold["kernel"].copy_(kf)
+                    fold["bias"].copy_(bf)
+                fold["key"] = key
+                fold["count"] += 1
+            self._bn_fold = fold
+        return fold["kernel"], fold["bias"], ("bn-fold", fold["count"])
+
+    def _set_f16_scale(self, plan, x):
+        """``precision="f16x3"``: the power of two x is multiplied by on its way into the f16 split (DSPH_OPT_F16_XEXP) --
+        max|x| 2^e in [2^13, 2^14), from the caller's ``x_absmax`` (a known bound on |x|: no extra work) or, when the caller
+        named none, from a reduction over x on the device and ONE host synchronisation per forward."""
+        if self.precision != "f16x3":
+            return
+        amax = getattr(self, "x_absmax", None)
+        if amax is None:
+            amax = float(x.abs().amax())
+        e = 0
+        if np.isfinite(amax) and amax > 0.0:
+            e = int(np.clip(14 - np.frexp(amax)[1], -100, 100))
+        if getattr(self, "_f16_xexp", None) != e:
+            plan.set_option(_native.OPT_F16_XEXP, e)
+            self._f16_xexp = e
 
     call = forward
 
@@ -434,7 +517,7 @@ class Chebyshev(torch.nn.Module):
         self._wkey = None
         self._graph = None
 
-    def _graph_forward(self, plan, x, bias, act_code, wkey):
+    def _graph_forward(self, plan, x, bias, act_code, wkey, kernel):
         """The prepared forward as one HIP-graph launch (``graph=True``).  Captured after an ordinary forward has packed the
         weight images and sized the workspace; the captured call keeps them (DSPH_FWD_KEEP_WEIGHTS), so the graph holds the
         compute kernels only -- and under capture the BFS-tile launch always runs beside the structured ones
@@ -443,14 +526,13 @@ class Chebyshev(torch.nn.Module):
         g = getattr(self, "_graph", None)
         if g is None or g["key"] != key:
             kw = dict(act=act_code, precision=self._prec_code(), algo=_ALGOS[self.algo], basis=self._basis)
-            y, self._workspace = _native.cheb_forward(plan, x, self.kernel.detach(), bias, self.K, workspace=self._workspace, **kw)
+            y, self._workspace = _native.cheb_forward(plan, x, kernel, bias, self.K, workspace=self._workspace, **kw)
             self._wkey = None
             graph = torch.cuda.CUDAGraph()
             out = torch.empty_like(y)
             cur = torch.cuda.current_stream(x.device)
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(cur)
-            kernel = self.kernel.detach()
             with torch.cuda.stream(side):
                 with torch.cuda.graph(graph, stream=side):
                     _native.cheb_forward(plan, x, kernel, bias, self.K, workspace=self._workspace, out=out, keep_weights=True, **kw)
@@ -483,6 +565,7 @@ class Chebyshev(torch.nn.Module):
         self.algo = kwargs.pop("algo", "auto")
         self._plan_options = dict(kwargs.pop("plan_options", None) or {})
         self._use_graph = bool(kwargs.pop("graph", False))
+        self.x_absmax = kwargs.pop("x_absmax", None)
         if self.precision not in _PRECISIONS or self.algo not in _ALGOS:
             raise ValueError("unknown precision or algo")
         self.kwargs = kwargs

@@ -58,6 +58,9 @@ class HealpyPool(torch.nn.Module):
         if x.is_cuda and x.dtype == torch.float32:
             return _NestPoolFunction.apply(x.contiguous(), self.filter_size,
                                            _native.POOL_MAX if self.pool_type == "MAX" else _native.POOL_AVG)
+        # (not a HIP float32 tensor -- a CPU tensor, another dtype: the same reduction as a strided op of the host framework.
+        # The one host-framework branch of the package, kept for shape checks and tests without a GPU; it is not on the
+        # convolution's path and DESIGN.md 1 says so.)
         x = x.reshape(N, M // self.filter_size, self.filter_size, F)
         return x.amax(dim=2) if self.pool_type == "MAX" else x.mean(dim=2)
 

@@ -235,7 +235,7 @@ class _ShardedConvFunction(torch.autograd.Function):
         dx = dk = None
         if ctx.needs_input_grad[0]:
             kernel_t = kernel.detach().reshape(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()
-            dx = shard._forward(dy, kernel_t, None, _native.ACT_NONE, buf="_dy_ext")
+            dx = shard._forward(dy, kernel_t, None, _native.ACT_NONE, buf="_dy_ext", precision=shard.precision_dx)
         if ctx.needs_input_grad[1]:
             dk = shard._wgrad_local(x_ext, dy)
             shard._all_reduce(dk)
@@ -280,6 +280,8 @@ class ShardedChebyshev:
         import torch.distributed as dist
 
         gather = int(world) > 1 and dist.is_available() and dist.is_initialized()
+        if gather and dist.get_world_size(group) != int(world):
+            raise ValueError(f"ShardedChebyshev(world={int(world)}) on a process group of {dist.get_world_size(group)} ranks")
         self.layout = ShardLayout(ell_cols, ell_vals, K, rank, world, M=M, peer_requests=None if gather else "replicated")
         if gather:
             # set-up only: every rank publishes which rows it needs from whom; a rank learns its send lists from that
@@ -294,7 +296,16 @@ class ShardedChebyshev:
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.group = group
         self._compute = _compute
-        self.precision = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6}[precision]
+        precisions = {"fp32": _native.PREC_FP32, "bf16x3": _native.PREC_BF16X3, "bf16x6": _native.PREC_BF16X6,
+                      "f16x3": _native.PREC_F16X3}
+        if precision not in precisions:
+            raise ValueError(f"precision must be one of {sorted(precisions)}")
+        self.precision = precisions[precision]
+        # the input gradient runs the forward kernels on dy, whose scale nobody vouches for: "f16x3" (x split into f16 pairs as it
+        # is) takes the six-term bf16 split there, like gnn_layers.resolve_dx_precision; the weight gradient has kernels for exact
+        # fp32 and the three-term bf16 split only (include/dsphere.h)
+        self.precision_dx = _native.PREC_BF16X6 if precision == "f16x3" else self.precision
+        self.precision_dw = _native.PREC_BF16X3 if precision == "bf16x3" else _native.PREC_FP32
         self.algo = {"auto": _native.ALGO_AUTO, "unfused": _native.ALGO_UNFUSED, "fused": _native.ALGO_FUSED}[algo]
         self.act = act
         # a torch tensor (e.g. a Parameter that requires grad) is kept as it is: calling the layer is then differentiable
@@ -434,12 +445,12 @@ class ShardedChebyshev:
                  _native.ACT_TANH: torch.tanh}[self.act](y)
         return y
 
-    def _forward(self, x_local, kernel, bias, act, buf="_x_ext"):
+    def _forward(self, x_local, kernel, bias, act, buf="_x_ext", precision=None):
         if self._compute is not None:
             return self._compute(self.layout, self.exchange(x_local, buf), kernel)
         Fin = x_local.shape[2]
         self.fused = self.plan.fused_ok(Fin, int(kernel.shape[1]), self.K) and self.algo != _native.ALGO_UNFUSED
-        kw = dict(act=act, precision=self.precision, algo=self.algo)
+        kw = dict(act=act, precision=self.precision if precision is None else precision, algo=self.algo)
         if not self.fused or self.world == 1:
             x_ext = self.exchange(x_local, buf)
             y, self._workspace = _native.cheb_forward(self.plan, x_ext, kernel, bias, self.K,
@@ -460,15 +471,24 @@ class ShardedChebyshev:
         if self._compute_wgrad is not None:
             return self._compute_wgrad(self.layout, x_ext, dy)
         dk, self._workspace_w = _native.cheb_backward_weights(self.plan, x_ext, dy, self.K, algo=self.algo,
-                                                              workspace=self._workspace_w, precision=self.precision)
+                                                              workspace=self._workspace_w, precision=self.precision_dw)
         return dk
 
     def _all_reduce(self, t):
         """Sum over the ranks, in place (RCCL; host-staged under a gloo group like the halo exchange)."""
         import torch.distributed as dist
 
-        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
-            return t  # (a one-rank process group still goes through the collective: the sum over one rank)
+        if not (dist.is_available() and dist.is_initialized()):
+            if self.world != 1:
+                raise RuntimeError("ShardedChebyshev: the gradient of a layer sharded over several ranks needs a process group")
+            return t
+        # The sum runs over THIS layer's ranks only: a one-rank layer (world = 1, group = None) inside a job whose default
+        # group is larger -- data parallel over 8 ranks, say -- must not sum its gradient over those unrelated ranks (or hang
+        # when they call unevenly).  A one-rank group still goes through the collective: the sum over one rank.
+        if dist.get_world_size(self.group) != self.world:
+            if self.world == 1:
+                return t
+            raise RuntimeError(f"ShardedChebyshev(world={self.world}) on a process group of {dist.get_world_size(self.group)} ranks")
         if t.is_cuda and dist.get_backend(self.group) == "gloo":
             h = t.cpu()
             dist.all_reduce(h, group=self.group)

@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define DSPH_ABI_VERSION 2  /* 2: dsph_plan_prepare_layer; the entry points added since version 1 (set_option,
-                              * forward_ex, forward_pool, healpix_pool, strip_pairs) are part of it */
+#define DSPH_ABI_VERSION 3  /* 3: DSPH_OPT_F16_XEXP (round 6); 2: dsph_plan_prepare_layer; the entry points added
+                              * since version 1 (set_option, forward_ex, forward_pool, healpix_pool, strip_pairs) are part of it */
 
 /* error codes */
 #define DSPH_OK 0
@@ -56,9 +56,16 @@ extern "C" {
 /* fp32-equivalent at the three-term split's price, where the quad-strip kernel runs (csrc/cheb_qstrip_kernel.h: K = 5, 64 input
  * and 64 output channels per column block, the rectangles of a HEALPix map): both operands split hi + lo into f16 (11 + 11
  * mantissa bits), hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16, fp32 accumulate: what is dropped is 2^-22 of a product.
- * The weights go in times a power of two (taken out again in the store), x as it is: an input of magnitude 65,504 or more
- * does not fit an f16 and comes out as Inf / NaN rows of y -- the caller vouches for the range.  Every tile, shape and kernel
- * the quad strips do not take runs DSPH_PREC_BF16X6 (same accuracy, no range condition). */
+ * The weights go in times a power of two of the library's choosing (taken out again in the store); x goes in times 2^e, e =
+ * DSPH_OPT_F16_XEXP of the plan (default 0), taken out again in the store as well.  The RANGE CONDITION is the caller's to meet:
+ *   upper: |x| 2^e < 65,504 -- an input beyond it does not fit an f16 and comes out as Inf / NaN rows of y (loud);
+ *   lower: an f16 pair keeps 22 bits only where both halves are normal numbers, |x| 2^e >= 2^-3; below that the lo half goes
+ *          subnormal and the absolute error of an input element stays at 2^-25 (2^-e of it in x's units): with unit-variance x and e
+ *          = 0 the result is 3e-7 of max|y| from float64, with x of scale 1e-3 and e = 0 it is 2e-5 -- WORSE than DSPH_PREC_BF16X3
+ *          (silent).  Choose e so that max|x| 2^e lies in [2^13, 2^15): every element within 2^-16 of the maximum then keeps its
+ *          22 bits and the smaller ones err by 2^-38 of the maximum (deepsphere/gnn_layers.py does this from `x_absmax`, or
+ *          from a reduction over x when the caller names no scale).
+ * Every tile, shape and kernel the quad strips do not take runs DSPH_PREC_BF16X6 (same accuracy, no range condition). */
 #define DSPH_PREC_F16X3 3
 
 /* polynomial basis of the recurrence: T_1 = L~ x in both;
@@ -167,6 +174,10 @@ int dsph_plan_prepare_layer(dsph_plan* plan, int32_t K, int32_t Fin, int32_t Fou
 #define DSPH_OPT_TSTEP 9
 #define DSPH_OPT_PACK 10
 #define DSPH_OPT_STRIP_FORM 11
+/*   DSPH_OPT_F16_XEXP       binary exponent e in [-100, 100], default 0: under DSPH_PREC_F16X3 the quad strips split x 2^e into
+ *                           f16 pairs and store y 2^-e (exact both ways); see DSPH_PREC_F16X3 for how to choose it.  Read when a
+ *                           forward is enqueued: it may change between forwards (not while one is being enqueued on this plan). */
+#define DSPH_OPT_F16_XEXP 12
 int dsph_plan_set_option(dsph_plan* plan, int32_t option, int64_t value);
 
 int64_t dsph_plan_rows(const dsph_plan* plan);
@@ -220,7 +231,10 @@ size_t dsph_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32
  *   bias  device [Fout] fp32 or NULL                    (the reference's `bias`, shape [1,1,Fout])
  *   y     device (N, out_rows, Fout) fp32
  * Batch normalisation (gnn_layers.py:152-153) sits between the contraction and the bias in the
- * reference; a layer with use_bn=True calls this with bias=NULL, act=NONE and finishes on the host.
+ * reference.  With the moving statistics (inference; center=False, scale=False) it is a per-channel scale and shift,
+ * s[o] = 1 / sqrt(var[o] + eps): the caller passes w[:, o] * s[o] as `w` and bias[o] - mean[o] * s[o] as `bias` and gets
+ * act(BN(conv) + bias) from this one call (deepsphere/gnn_layers.py does, keyed on the versions of the statistics); with
+ * batch statistics (training) a layer calls this with bias=NULL, act=NONE and finishes in the host framework.
  * Asynchronous on `hip_stream` (a hipStream_t; NULL = the default stream).  (Part of a large fused forward may run on a
  * stream the plan owns, forked from and joined back into `hip_stream` inside the call: invisible to the caller, capturable.) */
 int dsph_cheb_forward(const dsph_plan* plan, const float* x, const float* w, const float* bias,

@@ -30,7 +30,7 @@ def _dev(a):
 
 def test_native_library_is_loaded_and_gpu_visible():
     assert torch.cuda.is_available()
-    assert _native.lib().dsph_abi_version() == 2
+    assert _native.lib().dsph_abi_version() == _native.ABI_VERSION == 3
 
 
 @pytest.mark.parametrize("algo", ["unfused", "auto"])

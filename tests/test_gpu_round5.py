@@ -268,8 +268,8 @@ def test_one_rank_of_rccl():
 
 
 # the quad-strip weight gradient runs the three-term bf16 arithmetic on both operands and forms orders 3 and 4 from products of
-# order-2 planes (2 G - G': twice the rounding of one product): measured 4 - 8e-6 of max |dW|, held to 2e-5; the layers'
-# default for dW stays exact fp32 (gnn_layers.resolve_wgrad_precision)
+# order-2 planes (2 G - G': twice the rounding of one product): measured 4 - 8e-6 of max |dW|, held to 2e-5; it is the layers'
+# default for dW from gnn_layers.WGRAD_SPLIT_MIN_PIXELS = 4,096 pixels on, exact fp32 below (gnn_layers.resolve_wgrad_precision)
 TOL_QWGRAD = 2e-5
 
 

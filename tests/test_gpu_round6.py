@@ -1,0 +1,154 @@
+"""Round-6 GPU tests (all through the C ABI): the f16 three-term split at small input scales and in the backward,
+inference batch norm folded into the kernel epilogue, `bench.py --gpus N` started as given (item 3)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from deepsphere import _native, gnn_layers
+from helpers import rel_err
+from oracle import cheb_oracle as orc
+from test_gpu_round3 import _csr, _dev, _grid_ell
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_FP32_EQUIV = 2e-6  # exact fp32, the six-term bf16 split and the f16 three-term split measure 2 - 7e-7
+
+
+def _layer(cols, vals, K, Fout, W, **kw):
+    return gnn_layers.Chebyshev.from_prepared_ell(
+        cols, vals, K, Fout=Fout, device="cuda:0", initializer=lambda t: t.copy_(torch.from_numpy(W)),
+        plan_options={_native.OPT_STRIPS: _native.STRIPS_ALWAYS}, **kw)
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 3e4])
+def test_f16_split_is_fp32_equivalent_at_every_input_scale(scale):
+    """DSPH_PREC_F16X3 with the input's power-of-two factor (DSPH_OPT_F16_XEXP): 3e-7 of max|y| whatever the scale of x --
+    from the caller's bound (x_absmax) and from the layer's own reduction.  Without the factor an input of scale 1e-3 loses its
+    lo halves to f16 subnormals (measured 1.8e-5: the lower range condition of include/dsphere.h), and one of scale 3e4 overflows."""
+    K, Fin, Fout, nside, N = 5, 64, 64, 128, 2
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((N, M, Fin)) * scale).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    ref = orc.chebyshev_forward(_csr(cols, vals), x, W, K)
+    for hint in (None, float(np.abs(x).max())):
+        layer = _layer(cols, vals, K, Fout, W, precision="f16x3", x_absmax=hint)
+        with torch.no_grad():
+            y = layer(_dev(x))
+        assert layer._get_plan().strip_tiles(Fin, Fout, K, _native.PREC_F16X3, N=N) > 0, "the quad strips run this"
+        err = rel_err(y.cpu().numpy(), ref)
+        print(f"f16x3 scale {scale:g} x_absmax {hint}: exponent {layer._f16_xexp}, rel err {err:.2e}")
+        assert err < TOL_FP32_EQUIV
+    # the C ABI without the factor: what the header says of the range condition
+    plan = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
+    plan.prepare(K, Fin)
+    y0, _ = _native.cheb_forward(plan, _dev(x), _dev(W), None, K, precision=_native.PREC_F16X3, algo=_native.ALGO_FUSED)
+    e0 = rel_err(y0.cpu().numpy(), ref) if torch.isfinite(y0).all() else float("inf")
+    print(f"f16x3 scale {scale:g} without the factor: {e0:.2e}")
+    if scale == 1e-3:
+        assert e0 > 5e-6
+    if scale == 3e4:
+        assert not np.isfinite(e0), "beyond the f16 range: loud"
+    plan.set_option(_native.OPT_F16_XEXP, 3)  # any exponent is exact to apply: same bits up to the range
+    if scale == 1.0:
+        y3, _ = _native.cheb_forward(plan, _dev(x), _dev(W), None, K, precision=_native.PREC_F16X3, algo=_native.ALGO_FUSED)
+        assert rel_err(y3.cpu().numpy(), ref) < TOL_FP32_EQUIV
+    with pytest.raises(ValueError):
+        plan.set_option(_native.OPT_F16_XEXP, 1000)
+
+
+def test_f16_layer_backward_with_tiny_upstream_gradients():
+    """under precision="f16x3" the input gradient ran the quad strips on dy split into f16 as it is; a mean loss
+    over millions of pixels gives dy ~ 1e-8 (below the smallest f16 subnormal): dx came out zero on the strips' pixels.  The dx
+    contraction now runs the six-term bf16 split, the weight gradient exact fp32."""
+    K, Fin, Fout, nside, N = 5, 64, 64, 128, 1
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    dy = (rng.standard_normal((N, M, Fout)) * 1e-8).astype(np.float32)
+    layer = _layer(cols, vals, K, Fout, W, precision="f16x3")
+    xt = _dev(x).requires_grad_(True)
+    y = layer(xt)
+    y.backward(_dev(dy))
+    dx_ref, dk_ref = orc.chebyshev_backward(_csr(cols, vals), x, W, K, dy)
+    ex = rel_err(xt.grad.cpu().numpy(), dx_ref)
+    ek = rel_err(layer.kernel.grad.cpu().numpy(), dk_ref)
+    print(f"f16x3 backward, dy ~ 1e-8: dx {ex:.2e}, dkernel {ek:.2e}")
+    assert ex < TOL_FP32_EQUIV and ek < TOL_FP32_EQUIV
+    assert gnn_layers.resolve_dx_precision("f16x3", Fout, K) == "bf16x6"
+    assert gnn_layers.resolve_wgrad_precision("f16x3", N * M) == "fp32"
+
+
+@pytest.mark.parametrize("shape", [(32, 5, 16, 32, 3), (128, 5, 64, 64, 2)])
+def test_inference_batch_norm_is_folded_into_the_kernel_epilogue(shape):
+    """quick_start's layer (use_bn=True, use_bias=True, activation="elu", reference gnn_layers.py:152-159: BN -> bias -> act) in
+    inference: ONE kernel call -- the moving statistics folded into weights and bias -- against the oracle's bn=(mean, var);
+    neither the host framework's batch norm nor its activation runs.  A change of the statistics is noticed (version counters)."""
+    nside, K, Fin, Fout, N = shape
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(nside)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    layer = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=Fout, device="cuda:0", use_bn=True, use_bias=True, activation="elu",
+                                                   initializer=lambda t: t.copy_(torch.from_numpy(W)))
+    layer.build((N, M, Fin))
+    b = layer.bias.detach().cpu().numpy().reshape(-1)
+    for trial in range(2):
+        mean = rng.standard_normal(Fout).astype(np.float32) * 0.3
+        var = (0.5 + rng.random(Fout)).astype(np.float32)
+        with torch.no_grad():
+            layer.bn.running_mean.copy_(torch.from_numpy(mean))
+            layer.bn.running_var.copy_(torch.from_numpy(var))
+        ref = orc.chebyshev_forward(_csr(cols, vals), x, W, K, bias=b, activation="elu", bn=(mean, var))
+
+        def boom(*a, **k):
+            raise AssertionError("the host framework's epilogue ran in inference")
+        bn_forward, act = layer.bn.forward, layer.activation
+        layer.bn.forward, layer.activation = boom, boom
+        try:
+            with torch.no_grad():
+                y = layer(_dev(x))            # training=False: the reference's default call
+                y2 = layer(_dev(x))           # steady state: kept weight images of the folded kernel
+        finally:
+            layer.bn.forward, layer.activation = bn_forward, act
+        err = rel_err(y.cpu().numpy(), ref)
+        print(f"BN folded, nside {nside} {Fin}->{Fout} trial {trial}: rel err {err:.2e}")
+        assert err < 2e-5  # (the three-term bf16 split's tolerance, TOL_BF16X3 of the other tests: max|y| after the ELU is small)
+        assert torch.equal(y, y2)
+    # batch statistics (training=True) stay in the host framework: same layer, reference semantics
+    with torch.no_grad():
+        yt = layer(_dev(x), training=True)
+    lin = orc.chebyshev_forward(_csr(cols, vals), x, W, K)
+    mu, vv = lin.mean(axis=(0, 1)), lin.var(axis=(0, 1))
+    ref_t = orc.chebyshev_forward(_csr(cols, vals), x, W, K, bias=b, activation="elu", bn=(mu, vv))
+    assert rel_err(yt.cpu().numpy(), ref_t) < 2e-5
+    # ... and moved the moving statistics: the next inference call folds the new ones
+    with torch.no_grad():
+        y3 = layer(_dev(x))
+    m2, v2 = layer.bn.running_mean.cpu().numpy(), layer.bn.running_var.cpu().numpy()
+    ref3 = orc.chebyshev_forward(_csr(cols, vals), x, W, K, bias=b, activation="elu", bn=(m2, v2))
+    assert rel_err(y3.cpu().numpy(), ref3) < 2e-5
+
+
+def test_bench_gpus_2_as_given():
+    """`python3 bench.py --gpus 2 ...` without a launcher (the form the driver uses): bench.py starts its own ranks as a child job
+    and relays rank 0's line.  On a one-GPU box the two ranks share the GPU and stage halo rows through the host (--backend gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "c2", "--quick",
+                        "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert "contiguous NEST ranges" in rec["config"]["sharding"]

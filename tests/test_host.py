@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in dsphere.h but not exported"
     assert declared == set(_native.SIGNATURES), "ctypes table and header disagree"
-    assert lib.dsph_abi_version() == 2
+    assert lib.dsph_abi_version() == _native.ABI_VERSION == 3
 
 
 def test_bad_arguments_are_reported_not_fatal():
@@ -284,3 +284,49 @@ def test_healpy_gcnn_assembly_and_errors():
         healpy_networks.HealpyGCNN(nside=nside, indices=indices[:-3], layers=layers[:3])
     with pytest.raises(ValueError):  # too many reductions
         healpy_networks.HealpyGCNN(nside=2, indices=np.arange(48), layers=[healpy_layers.HealpyPool(p=2)])
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` as the driver gives it (no WORLD_SIZE): bench.py starts torch.distributed.run as a child
+    process, before touching the GPU, and leaves with the child's exit code.  Here (no GPU) both ranks stop at "needs a HIP
+    device" and the launcher reports the failure; on a GPU box tests/test_gpu_round6.py parses the line."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = ""  # (the same outcome on a GPU box)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "c1", "--quick"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "bench.py needs a HIP device" in r.stderr  # said by the ranks, i.e. the child job ran
+    assert "launch with torch.distributed.run" not in r.stderr + r.stdout
+    # under a launcher with another world size the mismatch is an error, not a silent replica run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c1", "--quick"],
+                        env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "--gpus 2 under WORLD_SIZE=1" in r2.stderr
+    assert "allow-replicas" not in open(os.path.join(root, "bench.py")).read()
+
+
+def test_plan_builders_under_sanitizers():
+    """SURVEY 5 / VERDICT r5 weak 10: the host halves of the library -- tile classification, class-T embedding, breadth-first ring
+    tables, rectangle merge, strip lists and the tape split, shard levels: 2,000 lines of index code in csrc/cheb_fused.hip and
+    csrc/dsphere_api.hip -- compiled with -fsanitize=address,undefined against a stub HIP runtime (`make asan`, no GPU code) and
+    driven through the C ABI on full-sphere, partial-sky, k-NN, sharded and ragged graphs (tools/asan/run_plan_builders.py)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "deepsphere-cosmo-tf2_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "asan", "-j", "4"], check=True, capture_output=True, timeout=900)
+    rt = subprocess.run(["/opt/rocm/bin/hipcc", "-print-file-name=libclang_rt.asan-x86_64.so"], check=True, capture_output=True,
+                        text=True).stdout.strip()
+    assert os.path.exists(rt), rt
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "asan", "run_plan_builders.py")], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "ASAN-DRIVER-OK" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+    assert "grid nside 128: K 5 64->64: tile_counts rc 0 struct 744 bfs 24, fused_ok 1, strip tiles [432, 432, 432]" in r.stdout

@@ -250,3 +250,65 @@ def test_sharded_training_gloo(world, K):
         assert p.exitcode == 0
     for e_dx, e_dw, e_db, e_y in res:
         assert e_dx < 1e-5 and e_dw < 1e-5 and e_db < 1e-5 and e_y < 1e-4
+
+
+def _scope_worker(rank, world, port, out):
+    """Two data-parallel ranks, each with its OWN one-rank layer (world = 1, group = None): the gradient must not be summed
+    over the job's default group.  A layer on a one-rank sub-group still goes through the collective."""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, cols, vals = _prepared_ell(4, "knn")
+        W = np.ones((2 * 3, 2), dtype=np.float32)
+        sh = sharding.ShardedChebyshev(cols, vals, 3, rank=0, world=1, kernel=W, _compute=_oracle_compute)
+        t = torch.full((4,), float(rank + 1))
+        sh._all_reduce(t)
+        own = bool(torch.equal(t, torch.full((4,), float(rank + 1))))
+        groups = [dist.new_group([r]) for r in range(world)]  # (every rank creates every group, in the same order)
+        sh1 = sharding.ShardedChebyshev(cols, vals, 3, rank=0, world=1, kernel=W, group=groups[rank], _compute=_oracle_compute)
+        t1 = torch.full((4,), float(rank + 1))
+        sh1._all_reduce(t1)
+        own = own and bool(torch.equal(t1, torch.full((4,), float(rank + 1))))
+        refused = False
+        try:  # a two-rank layer on a one-rank group is a configuration error, at construction
+            sharding.ShardedChebyshev(cols, vals, 3, rank=rank, world=2, kernel=W, group=groups[rank], _compute=_oracle_compute)
+        except ValueError:
+            refused = True
+        res = torch.tensor([1.0 if own else 0.0, 1.0 if refused else 0.0], dtype=torch.float64)
+        gathered = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, res)
+        if rank == 0:
+            out.put([g.tolist() for g in gathered])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_layer_inside_a_larger_job_keeps_its_gradient_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scope_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == [[1.0, 1.0], [1.0, 1.0]]
+
+
+def test_sharded_layer_precision_names():
+    """"f16x3" is a name every layer takes (KeyError here); its dx runs the six-term bf16 split, its dW exact fp32."""
+    _, cols, vals = _prepared_ell(4, "knn")
+    W = np.ones((2 * 3, 2), dtype=np.float32)
+    sh = sharding.ShardedChebyshev(cols, vals, 3, kernel=W, precision="f16x3", _compute=_oracle_compute)
+    assert (sh.precision, sh.precision_dx, sh.precision_dw) == (3, 2, 0)
+    sh = sharding.ShardedChebyshev(cols, vals, 3, kernel=W, precision="bf16x3", _compute=_oracle_compute)
+    assert (sh.precision, sh.precision_dx, sh.precision_dw) == (1, 1, 1)
+    with pytest.raises(ValueError):
+        sharding.ShardedChebyshev(cols, vals, 3, kernel=W, precision="fp8", _compute=_oracle_compute)
