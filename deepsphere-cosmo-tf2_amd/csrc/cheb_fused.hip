@@ -85,6 +85,20 @@ struct FusedTiles {
   int n_qstrips = 0;
   int64_t qtape_rows = 0;
   std::vector<QStrip> h_qstrips;
+  // ... addressed through tables of tile bases (round 6, build_qtstrips): the rectangles of the quad strips are found on the
+  // LOGICAL tile grid -- class-R tiles and the class-T tiles whose eight neighbour tiles continue the pixel grid by a pure
+  // translation (base-pixel borders between an equatorial and a polar face, superpixel borders of a compacted partial-sky
+  // map) -- and a strip looks its rows up as tab[tile row][tile column] + morton(x & 15, y & 15).
+  int32_t* d_qtab = nullptr;               // tile-base tables of all rectangles, back to back (row numbers)
+  std::vector<int32_t> h_qtab;
+  int64_t n_qstrip_tiles = 0;              // tiles the quad strips take
+  // what the quad strips leave to the structured kernel: class-R tiles (interior first) and class-T tiles with their tables
+  int32_t* d_qrrest = nullptr;
+  int n_qrrest = 0, n_qrrest_interior = 0;
+  int32_t* d_qtlist = nullptr;
+  int32_t* d_qtabrow = nullptr;
+  float* d_qtabvals = nullptr;
+  int n_qt = 0, n_qt_interior = 0;
   // input-side strip kernel (cheb_istrip_kernel.h): the same rectangles, uncut along y (the kernel cuts every strip into the
   // number of row segments that istrip_segments picks for the batch)
   StripPair* d_ipairs = nullptr;
@@ -189,6 +203,11 @@ static void free_tiles(FusedTiles& ft) {
   if (ft.d_pairs) (void)hipFree(ft.d_pairs);
   if (ft.d_qstrips) (void)hipFree(ft.d_qstrips);
   if (ft.d_qprefix) (void)hipFree(ft.d_qprefix);
+  if (ft.d_qtab) (void)hipFree(ft.d_qtab);
+  if (ft.d_qrrest) (void)hipFree(ft.d_qrrest);
+  if (ft.d_qtlist) (void)hipFree(ft.d_qtlist);
+  if (ft.d_qtabrow) (void)hipFree(ft.d_qtabrow);
+  if (ft.d_qtabvals) (void)hipFree(ft.d_qtabvals);
   if (ft.d_rrest) (void)hipFree(ft.d_rrest);
   if (ft.d_nonq) (void)hipFree(ft.d_nonq);
   if (ft.d_all) (void)hipFree(ft.d_all);
@@ -601,6 +620,206 @@ static void build_strips(const std::vector<int32_t>& r_interior, int D, int num_
 #endif
 }
 
+
+// ---- table-addressed quad strips (round 6) ----------------------------------------------------------------------------------
+// A candidate tile of the logical grid: its eight neighbour TILES by direction (kDirX / kDirY order: W NW N NE E SE S SW), each
+// verified to continue this tile's own 16 x 16 Morton square by a pure translation over the D rows / columns a strip's halo
+// reaches into it.  Class R: the neighbours of the virtual Morton plane (what the classification verified).  Class T: read off
+// the embedding embed_tile() found and verified (row[] = the row of every plane cell).
+struct QCand {
+  int32_t tile;
+  int32_t nbr[8];
+  int32_t tix;       // position in the class-T list (tables), -1 for a class-R tile
+  int32_t sheet, u, v;
+  bool taken;
+};
+
+static bool links_from_table(const int32_t* row, int D, int32_t ntiles, int32_t nbr[8]) {
+  static const int ddx[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, ddy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+  for (int d = 0; d < 8; ++d) {
+    const int xa = ddx[d] < 0 ? ST_DMAX - D : (ddx[d] == 0 ? ST_DMAX : ST_DMAX + ST_TILE);
+    const int xb = ddx[d] < 0 ? ST_DMAX : (ddx[d] == 0 ? ST_DMAX + ST_TILE : ST_DMAX + ST_TILE + D);
+    const int ya = ddy[d] < 0 ? ST_DMAX - D : (ddy[d] == 0 ? ST_DMAX : ST_DMAX + ST_TILE);
+    const int yb = ddy[d] < 0 ? ST_DMAX : (ddy[d] == 0 ? ST_DMAX + ST_TILE : ST_DMAX + ST_TILE + D);
+    int64_t base = -1;
+    for (int y = ya; y < yb; ++y)
+      for (int x = xa; x < xb; ++x) {
+        const int64_t r = row[st_cell_off((unsigned)x, (unsigned)y) / 64u];
+        const int64_t b = r - (int64_t)st_morton((unsigned)(x - ST_DMAX) & 15u, (unsigned)(y - ST_DMAX) & 15u);
+        if (b < 0 || (b & (FUSED_P - 1)) != 0 || (base >= 0 && b != base)) return false;
+        base = b;
+      }
+    if (base < 0 || base / FUSED_P >= ntiles) return false;
+    nbr[d] = (int32_t)(base / FUSED_P);
+  }
+  return true;
+}
+
+// What a rectangle of w x h tiles saves against the tile kernels, in units of 0.1 us of one CU and one map (the constants of
+// strips_apply: 18.7 us per tile, 2.8 us per strip step): strips of 56 output columns, 2 D + 1 run-in steps each.
+static int64_t qt_gain(int w, int h, int D) {
+  const int64_t ns = (16 * (int64_t)w + QS_USE - 1) / QS_USE;
+  return (int64_t)w * h * 187 - ns * (16 * (int64_t)h + 2 * D + 1) * 28;
+}
+
+// Rectangles of candidate tiles on the logical grid and their strips.  cands: every interior class-R tile and every eligible
+// interior class-T tile.  Out: strips (coordinates relative to the rectangle's table: the rectangle's first pixel is (16, 16)),
+// the tables, `taken` set in cands.
+static void build_qtstrips(std::vector<QCand>& cands, int32_t ntiles, int D, std::vector<QStrip>& strips, std::vector<int32_t>& tab,
+                           int64_t* n_taken) {
+  strips.clear();
+  tab.clear();
+  *n_taken = 0;
+  const int n = (int)cands.size();
+  if (n == 0) return;
+  std::vector<int32_t> cand_of((size_t)ntiles, -1);
+  for (int i = 0; i < n; ++i) cand_of[(size_t)cands[i].tile] = i;
+  static const int ddx[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, ddy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+  auto cand_at = [&](int32_t tile) -> int { return tile >= 0 && tile < ntiles ? cand_of[(size_t)tile] : -1; };
+  // sheets: logical coordinates by breadth-first search over the four axis links that both ends agree on
+  std::unordered_map<uint64_t, int32_t> at;  // (sheet, u, v) -> candidate
+  constexpr int64_t OFF = 1 << 20;
+  auto key_of = [&](int32_t sheet, int64_t u, int64_t v) { return ((uint64_t)sheet << 44) | ((uint64_t)(u + OFF) << 22) | (uint64_t)(v + OFF); };
+  int32_t nsheets = 0;
+  std::vector<int32_t> queue;
+  for (int i = 0; i < n; ++i) cands[i].sheet = -1;
+  for (int i0 = 0; i0 < n; ++i0) {
+    if (cands[i0].sheet >= 0) continue;
+    if (nsheets >= (1 << 19)) break;
+    const int32_t sh = nsheets++;
+    cands[i0].sheet = sh; cands[i0].u = 0; cands[i0].v = 0;
+    at[key_of(sh, 0, 0)] = i0;
+    queue.assign(1, i0);
+    for (size_t h = 0; h < queue.size(); ++h) {
+      const QCand a = cands[(size_t)queue[h]];
+      for (int d = 0; d < 8; d += 2) {
+        const int b = cand_at(a.nbr[d]);
+        if (b < 0 || cands[(size_t)b].sheet >= 0 || cands[(size_t)b].nbr[(d + 4) & 7] != a.tile) continue;
+        const int64_t u = (int64_t)a.u + ddx[d], v = (int64_t)a.v + ddy[d];
+        if (u <= -OFF + 2 || u >= OFF - 2 || v <= -OFF + 2 || v >= OFF - 2) continue;
+        const uint64_t k = key_of(sh, u, v);
+        if (at.find(k) != at.end()) continue;  // (a sphere unrolled onto the plane meets itself again: the place is taken)
+        cands[(size_t)b].sheet = sh; cands[(size_t)b].u = (int32_t)u; cands[(size_t)b].v = (int32_t)v;
+        at[k] = b;
+        queue.push_back(b);
+      }
+    }
+  }
+  // per sheet: occupancy grid over the bounding box, greedy extraction of the rectangle with the largest gain
+  std::vector<std::vector<int32_t>> members((size_t)nsheets);
+  for (int i = 0; i < n; ++i)
+    if (cands[i].sheet >= 0) members[(size_t)cands[i].sheet].push_back(i);
+  for (int32_t sh = 0; sh < nsheets; ++sh) {
+    const std::vector<int32_t>& mem = members[(size_t)sh];
+    if (mem.size() < 6) continue;
+    int u0 = 1 << 30, u1 = -(1 << 30), v0 = 1 << 30, v1 = -(1 << 30);
+    for (int32_t i : mem) { u0 = std::min(u0, cands[(size_t)i].u); u1 = std::max(u1, cands[(size_t)i].u); v0 = std::min(v0, cands[(size_t)i].v); v1 = std::max(v1, cands[(size_t)i].v); }
+    const int64_t GW = (int64_t)u1 - u0 + 1, GH = (int64_t)v1 - v0 + 1;
+    if (GW * GH > (1ll << 26)) continue;  // (a sheet that sprawls: left to the tile kernels)
+    std::vector<int32_t> grid((size_t)(GW * GH), -1);  // candidate index, -1 empty, -2 blocked
+    for (int32_t i : mem) grid[(size_t)((cands[(size_t)i].v - v0) * GW + (cands[(size_t)i].u - u0))] = i;
+    std::vector<int32_t> hgt((size_t)GW);
+    std::vector<std::pair<int, int>> stack;  // (start column, height)
+    for (;;) {
+      // the best (gain) rectangle of free cells: histogram of free runs along v, one sweep per row
+      int64_t best = 0;
+      int bu = 0, bv = 0, bw = 0, bh = 0;
+      std::fill(hgt.begin(), hgt.end(), 0);
+      for (int64_t y = 0; y < GH; ++y) {
+        for (int64_t x = 0; x < GW; ++x) hgt[(size_t)x] = grid[(size_t)(y * GW + x)] >= 0 ? hgt[(size_t)x] + 1 : 0;
+        stack.clear();
+        for (int64_t x = 0; x <= GW; ++x) {
+          const int hx = x < GW ? hgt[(size_t)x] : 0;
+          int start = (int)x;
+          while (!stack.empty() && stack.back().second > hx) {
+            const int s0 = stack.back().first, hh = stack.back().second;
+            stack.pop_back();
+            const int wmax = (int)x - s0;
+            // the widest rectangle of this height, or one a few columns narrower where the last strip would be nearly empty
+            for (int w = std::min(wmax, 1000); w >= std::max(1, std::min(wmax, 1000) - 3); --w) {  // (1,000: the kernels keep a tile column in ten bits)
+              const int64_t g = qt_gain(w, hh, D);
+              if (g > best) { best = g; bu = s0; bv = (int)y - hh + 1; bw = w; bh = hh; }
+            }
+            start = s0;
+          }
+          if (hx > 0 && (stack.empty() || stack.back().second < hx)) stack.push_back({start, hx});
+        }
+      }
+      if (best <= 0) break;
+      // the table of tile bases: the rectangle and one ring of tiles around it
+      const int TW = bw + 2, TH = bh + 2;
+      std::vector<int32_t> t((size_t)TW * TH, -1);
+      bool good = true;
+      auto inside = [&](int i, int j) { return i >= 1 && i <= bw && j >= 1 && j <= bh; };
+      for (int j = 1; j <= bh && good; ++j)
+        for (int i = 1; i <= bw && good; ++i) {
+          const int32_t c = grid[(size_t)((bv + j - 1) * GW + (bu + i - 1))];
+          const QCand& q = cands[(size_t)c];
+          t[(size_t)j * TW + i] = q.tile;
+          for (int d = 0; d < 8 && good; ++d) {
+            const int i2 = i + ddx[d], j2 = j + ddy[d];
+            int32_t& slot = t[(size_t)j2 * TW + i2];
+            if (inside(i2, j2)) {  // the neighbour inside the rectangle must be the tile the grid holds there
+              const int32_t c2 = grid[(size_t)((bv + j2 - 1) * GW + (bu + i2 - 1))];
+              if (cands[(size_t)c2].tile != q.nbr[d]) good = false;
+            } else if (slot < 0) slot = q.nbr[d];
+            else if (slot != q.nbr[d]) good = false;  // two tiles of the rectangle name different tiles for one place of the ring
+          }
+        }
+      if (!good) {  // (a seam the sheet's coordinates paper over: these tiles stay with the tile kernels)
+        for (int j = 0; j < bh; ++j)
+          for (int i = 0; i < bw; ++i) grid[(size_t)((bv + j) * GW + (bu + i))] = -2;
+        continue;
+      }
+      const int32_t toff = (int32_t)tab.size();
+      for (int32_t tile : t) tab.push_back(tile < 0 ? 0 : tile * FUSED_P);  // (the four corners of the ring of a 1-wide rectangle ... are never -1: every ring place has a neighbour inside)
+      for (int j = 0; j < bh; ++j)
+        for (int i = 0; i < bw; ++i) {
+          int32_t& c = grid[(size_t)((bv + j) * GW + (bu + i))];
+          cands[(size_t)c].taken = true;
+          c = -2;
+        }
+      *n_taken += (int64_t)bw * bh;
+      const int X0 = 16, X1 = 16 + 16 * bw, Y0 = 16, Y1 = 16 + 16 * bh;
+      for (int x0 = X0; x0 < X1; x0 += QS_USE) {
+        QStrip q{};
+        q.x0 = x0; q.w = std::min(QS_USE, X1 - x0); q.xs = x0 - D;
+        q.y0 = Y0; q.y1 = Y1;
+        q.xlo = X0 - D; q.xhi = X1 - 1 + D; q.ylo = Y0 - D; q.yhi = Y1 - 1 + D;
+        q.tab = toff; q.tws = TW;
+        strips.push_back(q);
+      }
+    }
+  }
+  // The kernel cuts the tape of all strips' rows into equal pieces, and a piece pays 2 D + 1 run-in steps for every strip that
+  // begins in it: the greedy extraction leaves the low strips (a few tiles high) at the end of the list, where a piece would
+  // hold dozens of them (measured at the headline map: the last pieces took 14 % longer than the first, and the forward with
+  // them).  So the low strips are dealt out evenly between the tall ones, by rows.
+  {
+    std::vector<QStrip> tall, low;
+    int64_t rows_tall = 0, rows_low = 0;
+    for (const QStrip& q : strips) {
+      if (q.y1 - q.y0 >= 256) { tall.push_back(q); rows_tall += q.y1 - q.y0; }
+      else { low.push_back(q); rows_low += q.y1 - q.y0; }
+    }
+    if (!tall.empty() && !low.empty()) {
+      strips.clear();
+      size_t li = 0;
+      int64_t done_tall = 0, done_low = 0;
+      for (const QStrip& q : tall) {
+        strips.push_back(q);
+        done_tall += q.y1 - q.y0;
+        while (li < low.size() && done_low * rows_tall < rows_low * done_tall) {
+          strips.push_back(low[li]);
+          done_low += low[li].y1 - low[li].y0;
+          ++li;
+        }
+      }
+      for (; li < low.size(); ++li) strips.push_back(low[li]);
+    }
+  }
+}
+
 // Breadth-first rings of every tile; uploads the tables.  Returns a reference to the cached entry.
 // full: BFS tables of every tile (planes / weight-gradient modes of the BFS kernel); otherwise the tiles are first
 // classified and only the class-G ones (not a plain 2-D stencil square) get BFS tables, the rest go to d_rlist.
@@ -868,9 +1087,76 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   ft.strip_forced = plan->opt.strips == 1;
   std::vector<QStrip> qstrips;
   if (!full && D <= SP_DMAX && plan->opt.strips != 2)
-    build_strips(r_interior, D, fp->num_cu, plan->opt, pairs, rrest, &ft.n_strip_tiles, ft.strip_steps, ipairs, &qstrips);
+    build_strips(r_interior, D, fp->num_cu, plan->opt, pairs, rrest, &ft.n_strip_tiles, ft.strip_steps, ipairs, nullptr);
   else
     rrest = r_interior;
+  // The quad strips (K = 5): rectangles on the logical tile grid, addressed through tables (build_qtstrips) -- every interior
+  // class-R tile and every interior class-T tile whose eight neighbour tiles are pure translations.
+  std::vector<int32_t> qtab, qrrest, qt_list, qt_rows;
+  std::vector<float> qt_vals;
+  std::vector<int32_t> patch_rows;
+  std::vector<float> patch_vals;
+  ft.n_qstrip_tiles = 0;
+  if (!full && D == QS_D && plan->opt.strips != 2 && plan->opt.strip_form == 0 && fp->d_gvals8 != nullptr) {
+    std::vector<QCand> cands;
+    cands.reserve(r_interior.size() + t_interior.size());
+    static const int ddx[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, ddy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+    for (int32_t t : r_interior) {
+      QCand c{};
+      c.tile = t; c.tix = -1; c.taken = false;
+      const int tx = (int)st_compress((unsigned)t), ty = (int)st_compress((unsigned)t >> 1);
+      for (int d = 0; d < 8; ++d) {
+        const int nx = tx + ddx[d], ny = ty + ddy[d];
+        const int64_t nt = nx < 0 || ny < 0 ? -1 : (int64_t)st_morton((unsigned)nx, (unsigned)ny);
+        c.nbr[d] = nt >= 0 && nt < ntiles ? (int32_t)nt : -1;
+      }
+      cands.push_back(c);
+    }
+    const size_t n_rc = cands.size();
+    for (size_t i = 0; i < t_interior.size(); ++i) {
+      QCand c{};
+      c.tile = t_interior[i]; c.tix = (int32_t)i; c.taken = false;
+      if (links_from_table(&trow_i[i * ST_CELLS], D, ntiles, c.nbr)) cands.push_back(c);
+    }
+    build_qtstrips(cands, ntiles, D, qstrips, qtab, &ft.n_qstrip_tiles);
+    std::vector<unsigned char> t_taken(t_interior.size(), 0);
+    for (size_t i = 0; i < cands.size(); ++i) {
+      if (i < n_rc) { if (!cands[i].taken) qrrest.push_back(cands[i].tile); }
+      else if (cands[i].taken) t_taken[(size_t)cands[i].tix] = 1;
+    }
+    // (r_interior is sorted; cands keeps its order)
+    ft.n_qrrest_interior = (int)qrrest.size();
+    qrrest.insert(qrrest.end(), r_boundary.begin(), r_boundary.end());
+    for (size_t i = 0; i < t_interior.size(); ++i) {
+      if (!t_taken[i]) {
+        qt_list.push_back(t_interior[i]);
+        qt_rows.insert(qt_rows.end(), trow_i.begin() + i * ST_CELLS, trow_i.begin() + (i + 1) * ST_CELLS);
+        qt_vals.insert(qt_vals.end(), tval_i.begin() + i * ST_CELLS * ST_TABV, tval_i.begin() + (i + 1) * ST_CELLS * ST_TABV);
+        continue;
+      }
+      // a class-T tile on the strips: the strips read L~ by direction from gvals8 / gdiag, which the row pass filled from
+      // the VIRTUAL Morton plane (a neighbour beyond a base-pixel border has no direction there and was dropped).  The
+      // tile's verified embedding has every evaluated row's values by direction: written over the rows' entries (no other
+      // kernel reads them for rows that are irregular in the virtual plane; for regular rows the two agree).
+      const int blo = ST_DMAX - D + 1, bhi = ST_DMAX + ST_TILE - 1 + D - 1;  // rings 0 .. D-1
+      for (int y = blo; y <= bhi; ++y)
+        for (int x = blo; x <= bhi; ++x) {
+          const size_t cell = i * ST_CELLS + st_cell_off((unsigned)x, (unsigned)y) / 64u;
+          patch_rows.push_back(trow_i[cell]);
+          patch_vals.insert(patch_vals.end(), tval_i.begin() + cell * ST_TABV, tval_i.begin() + cell * ST_TABV + 9);
+        }
+    }
+    ft.n_qt_interior = (int)qt_list.size();
+    qt_list.insert(qt_list.end(), t_boundary.begin(), t_boundary.end());
+    qt_rows.insert(qt_rows.end(), trow_b.begin(), trow_b.end());
+    qt_vals.insert(qt_vals.end(), tval_b.begin(), tval_b.end());
+  }
+  ft.n_qrrest = (int)qrrest.size();
+  ft.n_qt = (int)qt_list.size();
+  if (qrrest.empty()) qrrest.push_back(0);
+  if (qt_list.empty()) { qt_list.push_back(0); qt_rows.push_back(0); qt_vals.push_back(0.f); }
+  ft.h_qtab = qtab;
+  qtab.resize(qtab.size() + 8, 0);  // (a lane's five tile columns are read by scalar loads from the strip's first column on: readable past the end)
   ft.n_pairs = (int)pairs.size();
   ft.h_pairs = pairs;
   ft.n_qstrips = (int)qstrips.size();
@@ -891,9 +1177,15 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
   ft.n_rrest_interior = (int)rrest.size();
   rrest.insert(rrest.end(), r_boundary.begin(), r_boundary.end());
   ft.n_rrest = (int)rrest.size();
-  std::vector<int32_t> nonq(rrest);
-  nonq.insert(nonq.end(), t_interior.begin(), t_interior.end());
-  nonq.insert(nonq.end(), t_boundary.begin(), t_boundary.end());
+  // every tile the QUAD strips leave over, whatever its class
+  std::vector<int32_t> nonq(qrrest.begin(), qrrest.begin() + ft.n_qrrest);
+  nonq.insert(nonq.end(), qt_list.begin(), qt_list.begin() + ft.n_qt);
+  if (ft.n_qstrip_tiles == 0) {  // (no quad strips: the list is not used; keep it the complement of nothing)
+    nonq.assign(r_interior.begin(), r_interior.end());
+    nonq.insert(nonq.end(), r_boundary.begin(), r_boundary.end());
+    nonq.insert(nonq.end(), t_interior.begin(), t_interior.end());
+    nonq.insert(nonq.end(), t_boundary.begin(), t_boundary.end());
+  }
   nonq.insert(nonq.end(), interior.begin(), interior.begin() + ft.n_part);
   ft.n_nonq = (int)nonq.size();
   if (nonq.empty()) nonq.push_back(0);
@@ -926,7 +1218,13 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
               up((void**)&ft.d_pairs, pairs.data(), pairs.size() * sizeof(StripPair)) &&
               up((void**)&ft.d_qstrips, qstrips.data(), qstrips.size() * sizeof(QStrip)) &&
               up((void**)&ft.d_qprefix, qprefix.data(), qprefix.size() * 4) &&
+              up((void**)&ft.d_qtab, qtab.data(), qtab.size() * 4) &&
+              up((void**)&ft.d_qrrest, qrrest.data(), qrrest.size() * 4) &&
+              up((void**)&ft.d_qtlist, qt_list.data(), qt_list.size() * 4) &&
+              up((void**)&ft.d_qtabrow, qt_rows.data(), qt_rows.size() * 4) &&
+              up((void**)&ft.d_qtabvals, qt_vals.data(), qt_vals.size() * 4) &&
               up((void**)&ft.d_ipairs, ipairs.data(), ipairs.size() * sizeof(StripPair));
+  if (good && !patch_rows.empty()) good = struct_patch_rows(plan, fp->d_gvals8, fp->d_gdiag, patch_rows.data(), patch_vals.data(), (int64_t)patch_rows.size()) == DSPH_OK;
   if (!good) {
     FusedTiles keep = ft;
     free_tiles(ft);
@@ -1077,16 +1375,17 @@ static bool use_qstrips(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin
 }
 static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t N,
                          int32_t ld) {
-  if (!(ft.n_pairs > 0 && (precision == DSPH_PREC_BF16X3 || (precision == DSPH_PREC_F16X3 && use_qstrips(plan, ft, Fin, Fout, K))) &&
+  const bool quad = use_qstrips(plan, ft, Fin, Fout, K);
+  if (!((quad || ft.n_pairs > 0) && (precision == DSPH_PREC_BF16X3 || (precision == DSPH_PREC_F16X3 && quad)) &&
         strip_shape_ok(Fin, Fout, K) && ld % 4 == 0 && plan->n_cols * (int64_t)std::max(Fin, ld) * 4 < (1ll << 32)))
     return false;
   if (ft.strip_forced) return true;
   FusedPlan* fp = plan->fused;
-  if (use_qstrips(plan, ft, Fin, Fout, K)) {
+  if (quad) {
     // (a quad-strip step takes 2.8 us, a tile-map 18.7; the tape of rows is cut evenly, so the span is a formula)
     if (N < 1) return false;
     const int64_t span = qstrip_split(fp->num_cu, ft.qtape_rows, N, ft.qtape_rows / std::max(1, ft.n_qstrips), nullptr, nullptr, nullptr);
-    return span * 28 * 103 < ft.n_strip_tiles * N * 187 / fp->num_cu * 100;
+    return span * 28 * 103 < ft.n_qstrip_tiles * N * 187 / fp->num_cu * 100;
   }
   const std::vector<int32_t>& steps = ft.strip_steps;
   if (N < 1 || (int64_t)steps.size() * N > (1ll << 24)) return false;
@@ -1141,7 +1440,7 @@ int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t
   if (Fin != pad4(Fin) || Fout < 64) return 0;
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
   if (!ft.ok) return 0;
-  return strips_apply(plan, ft, Fin, 64, K, precision, N, Fout) ? ft.n_strip_tiles : 0;
+  return strips_apply(plan, ft, Fin, 64, K, precision, N, Fout) ? (use_qstrips(plan, ft, Fin, 64, K) ? ft.n_qstrip_tiles : ft.n_strip_tiles) : 0;
 }
 
 // the strip pairs of the K-term tables, 12 int32 each: x0[2], w[2], xs[2], y0, y1, xlo, xhi, ylo, yhi (StripPair); returns how
@@ -1162,6 +1461,26 @@ int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_
   }
   const int64_t n = (int64_t)ft.h_pairs.size();
   for (int64_t i = 0; i < n && i < cap; ++i) memcpy(out + 12 * i, &ft.h_pairs[(size_t)i], sizeof(StripPair));
+  return n;
+}
+
+// rows of n pixels of strip record `strip` (dsph_plan_strip_rows): through the rectangle's table for the quad strips, the
+// virtual Z-order plane for the strip pairs; -1 when there is no such record
+int64_t fused_strip_rows(const dsph_plan* plan, int32_t K, int64_t strip, int64_t n, const int32_t* xy, int64_t* rows) {
+  if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return -1;
+  const FusedTiles& ft = get_tiles(plan, K - 1, false);
+  if (!ft.ok || strip < 0) return -1;
+  if (plan->opt.strip_form == 0 && K == 5 && !ft.h_qstrips.empty()) {
+    if (strip >= (int64_t)ft.h_qstrips.size()) return -1;
+    const QStrip& q = ft.h_qstrips[(size_t)strip];
+    for (int64_t i = 0; i < n; ++i) {
+      const int x = std::min(std::max(xy[2 * i], q.xlo), q.xhi), y = std::min(std::max(xy[2 * i + 1], q.ylo), q.yhi);
+      rows[i] = (int64_t)ft.h_qtab[(size_t)(q.tab + (y >> 4) * q.tws + (x >> 4))] + (int64_t)st_morton((unsigned)x & 15u, (unsigned)y & 15u);
+    }
+    return n;
+  }
+  if (strip >= (int64_t)ft.h_pairs.size()) return -1;
+  for (int64_t i = 0; i < n; ++i) rows[i] = (int64_t)st_morton((unsigned)xy[2 * i], (unsigned)xy[2 * i + 1]);
   return n;
 }
 
@@ -1534,7 +1853,7 @@ int launch_cheb_fused_qwgrad(const dsph_plan* plan, const float* x, const float*
     QWgradLaunch q;
     q.x = x; q.dy = dy + cb; q.dw = dw + cb;
     q.slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + bfs_slab_bytes);
-    q.strips = ft.d_qstrips; q.prefix = ft.d_qprefix; q.tape_rows = ft.qtape_rows;
+    q.strips = ft.d_qstrips; q.prefix = ft.d_qprefix; q.tape_rows = ft.qtape_rows; q.tab = ft.d_qtab;
     q.gvals8 = plan->fused->d_gvals8; q.gdiag = plan->fused->d_gdiag;
     q.x_rows = plan->n_cols; q.dy_rows = plan->n_rows; q.N = N;
     q.nstrips = ft.n_qstrips; q.lddy = Fout; q.lddw = Fout; q.num_cu = plan->fused->num_cu;
@@ -1605,6 +1924,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       qs.wimg = static_cast<unsigned char*>(workspace) + wb + struct_wfrag_bytes(Fin, Fout, K) + strip_wimg_bytes(Fin, Fout, K) +
                 2 * istrip_wimg_bytes(K, DSPH_PREC_BF16X6);
       qs.strips = ft.d_qstrips;
+      qs.tab = ft.d_qtab;
       qs.prefix = ft.d_qprefix;
       qs.tape_rows = ft.qtape_rows;
       qs.gvals8 = plan->fused->d_gvals8;
@@ -1658,8 +1978,9 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       if (rc != DSPH_OK) return rc;
     }
     const bool stripped = strips || istrips;
-    const int32_t* rl = stripped ? ft.d_rrest : ft.d_rlist;
-    const int rl_n = stripped ? ft.n_rrest : ft.n_r, rl_ni = stripped ? ft.n_rrest_interior : ft.n_r_interior;
+    const bool qrest = strips && use_qstrips(plan, ft, Fin, Fout, K);  // the quad strips took class-T tiles too: their own rest lists
+    const int32_t* rl = qrest ? ft.d_qrrest : (stripped ? ft.d_rrest : ft.d_rlist);
+    const int rl_n = qrest ? ft.n_qrrest : (stripped ? ft.n_rrest : ft.n_r), rl_ni = qrest ? ft.n_qrrest_interior : (stripped ? ft.n_rrest_interior : ft.n_r_interior);
     const int nr = part == 0 ? rl_n : (part == 1 ? rl_ni : rl_n - rl_ni);
     if (nr > 0 && !dbg_only('b')) {
       sl.tiles = part == 2 ? rl + rl_ni : rl;
@@ -1671,12 +1992,13 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       const int rc = launch_cheb_struct(sl, stream);
       if (rc != DSPH_OK) return rc;
     }
-    const int nt = part == 0 ? ft.n_t : (part == 1 ? ft.n_t_interior : ft.n_t - ft.n_t_interior);
+    const int n_t = qrest ? ft.n_qt : ft.n_t, n_t_interior = qrest ? ft.n_qt_interior : ft.n_t_interior;
+    const int nt = part == 0 ? n_t : (part == 1 ? n_t_interior : n_t - n_t_interior);
     if (nt > 0 && !dbg_only('b')) {
-      const size_t first = part == 2 ? (size_t)ft.n_t_interior : 0;
-      sl.tiles = ft.d_tlist + first;
-      sl.tabrow = ft.d_tabrow + first * ST_CELLS;
-      sl.tabvals = ft.d_tabvals + first * ST_CELLS * ST_TABV;
+      const size_t first = part == 2 ? (size_t)n_t_interior : 0;
+      sl.tiles = (qrest ? ft.d_qtlist : ft.d_tlist) + first;
+      sl.tabrow = (qrest ? ft.d_qtabrow : ft.d_tabrow) + first * ST_CELLS;
+      sl.tabvals = (qrest ? ft.d_qtabvals : ft.d_tabvals) + first * ST_CELLS * ST_TABV;
       sl.ntiles = nt;
       sl.prep_weights = struct_prep && fused_images_claim(plan, workspace, IMG_STRUCT);
       struct_prep = false;

@@ -103,6 +103,7 @@ int launch_cheb_qstrip(const QStripLaunch& s, hipStream_t stream) {
   a.gvals8 = s.gvals8;
   a.gdiag = s.gdiag;
   a.strips = s.strips;
+  a.tab = s.tab;
   a.prefix = s.prefix;
   a.x_rows = s.x_rows;
   a.y_rows = s.y_rows;

@@ -62,7 +62,9 @@ struct QStrip {
   int32_t y0, y1;     // output rows [y0, y1)
   int32_t xlo, xhi;   // the rectangle and its halo
   int32_t ylo, yhi;
-  int32_t pad[3];
+  int32_t tab, tws;   // the rectangle's table of tile bases (offset into QStripArgs::tab) and its row stride: pixel (x, y) of the
+                      // strip's plane is row tab[(y >> 4) * tws + (x >> 4)] + morton(x & 15, y & 15)
+  int32_t pad[1];
 };
 
 struct QStripArgs {
@@ -73,6 +75,7 @@ struct QStripArgs {
   const float* gvals8;        // [rows][8] values of L~ by direction (kDirX / kDirY order)
   const float* gdiag;         // [rows]
   const QStrip* strips;
+  const int32_t* tab;         // tile-base tables of the strips' rectangles (QStrip::tab, ::tws): row numbers of 16 x 16 Morton squares
   const int32_t* prefix;      // [nstrips + 1] rows of the strips before strip s (the "tape" of one map; prefix[nstrips] = all rows)
   int64_t x_rows, y_rows;
   int nstrips, N, Fin, Fout, ld, act;
@@ -286,7 +289,13 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       const int mid = (lo + hi) >> 1;
       if ((int64_t)a.prefix[mid] <= r) lo = mid; else hi = mid;
     }
-    st = a.strips[lo];
+    {  // (the record through scalar registers: every field is wave-uniform, and the compiler should know -- rows, clamps and the
+       // table look-ups' branches then run on the scalar unit)
+      const QStrip g = a.strips[lo];
+#define QS_U(f) st.f = __builtin_amdgcn_readfirstlane(g.f)
+      QS_U(x0); QS_U(w); QS_U(xs); QS_U(y0); QS_U(y1); QS_U(xlo); QS_U(xhi); QS_U(ylo); QS_U(yhi); QS_U(tab); QS_U(tws);
+#undef QS_U
+    }
     const int h = st.y1 - st.y0;
     const int off = (int)(r - (int64_t)a.prefix[lo]);
     const int len = (int)(((int64_t)(h - off) < r_end - r) ? (int64_t)(h - off) : r_end - r);
@@ -323,7 +332,30 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
                                  : (unsigned)(lane >> 5) * 64u + (unsigned)(2 * ((lane >> 4) & 1) + (lane & 1)) * 16u;
   const unsigned x_loff = (unsigned)xt * QS_FRAG + (unsigned)(lane & 1) * 8u +
                           (X_BY_H ? (unsigned)(xpix + 16 * (lane >> 5)) * 16u : (unsigned)(xpix + 16 * (2 * (lane >> 5) + ((lane >> 4) & 1))) * 16u);
-  auto xfetch = [&](const char* xmap, unsigned sXf, unsigned sY, qs_f4 (&xv)[XN]) __attribute__((always_inline)) {
+  // Where a pixel of the strip's plane lives: row = tab[(y >> 4) tws + (x >> 4)] + morton(x & 15, y & 15) -- the rectangle's table
+  // of tile bases (cheb_fused.hip, build_qtstrips: a rectangle may cross base-pixel borders that continue the pixel grid by a
+  // translation; inside a base pixel the table is the Morton plane itself).  A strip's 64 columns lie in at most five tile
+  // columns, the row y is wave-uniform: the five bases of a tile row come by SCALAR loads (they share no counter with the
+  // vector memory: a vector load here would wait for the previous step's y stores to drain -- measured, 12 % of the forward),
+  // a lane keeps the one of its column (ci = its tile column - the strip's first) -- looked up when a row enters a new tile
+  // row, every sixteenth step.
+  typedef int qs_i4 __attribute__((ext_vector_type(4)));
+  auto tab_lane = [&](const QStrip& st, unsigned ci, int yrow) __attribute__((always_inline)) -> unsigned {
+    const int yc = min(max(yrow, st.ylo), st.yhi);
+    const int32_t* trow = a.tab + __builtin_amdgcn_readfirstlane(st.tab + (yc >> 4) * st.tws + (max(st.xs, st.xlo) >> 4));
+    qs_i4 b;
+    int b4;
+    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(b), "=&s"(b4) : "s"(trow) : "memory");
+    return (unsigned)(ci == 0 ? b[0] : ci == 1 ? b[1] : ci == 2 ? b[2] : ci == 3 ? b[3] : b4);
+  };
+  auto tab_new_row = [&](const QStrip& st, int yrow) __attribute__((always_inline)) -> bool {  // does row yrow start a tile row of the table
+    return yrow > st.ylo && yrow <= st.yhi && (yrow & 15) == 0;
+  };
+  auto row_in = [&](const QStrip& st, unsigned base, unsigned mX, int yrow) __attribute__((always_inline)) -> unsigned {
+    const int yc = min(max(yrow, st.ylo), st.yhi);
+    return base + (mX | (st_spread((unsigned)yc & 15u) << 1));
+  };
+  auto xfetch = [&](const char* xmap, unsigned xrow, qs_f4 (&xv)[XN]) __attribute__((always_inline)) {
     if (QS_ABL & 8) {
 #pragma unroll
       for (int i = 0; i < XN; ++i) xv[i] = qs_f4{0.f, 0.f, 0.f, 0.f};
@@ -332,7 +364,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
     // (plain loads: the compiler knows the data is in flight, keeps the registers out of other use and counts vmcnt itself;
     // the asm statements around them keep the requests where they are written -- see cheb_qwgrad_kernel.h for what loads
     // inside asm statements did there)
-    const char* src = xmap + (size_t)((sXf | sY) * xrowb + x_goff);
+    const char* src = xmap + (size_t)(xrow * xrowb + x_goff);
 #pragma unroll
     for (int i = 0; i < XN; ++i) xv[i] = *reinterpret_cast<const qs_f4*>(src + (X_BY_H ? 64 : 128) * i);
   };
@@ -498,12 +530,12 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       QStrip st;
       tr += locate(tr, tape_end, st);
       for (int nq = map0; nq < a.N; nq += a.wg_per_piece) {
-      const unsigned sXc = st_spread((unsigned)min(max(st.xs + 4 * p + oq, st.xlo), st.xhi));         // L~: pixel 4 p + oq
-      const unsigned sXf = st_spread((unsigned)min(max(st.xs + 4 * xpix + xt, st.xlo), st.xhi));      // x: pixel 4 xpix + xt
+      const int Xc = min(max(st.xs + 4 * p + oq, st.xlo), st.xhi);         // L~: pixel 4 p + oq
+      const int Xf = min(max(st.xs + 4 * xpix + xt, st.xlo), st.xhi);      // x: pixel 4 xpix + xt
+      const int tc0 = max(st.xs, st.xlo) >> 4;  // the strip's first tile column
+      const unsigned ciC = (unsigned)((Xc >> 4) - tc0), mXc = st_spread((unsigned)Xc & 15u);
+      const unsigned ciF = (unsigned)((Xf >> 4) - tc0), mXf = st_spread((unsigned)Xf & 15u);
       const int T3 = ((st.y1 - st.y0) + 2 * D + 1 + 3) / 3;
-      auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
-        return st_spread((unsigned)min(max(yrow, st.ylo), st.yhi)) << 1;
-      };
       const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)nq * a.x_rows * xrowb;
       QRow R[2][3];
 #pragma unroll
@@ -517,13 +549,15 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       {
         qs_f4 cv, xv[XN];
         float cd;
-        cfetch(sXc | spread_y(ytop - 1), cv, cd);
-        xfetch(xmap, sXf, spread_y(ytop), xv);
+        cfetch(row_in(st, tab_lane(st, ciC, ytop - 1), mXc, ytop - 1), cv, cd);
+        xfetch(xmap, row_in(st, tab_lane(st, ciF, ytop), mXf, ytop), xv);
         cw_wait(cv, cd);
         cstore(CRING - 1, cv, cd);
         xw_wait(xv);
         xstore(0, xv);
       }
+      // the lane's tile bases of the rows the steps ask for: x of row ytop + 1, L~ of row ytop
+      unsigned bXf = tab_lane(st, ciF, ytop + 1), bXc = tab_lane(st, ciC, ytop);
       step_barrier();
       auto step = [&](auto ph_c) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_c)::value;
@@ -544,7 +578,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         QS_STAMP(0);
         qs_f4 xv[XN];
         constexpr bool XLATE = H1;  // (the row's registers are H1's weights' in the slots s0, s1: requested behind s1 instead)
-        if (!XLATE) xfetch(xmap, sXf, spread_y(ytop + 1), xv);
+        if (tab_new_row(st, ytop + 1)) bXf = tab_lane(st, ciF, ytop + 1);
+        if (tab_new_row(st, ytop)) bXc = tab_lane(st, ciC, ytop);
+        if (!XLATE) xfetch(xmap, row_in(st, bXf, mXf, ytop + 1), xv);
         const unsigned f0 = (unsigned)slot_top * ROWB + lane16, f1 = (unsigned)slot_ix(1) * ROWB + lane16, f2 = (unsigned)slot_ix(2) * ROWB + lane16;
         const unsigned f3 = (unsigned)slot_ix(3) * ROWB + lane16;
         constexpr bool N3 = CHEB;  // level 3 enters with -2 L~ (Chebyshev), level 2 with +2 L~
@@ -566,11 +602,11 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
                  { if (qq < QS_UPR) QS_UNIT<!CHEB, false>(R[0][L0], R[1][L0], qq, QS_LO0(c2)); else QS_UNIT<false, false>(R[0][L0], R[1][L1], qq - QS_UPR, QS_LO1(c2)); })
         qs_settle<9>(R[1][L2]);
         qs_settle<1>(R[0][L0]);
-        if (XLATE) xfetch(xmap, sXf, spread_y(ytop + 1), xv);  // (two thirds of a step ahead of its use: still more than the memory's latency)
+        if (XLATE) xfetch(xmap, row_in(st, bXf, mXf, ytop + 1), xv);  // (two thirds of a step ahead of its use: still more than the memory's latency)
         QS_STAMP(2);
         // s2: z_2 -> b2[new] | b3[new] += b4[new]
         // (the row ytop of L~ is requested in the tail as well: its latency is H's to wait out, H reaches the barrier before L)
-        QS_CHAIN(R[0][L0], false, 2, f2, QS_UPR, { c2h = chi_read(cslot_ix(2)); cfetch(sXc | spread_y(ytop), cv, cd); if (H1) { QS_FR0(f3) } },
+        QS_CHAIN(R[0][L0], false, 2, f2, QS_UPR, { c2h = chi_read(cslot_ix(2)); cfetch(row_in(st, bXc, mXc, ytop), cv, cd); if (H1) { QS_FR0(f3) } },
                  { QS_UNIT<false, N3>(R[1][L2], R[0][L2], qq, QS_HI(c3h)); })
         qs_settle<9>(R[0][L0]);
         qs_settle<1>(R[1][L2]);
@@ -646,15 +682,15 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       QStrip st;
       tr += locate(tr, tape_end, st);
       for (int nq = map0; nq < a.N; nq += a.wg_per_piece) {
-      const unsigned sXf = st_spread((unsigned)min(max(st.xs + 4 * xpix + xt, st.xlo), st.xhi));
-      unsigned sXt[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) sXt[t] = st_spread((unsigned)min(max(st.xs + 4 * p + t, st.xlo), st.xhi));
+      const int Xf = min(max(st.xs + 4 * xpix + xt, st.xlo), st.xhi);
+      const int tc0 = max(st.xs, st.xlo) >> 4;  // the strip's first tile column
+      const unsigned ciF = (unsigned)((Xf >> 4) - tc0), mXf = st_spread((unsigned)Xf & 15u);
+      // the lane's four output pixels 4 p + t are one aligned group of four inside one tile (xs is a multiple of four): their
+      // Morton bits are those of the group's first pixel plus 0, 1, 4, 5 (only pixels of [x0, x0 + w) are stored: never clamped)
+      const int Xg = st.xs + 4 * p;
+      const unsigned ciY = (unsigned)((min(max(Xg, st.xlo), st.xhi) >> 4) - tc0), mXg = st_spread((unsigned)Xg & 12u);
       const int cfirst = st.x0 - st.xs, clast = cfirst + st.w;  // output columns of the strip: [cfirst, clast)
       const int T3 = ((st.y1 - st.y0) + 2 * D + 1 + 3) / 3;
-      auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
-        return st_spread((unsigned)min(max(yrow, st.ylo), st.yhi)) << 1;
-      };
       const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)nq * a.x_rows * xrowb;
       char* __restrict__ ymap = reinterpret_cast<char*>(a.y) + (size_t)nq * a.y_rows * yrowb;
       QRow R[2][3], Y;
@@ -670,10 +706,12 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       step_barrier();  // (the previous item's last reads of the rings)
       if (!X_BY_H) {
         qs_f4 xv[XN];
-        xfetch(xmap, sXf, spread_y(ytop), xv);
+        xfetch(xmap, row_in(st, tab_lane(st, ciF, ytop), mXf, ytop), xv);
         xw_wait(xv);
         xstore(0, xv);
       }
+      // the lane's tile bases: x of row ytop + 1 (when all eight waves fetch x), y of row ytop - K
+      unsigned bXf = X_BY_H ? 0u : tab_lane(st, ciF, ytop + 1), bY = tab_lane(st, ciY, st.y0);
       step_barrier();
       auto step = [&](auto ph_c) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_c)::value;
@@ -693,7 +731,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         QS_STAMP_DECL
         QS_STAMP(0);
         qs_f4 xv[XN];
-        if (!X_BY_H) xfetch(xmap, sXf, spread_y(ytop + 1), xv);
+        if (!X_BY_H && tab_new_row(st, ytop + 1)) bXf = tab_lane(st, ciF, ytop + 1);
+        if (ytop - K > st.y0 && tab_new_row(st, ytop - K)) bY = tab_lane(st, ciY, ytop - K);
+        if (!X_BY_H) xfetch(xmap, row_in(st, bXf, mXf, ytop + 1), xv);
         // the rows H left at the end of the previous step: b2[new] -> R[0][L2] (the set that died then), b3 -> R[1][L2]
         if (!(QS_ABL & 2048)) {
           const unsigned char* hp = smem + hand;
@@ -749,7 +789,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         {
           const int yr = ytop - K;
           const bool row_ok = yr >= st.y0 && yr < ((QS_ABL & 16) ? st.y0 + 1 : st.y1);
-          const unsigned sY = st_spread((unsigned)max(yr, 0)) << 1;
+          const unsigned rowg = bY + (mXg | (st_spread((unsigned)max(yr, 0) & 15u) << 1));
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int c = 4 * p + t;
@@ -761,7 +801,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
                 // (f16: an input beyond the f16 range has become a NaN by now -- it must reach y, not be floored away by the ReLU)
                 o[e] = F16 ? (v < floor_v ? floor_v : v) : fmaxf(v, floor_v);
               }
-              *reinterpret_cast<qs_f4*>(ymap + (size_t)(sXt[t] | sY) * yrowb + (unsigned)(16 * oq + 4 * q4) * 4u) = o;
+              *reinterpret_cast<qs_f4*>(ymap + (size_t)(rowg + (unsigned)((t & 1) + 4 * (t >> 1))) * yrowb + (unsigned)(16 * oq + 4 * q4) * 4u) = o;
             }
           }
         }

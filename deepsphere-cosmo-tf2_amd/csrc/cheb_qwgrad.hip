@@ -65,6 +65,7 @@ int launch_cheb_qwgrad(const QWgradLaunch& s, hipStream_t stream) {
   a.gvals8 = s.gvals8;
   a.gdiag = s.gdiag;
   a.strips = s.strips;
+  a.tab = s.tab;
   a.prefix = s.prefix;
   a.x_rows = s.x_rows;
   a.dy_rows = s.dy_rows;

@@ -62,6 +62,7 @@ struct QWgradArgs {
   const float* gvals8;
   const float* gdiag;
   const QStrip* strips;
+  const int32_t* tab;         // the rectangles' tables of tile bases (cheb_qstrip_kernel.h: QStrip::tab, ::tws)
   const int32_t* prefix;
   int64_t x_rows, dy_rows;    // rows per map
   int nstrips, N, lddy;       // lddy: row stride of dy in floats (x: 64)
@@ -106,7 +107,13 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
       const int mid = (lo + hi) >> 1;
       if ((int64_t)a.prefix[mid] <= r) lo = mid; else hi = mid;
     }
-    st = a.strips[lo];
+    {  // (the record through scalar registers: every field is wave-uniform, and the compiler should know -- rows, clamps and the
+       // table look-ups' branches then run on the scalar unit)
+      const QStrip g = a.strips[lo];
+#define QS_U(f) st.f = __builtin_amdgcn_readfirstlane(g.f)
+      QS_U(x0); QS_U(w); QS_U(xs); QS_U(y0); QS_U(y1); QS_U(xlo); QS_U(xhi); QS_U(ylo); QS_U(yhi); QS_U(tab); QS_U(tws);
+#undef QS_U
+    }
     const int h = st.y1 - st.y0;
     const int off = (int)(r - (int64_t)a.prefix[lo]);
     const int len = (int)(((int64_t)(h - off) < r_end - r) ? (int64_t)(h - off) : r_end - r);
@@ -198,27 +205,43 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
       unsigned voff[4];
       bool colk[4];
       const int cfirst = st.x0 - st.xs, clast = cfirst + st.w;
+      // (rows through the rectangle's table of tile bases, as the forward kernel: row = tab[(y >> 4) tws + (x >> 4)] + morton(x & 15,
+      // y & 15); the lane's four pixels are one aligned group of four inside one tile, or -- clamped -- one and the same pixel)
+      const int xclo = sideQ ? st.x0 : st.xlo, xchi = sideQ ? st.x0 + st.w - 1 : st.xhi;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         // (dy is read on the output pixels only -- elsewhere it is zeroed, and its halo may not exist: the load stays inside)
-        voff[t] = st_spread((unsigned)min(max(st.xs + 4 * p + t, sideQ ? st.x0 : st.xlo), sideQ ? st.x0 + st.w - 1 : st.xhi)) * srowb +
-                  (unsigned)(16 * cq + 4 * q4) * 4u;
+        voff[t] = st_spread((unsigned)min(max(st.xs + 4 * p + t, xclo), xchi) & 15u) * srowb + (unsigned)(16 * cq + 4 * q4) * 4u;
         colk[t] = !sideQ || (4 * p + t >= cfirst && 4 * p + t < clast);
       }
-      const unsigned sXc = st_spread((unsigned)min(max(st.xs + 4 * p + cq, st.xlo), st.xhi));
-      const unsigned coffv = sXc * 32u + (unsigned)(q4 & 1) * 16u, coffd = sXc * 4u;
+      // (one register for the lane's tile columns, counted from the strip's first: the operand's pixels [0, 4), the pixel of L~
+      // [4, 8), its Morton bits [8, 15); the five tile bases of a tile row come by scalar loads when a row enters a new tile row,
+      // as in cheb_qstrip_kernel.h)
+      const int Xc = min(max(st.xs + 4 * p + cq, st.xlo), st.xhi);
+      const int tc0 = max(st.xs, st.xlo) >> 4;
+      const unsigned pk = (unsigned)((min(max(st.xs + 4 * p, xclo), xchi) >> 4) - tc0) | ((unsigned)((Xc >> 4) - tc0) << 4) | (st_spread((unsigned)Xc & 15u) << 8);
       const char* smap = sbase + (size_t)nq * srows * srowb;
-      auto spread_y = [&](int yrow) __attribute__((always_inline)) -> unsigned {
-        return st_spread((unsigned)min(max(yrow, st.ylo), st.yhi)) << 1;
+      typedef int qs_i4 __attribute__((ext_vector_type(4)));
+      auto tab_lane = [&](unsigned ci, int yc) __attribute__((always_inline)) -> unsigned {
+        const int32_t* trow = a.tab + __builtin_amdgcn_readfirstlane(st.tab + (yc >> 4) * st.tws + tc0);
+        qs_i4 b;
+        int b4;
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(b), "=&s"(b4) : "s"(trow) : "memory");
+        return (unsigned)(ci == 0 ? b[0] : ci == 1 ? b[1] : ci == 2 ? b[2] : ci == 3 ? b[3] : b4);
       };
       const int rlo = sideQ ? st.y0 : st.ylo, rhi = sideQ ? st.y1 - 1 : st.yhi;
+      // the lane's tile bases of the rows in flight: the operand's (row clamped to [rlo, rhi]) and L~'s (to [ylo, yhi])
+      unsigned bV = tab_lane(pk & 15u, min(max(st.y0 - D, rlo), rhi)), bC = sideQ ? 0u : tab_lane((pk >> 4) & 15u, min(max(st.y0 - D, st.ylo), st.yhi));
       // Plain loads, not asm: the compiler then knows the data is in flight -- it keeps the registers out of other use until
       // the first reader and counts vmcnt itself.  (With the loads in asm statements it took their results for present and
       // moved them through registers it reused meanwhile: wrong rows.)  The asm statements around keep the requests in place.
       auto row_fetch = [&](int yrow, QRow& R) __attribute__((always_inline)) {
-        const char* rb = smap + (size_t)(st_spread((unsigned)min(max(yrow, rlo), rhi)) << 1) * srowb;
+        // (32-bit offsets from the map's scalar base: a map is under 4 GiB -- strips_apply -- and the loads keep their scalar-base form)
+        const int yc = min(max(yrow, rlo), rhi);
+        if (yrow > rlo && yrow <= rhi && (yrow & 15) == 0) bV = tab_lane(pk & 15u, yc);
+        const unsigned rb = (bV + (st_spread((unsigned)yc & 15u) << 1)) * srowb;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) R.t[t] = *reinterpret_cast<const qs_f4*>(rb + voff[t]);
+        for (int t = 0; t < 4; ++t) R.t[t] = *reinterpret_cast<const qs_f4*>(smap + (rb + voff[t]));
       };
       const int T3 = ((st.y1 - st.y0) + 2 * D + 1 + 2) / 3;
       QRow S0[3], S1[3];
@@ -233,8 +256,10 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qwgrad5_kernel(QWgradArgs 
       qs_f4 cv = qs_f4{0.f, 0.f, 0.f, 0.f};
       float cd = 0.f;
       auto coef_fetch = [&](int yrow) __attribute__((always_inline)) {
-        const size_t sy = spread_y(yrow);
-        cfetch(reinterpret_cast<const char*>(a.gvals8) + sy * 32u, reinterpret_cast<const char*>(a.gdiag) + sy * 4u, coffv, coffd, cv, cd);
+        const int yc = min(max(yrow, st.ylo), st.yhi);
+        if (yrow > st.ylo && yrow <= st.yhi && (yrow & 15) == 0) bC = tab_lane((pk >> 4) & 15u, yc);
+        const size_t rid = bC + ((pk >> 8) | (st_spread((unsigned)yc & 15u) << 1));
+        cfetch(reinterpret_cast<const char*>(a.gvals8) + rid * 32u, reinterpret_cast<const char*>(a.gdiag) + rid * 4u, (unsigned)(q4 & 1) * 16u, 0u, cv, cd);
       };
       if (!sideQ) coef_fetch(ytop);
 

@@ -143,6 +143,42 @@ int struct_build_rows(const dsph_plan* plan, float** gvals8, float** gdiag, unsi
   return DSPH_OK;
 }
 
+__host__ __device__ inline void struct_patch_body(int64_t i, const int32_t* __restrict__ rows, const float* __restrict__ vals,
+                                                  float* __restrict__ gvals8, float* __restrict__ gdiag) {
+  const int64_t r = rows[i];
+  gdiag[r] = vals[9 * i];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) gvals8[r * 8 + d] = vals[9 * i + 1 + d];
+}
+__global__ __launch_bounds__(256) void struct_patch_kernel(const int32_t* __restrict__ rows, const float* __restrict__ vals, int64_t n,
+                                                           float* __restrict__ gvals8, float* __restrict__ gdiag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) struct_patch_body(i, rows, vals, gvals8, gdiag);
+}
+int struct_patch_rows(const dsph_plan* plan, float* gvals8, float* gdiag, const int32_t* rows, const float* vals, int64_t n) {
+  (void)plan;
+  if (n <= 0) return DSPH_OK;
+  int32_t* d_rows = nullptr;
+  float* d_vals = nullptr;
+  hipError_t e = hipMalloc((void**)&d_rows, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_vals, (size_t)n * 36);
+  if (e == hipSuccess) e = hipMemcpy(d_rows, rows, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_vals, vals, (size_t)n * 36, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+#ifdef DSPH_HOST_EMU
+    for (int64_t i = 0; i < n; ++i) struct_patch_body(i, d_rows, d_vals, gvals8, gdiag);
+#else
+    hipLaunchKernelGGL(struct_patch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_rows, d_vals, n, gvals8, gdiag);
+#endif
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (d_rows) (void)hipFree(d_rows);
+  if (d_vals) (void)hipFree(d_vals);
+  if (e != hipSuccess) return hip_fail(e, "struct_patch_rows");
+  return DSPH_OK;
+}
+
 // cls (host, ntiles bytes) <- classification of every 256-row tile for depth D
 int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, int ntiles, int D, int64_t out_rows,
                           unsigned char* h_cls) {

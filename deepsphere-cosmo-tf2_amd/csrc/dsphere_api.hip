@@ -184,6 +184,13 @@ int dsph_plan_strip_pairs(const dsph_plan* p, int32_t K, int32_t* out, int64_t c
   return DSPH_OK;
 }
 
+int dsph_plan_strip_rows(const dsph_plan* p, int32_t K, int64_t strip, int64_t n, const int32_t* xy, int64_t* rows) {
+  if (!p || n < 0 || (n > 0 && (!xy || !rows))) { set_error("plan_strip_rows: bad arguments"); return DSPH_E_BADARG; }
+  DeviceGuard guard(p->device);
+  if (fused_strip_rows(p, K, strip, n, xy, rows) < 0) { set_error("plan_strip_rows: no strip record %lld for K = %d", (long long)strip, (int)K); return DSPH_E_UNSUPPORTED; }
+  return DSPH_OK;
+}
+
 static bool use_split(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo, int32_t part);
 
 int dsph_plan_strip_split(const dsph_plan* p, int64_t N, int32_t* grid, int32_t* pieces, int32_t* wg_per_piece, int64_t* tape_rows) {

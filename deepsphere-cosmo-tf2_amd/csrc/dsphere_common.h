@@ -102,6 +102,7 @@ bool fused_weights_resident(const dsph_plan* plan, int32_t Fin, int32_t Fout, in
 bool fused_tile_counts(const dsph_plan* plan, int32_t K, int64_t* n_struct, int64_t* n_bfs);
 int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K, int32_t precision);
 int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_t cap);
+int64_t fused_strip_rows(const dsph_plan* plan, int32_t K, int64_t strip, int64_t n, const int32_t* xy, int64_t* rows);
 bool fused_strip_split(const dsph_plan* plan, int64_t N, int32_t* grid, int32_t* pieces, int32_t* wg_per_piece, int64_t* tape_rows);
 // conv + HealpyPool(p = 1) in one forward: the pooled map (N, n_rows / 4, Fout) and the kind of reduction (1 max, 2 mean)
 struct FusedPool {
@@ -177,6 +178,9 @@ struct StructLaunch {
   int32_t pool = 0;                 // 0 none, 1 max, 2 mean
 };
 int struct_build_rows(const dsph_plan* plan, float** gvals8, float** gdiag, unsigned char** flag);
+// gdiag[rows[i]] <- vals[9 i], gvals8[rows[i]][d] <- vals[9 i + 1 + d] (host arrays; duplicates carry equal values): the rows of
+// class-T tiles that the table-addressed quad strips evaluate, by the directions of the tile's verified embedding
+int struct_patch_rows(const dsph_plan* plan, float* gvals8, float* gdiag, const int32_t* rows, const float* vals, int64_t n);
 int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, int ntiles, int D, int64_t out_rows,
                           unsigned char* h_cls);
 bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
@@ -210,6 +214,7 @@ struct QStripLaunch {
   const float* x; const float* w; const float* bias; float* y;
   unsigned char* wimg;       // workspace: qstrip_wimg_bytes()
   const QStrip* strips;      // device list of strips (uncut along y: the kernel cuts the tape of their rows by workgroup)
+  const int32_t* tab = nullptr;  // device: the rectangles' tables of tile bases (QStrip::tab, ::tws)
   const int32_t* prefix;     // device [nstrips + 1]: rows of the strips before each one
   int64_t tape_rows;         // prefix[nstrips]
   const float* gvals8; const float* gdiag;
@@ -231,6 +236,7 @@ struct QWgradLaunch {
   float* dw;                 // [64 * 5][lddw]
   float* slabs;              // workspace: qwgrad_slab_bytes(num_cu)
   const QStrip* strips; const int32_t* prefix;
+  const int32_t* tab = nullptr;  // the rectangles' tables of tile bases
   int64_t tape_rows;
   const float* gvals8; const float* gdiag;
   int64_t x_rows, dy_rows, N;

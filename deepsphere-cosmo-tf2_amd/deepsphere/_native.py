@@ -47,6 +47,7 @@ SIGNATURES = {
     "dsph_plan_strip_pairs": (ctypes.c_int, [_c_vp, _c_i32, _c_vp, _c_i64, ctypes.POINTER(_c_i64)]),
     "dsph_plan_strip_split": (ctypes.c_int, [_c_vp, _c_i64, ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i32),
                                              ctypes.POINTER(_c_i64)]),
+    "dsph_plan_strip_rows": (ctypes.c_int, [_c_vp, _c_i32, _c_i64, _c_i64, _c_vp, _c_vp]),
     "dsph_plan_rows": (_c_i64, [_c_vp]),
     "dsph_plan_cols": (_c_i64, [_c_vp]),
     "dsph_plan_ell_width": (_c_i32, [_c_vp]),
@@ -237,6 +238,15 @@ class LaplacianPlan:
             check(lib().dsph_plan_strip_pairs(self.handle, int(K), out.ctypes.data, int(n.value), ctypes.byref(n)),
                   "dsph_plan_strip_pairs")
         return out
+
+    def strip_rows(self, K, strip, xs, ys):
+        """Row numbers of the pixels (xs[i], ys[i]) of the plane of strip record ``strip`` (``dsph_plan_strip_rows``): through the
+        rectangle's table of tile bases for the quad strips, the Z-order plane of the row index for the strip pairs."""
+        xy = np.ascontiguousarray(np.stack([np.asarray(xs), np.asarray(ys)], axis=1), dtype=np.int32)
+        rows = np.zeros(xy.shape[0], dtype=np.int64)
+        check(lib().dsph_plan_strip_rows(self.handle, int(K), int(strip), int(xy.shape[0]), xy.ctypes.data, rows.ctypes.data),
+              "dsph_plan_strip_rows")
+        return rows
 
     def strip_split(self, N):
         """How a quad-strip forward of ``N`` maps cuts its work (``dsph_plan_strip_split``): (grid, pieces, workgroups per piece,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DSPH_ABI_VERSION 3  /* 3: DSPH_OPT_F16_XEXP (round 6); 2: dsph_plan_prepare_layer; the entry points added
+#define DSPH_ABI_VERSION 3  /* 3: DSPH_OPT_F16_XEXP, dsph_plan_strip_rows (round 6); 2: dsph_plan_prepare_layer; the entry points added
                               * since version 1 (set_option, forward_ex, forward_pool, healpix_pool, strip_pairs) are part of it */
 
 /* error codes */
@@ -218,6 +218,13 @@ int dsph_plan_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_
  * `pieces` equal pieces, `wg_per_piece` workgroups per piece each taking every wg_per_piece-th map of the batch; a strip is cut
  * wherever a piece ends.  This call reports that split for a batch of N maps -- for tests and tools that want to look at the seams.) */
 int dsph_plan_strip_split(const dsph_plan* plan, int64_t N, int32_t* grid, int32_t* pieces, int32_t* wg_per_piece, int64_t* tape_rows);
+/* (Round 6: the rectangles of the quad strips are found on the LOGICAL tile grid -- tiles on a border between two base pixels, or
+ * between two superpixels of a compacted partial-sky map, belong to them wherever the neighbouring tiles continue the pixel grid by
+ * a pure translation -- and a strip's record is in the coordinates of its rectangle's plane: the rectangle's first pixel is
+ * (16, 16), one ring of tiles around it is addressable.  Which ROW of the map a pixel of that plane is, the strip's table says:
+ * this call looks up n pixels xy[2 i], xy[2 i + 1] of record `strip` (clamped to the rectangle and its halo as the kernel clamps
+ * them) into rows[i].  For the strip pairs (DSPH_OPT_STRIP_FORM 1) the plane is the virtual Z-order plane of the row index itself.) */
+int dsph_plan_strip_rows(const dsph_plan* plan, int32_t K, int64_t strip, int64_t n, const int32_t* xy, int64_t* rows);
 
 /* Bytes of scratch dsph_cheb_forward needs for this call shape (0 is possible). */
 size_t dsph_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout,

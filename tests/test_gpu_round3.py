@@ -67,7 +67,7 @@ def test_strip_kernel_whole_map(nside, N, basis, act, use_bias):
     n_struct, n_bfs = plan.tile_counts(K)
     n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3)
     nt = nside // 16
-    assert n_strip == 12 * (nt - 2) ** 2, "the interior tiles of every base pixel go to the strip kernel"
+    assert n_strip >= 12 * (nt - 2) ** 2, "the interior tiles of every base pixel go to the strip kernel (the quad strips: border tiles too)"
     assert n_strip <= n_struct and n_struct + n_bfs == M // 256
     assert plan.strip_tiles(Fin, Fout, K, _native.PREC_FP32) == 0 and plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X6) == 0
     assert plan.strip_tiles(32, 64, K, _native.PREC_BF16X3) == 0 and plan.strip_tiles(Fin, Fout, 4, _native.PREC_BF16X3) == 0

@@ -45,12 +45,14 @@ def test_quad_strips_whole_map_and_against_the_strip_pairs(nside, N, basis, act)
     for form in (_native.STRIP_FORM_QUAD, _native.STRIP_FORM_PAIRS):
         plan = _plan(cols, vals, K, Fin, {_native.OPT_STRIPS: _native.STRIPS_ALWAYS, _native.OPT_STRIP_FORM: form})
         nt = nside // 16
-        assert plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N) == 12 * (nt - 2) ** 2
+        n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
         pairs = plan.strip_pairs(K)
-        if form == _native.STRIP_FORM_QUAD:
-            per_face = -(-16 * (nt - 2) // 56)
-            assert pairs.shape == (12 * per_face, 12) and np.all(pairs[:, 3] == 0), "uncut 64-column strips, one per record"
-            assert np.all(pairs[:, 2] <= 56) and np.all(pairs[:, 7] - pairs[:, 6] == 16 * (nt - 2))
+        if form == _native.STRIP_FORM_QUAD:  # (rectangles on the logical tile grid: the interiors and the translated borders)
+            assert 12 * (nt - 2) ** 2 < n_strip <= 12 * nt * nt - 24
+            assert pairs.shape[1] == 12 and np.all(pairs[:, 3] == 0), "uncut 64-column strips, one per record"
+            assert np.all(pairs[:, 2] <= 56) and np.all((pairs[:, 7] - pairs[:, 6]) % 16 == 0)
+        else:
+            assert n_strip == 12 * (nt - 2) ** 2
         y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, **kw)
         y2, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, **kw)
         assert torch.equal(y, y2), "two launches of the same inputs must agree bit for bit"
@@ -79,7 +81,7 @@ def test_f16_three_term_split_is_fp32_equivalent(basis):
     fwd = orc.chebyshev_forward if basis == "chebyshev" else orc.monomial_forward
     ref = fwd(_csr(cols, vals), x, W, K, bias=b, activation="relu")
     plan = _plan(cols, vals, K, Fin, {_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
-    assert plan.strip_tiles(Fin, Fout, K, _native.PREC_F16X3, N=N) == 12 * (nside // 16 - 2) ** 2
+    assert plan.strip_tiles(Fin, Fout, K, _native.PREC_F16X3, N=N) >= 12 * (nside // 16 - 2) ** 2
     B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
     kw = dict(act=_native.ACT_RELU, algo=_native.ALGO_FUSED, basis=B)
     y, ws = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, precision=_native.PREC_F16X3, **kw)
@@ -296,7 +298,7 @@ def test_quad_strip_weight_gradient(nside, N, Fout, basis):
     B = {"chebyshev": _native.BASIS_CHEBYSHEV, "monomial": _native.BASIS_MONOMIAL}[basis]
     plan = _plan(cols, vals, K, Fin, {_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
     nt = nside // 16
-    assert plan.strip_tiles(Fin, 64, K, _native.PREC_BF16X3, N=N) == 12 * (nt - 2) ** 2, "the strips this test is about exist"
+    assert plan.strip_tiles(Fin, 64, K, _native.PREC_BF16X3, N=N) >= 12 * (nt - 2) ** 2, "the strips this test is about exist"
     dw, ws = _native.cheb_backward_weights(plan, _dev(x), _dev(dy), K, basis=B, algo=_native.ALGO_FUSED, precision=_native.PREC_BF16X3)
     err = rel_err(dw.cpu().numpy(), ref)
     print(f"quad-strip dW nside={nside} N={N} Fout={Fout} {basis}: rel err {err:.2e}")

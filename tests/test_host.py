@@ -329,4 +329,8 @@ def test_plan_builders_under_sanitizers():
                        text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "ASAN-DRIVER-OK" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
-    assert "grid nside 128: K 5 64->64: tile_counts rc 0 struct 744 bfs 24, fused_ok 1, strip tiles [432, 432, 432]" in r.stdout
+    # (the quad strips' rectangles on the logical tile grid -- 588 tiles at nside 128, the 432 interior ones and the translated
+    # borders -- with every strip's table of tile bases verified against the graph itself by the driver)
+    assert "grid nside 128: K 5 64->64: tile_counts rc 0 struct 744 bfs 24, fused_ok 1, strip tiles [588, 588, 588]" in r.stdout
+    assert "grid nside 128: 18 strips, 150528 output pixels = 588 tiles, tables verified against the graph" in r.stdout
+    assert "cap nside 128 superpixels 8: " in r.stdout and "tables verified against the graph" in r.stdout.split("cap nside 128 superpixels 8: ")[1]

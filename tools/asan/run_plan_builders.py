@@ -34,6 +34,7 @@ LIB.dsph_plan_tile_counts.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINT
 LIB.dsph_plan_strip_tiles.argtypes = [vp, i64, i32, i32, i32, i32, ctypes.POINTER(i64)]
 LIB.dsph_plan_strip_pairs.argtypes = [vp, i32, vp, i64, ctypes.POINTER(i64)]
 LIB.dsph_plan_strip_split.argtypes = [vp, i64, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i64)]
+LIB.dsph_plan_strip_rows.argtypes = [vp, i32, i64, i64, vp, vp]
 LIB.dsph_plan_fused_ok.argtypes = [vp, i32, i32, i32]
 LIB.dsph_workspace_bytes.argtypes = [vp, i64, i32, i32, i32, i32, i32]
 LIB.dsph_workspace_bytes.restype = ctypes.c_size_t
@@ -80,7 +81,38 @@ def look(h, K, Fin, Fout, name, flags=1, N=(1, 3, 16)):
     if n.value:
         assert LIB.dsph_plan_strip_pairs(h, K, rec.ctypes.data, n.value, ctypes.byref(n)) == 0
     print(f"{name}: K {K} {Fin}->{Fout}: tile_counts rc {rc} struct {a.value} bfs {b.value}, fused_ok {ok}, strip tiles {strips}, records {n.value}", flush=True)
+    look.records = rec[: n.value]
     return a.value, b.value, strips
+
+
+def check_strip_tables(h, K, cols, vals, name):
+    """Every quad strip's table against the graph itself: a pixel's row, looked up through dsph_plan_strip_rows, must have its
+    non-zeros of L~ exactly on the rows of the eight neighbouring pixels of the strip's plane (and itself) -- for every output
+    pixel and every halo pixel a level is evaluated on (rings 0 .. 3 of the rectangle); output pixels are covered once."""
+    rec = look.records
+    seen = np.zeros(cols.shape[0], np.int32)
+    for s, r in enumerate(rec):
+        x0, w, y0, y1, xlo, xhi, ylo, yhi = int(r[0]), int(r[2]), int(r[6]), int(r[7]), int(r[8]), int(r[9]), int(r[10]), int(r[11])
+        xa, xb = max(x0 - 3, xlo + 1), min(x0 + w + 3, xhi)          # evaluated columns of this strip (its neighbours cover the rest)
+        ys = np.arange(ylo, yhi + 1)
+        xs = np.arange(xa - 1, xb + 1)
+        X, Y = np.meshgrid(xs, ys, indexing="ij")
+        rows = np.zeros(X.size, np.int64)
+        xy = np.ascontiguousarray(np.stack([X.ravel(), Y.ravel()], 1), np.int32)
+        assert LIB.dsph_plan_strip_rows(h, K, s, xy.shape[0], xy.ctypes.data, rows.ctypes.data) == 0
+        R = rows.reshape(X.shape)
+        assert R.min() >= 0 and R.max() < cols.shape[0]
+        inner = R[1:-1, 1:-1]                                          # rings 0 .. 3
+        nb = np.stack([R[1 + dx: R.shape[0] - 1 + dx, 1 + dy: R.shape[1] - 1 + dy] for dx in (-1, 0, 1) for dy in (-1, 0, 1)], -1)
+        c = cols[inner.ravel()]
+        v = vals[inner.ravel()]
+        ok = (v == 0) | (c[:, :, None] == nb.reshape(-1, 9)[:, None, :]).any(-1)
+        assert ok.all(), f"{name}: strip {s}: a non-zero of L~ off the 3 x 3 window of the strip's plane"
+        out = R[(x0 - (xa - 1)): (x0 - (xa - 1)) + w, (y0 - ylo): (y0 - ylo) + (y1 - y0)]
+        np.add.at(seen, out.ravel(), 1)
+    assert seen.max() <= 1, f"{name}: an output pixel in two strips"
+    print(f"{name}: {len(rec)} strips, {int(seen.sum())} output pixels = {int(seen.sum()) // 256} tiles, tables verified against the graph", flush=True)
+    return int(seen.sum()) // 256
 
 
 def shard_of(cols, vals, lo, hi, K):
@@ -117,8 +149,8 @@ def main():
         h = plan_of(cols, vals, options={OPT_STRIPS: 1})
         s, b, st = look(h, 5, 64, 64, f"grid nside {nside}")
         assert s + b == cols.shape[0] // 256 and b == 24
-        if nside == 128:
-            assert st[0] == 12 * (nside // 16 - 2) ** 2
+        if st[0]:
+            assert check_strip_tables(h, 5, cols, vals, f"grid nside {nside}") == st[0]
         look(h, 5, 16, 32, f"grid nside {nside}")
         look(h, 3, 1, 16, f"grid nside {nside}")
         if nside == 64:
@@ -136,7 +168,9 @@ def main():
         idx = healpix.extend_indices(healpix.cap_indices(nside, fraction=1.0 / 3.0), nside, sup)
         cols, vals = ell_of(healpix.healpix_laplacian(nside, indices=idx, mode="grid"))
         h = plan_of(cols, vals, options={OPT_STRIPS: 1})
-        look(h, 5, 64, 64, f"cap nside {nside} superpixels {sup} ({cols.shape[0]} rows)")
+        _, _, st = look(h, 5, 64, 64, f"cap nside {nside} superpixels {sup} ({cols.shape[0]} rows)")
+        if st[0]:
+            assert check_strip_tables(h, 5, cols, vals, f"cap nside {nside} superpixels {sup}") == st[0]
         LIB.dsph_plan_destroy(h)
     # the reference's graphs: k nearest neighbours (ELL width 11: BFS tiles; 23: the tiled step's depth-1 tables)
     for k in (8, 20):

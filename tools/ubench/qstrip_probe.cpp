@@ -40,6 +40,7 @@ static std::vector<QStrip> cut(int S, int border, int seg) {
       QStrip s{};
       s.x0 = x0; s.w = std::min(QS_USE, X1 - x0); s.xs = x0 - QS_D;
       s.y0 = ya; s.y1 = yb; s.xlo = X0 - QS_D; s.xhi = X1 - 1 + QS_D; s.ylo = Y0 - QS_D; s.yhi = Y1 - 1 + QS_D;
+      s.tab = 0; s.tws = S / 16;  // (round 6: rows through a table of tile bases -- here the Morton plane itself)
       v.push_back(s);
     }
   }
@@ -70,11 +71,17 @@ static double run(const Case& c, bool check, int reps) {
   CK(hipMemcpy(d_s, strips.data(), strips.size() * sizeof(QStrip), hipMemcpyHostToDevice));
   std::vector<int32_t> prefix(1, 0);
   for (const QStrip& q : strips) prefix.push_back(prefix.back() + (q.y1 - q.y0));
+  std::vector<int32_t> tab((size_t)(S / 16) * (S / 16) + 8, 0);
+  for (int ty = 0; ty < S / 16; ++ty)
+    for (int tx = 0; tx < S / 16; ++tx) tab[(size_t)ty * (S / 16) + tx] = (int32_t)(st_morton((unsigned)tx, (unsigned)ty) * 256u);
+  int32_t* d_tab;
+  CK(hipMalloc(&d_tab, tab.size() * 4));
+  CK(hipMemcpy(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
   int32_t* d_p;
   CK(hipMalloc(&d_p, prefix.size() * 4));
   CK(hipMemcpy(d_p, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice));
   QStripLaunch L;
-  L.prefix = d_p; L.tape_rows = prefix.back();
+  L.prefix = d_p; L.tape_rows = prefix.back(); L.tab = d_tab;
   L.x = d_x; L.w = d_w; L.bias = d_b; L.y = d_y; L.wimg = d_img; L.strips = d_s; L.gvals8 = d_g8; L.gdiag = d_gd;
   L.x_rows = (int64_t)M; L.y_rows = (int64_t)M; L.N = N; L.nstrips = (int)strips.size(); L.Fin = F; L.Fout = F; L.act = DSPH_ACT_RELU;
   L.ld = F; L.num_cu = getenv("QS_NUM_CU") ? atoi(getenv("QS_NUM_CU")) : 256; /* (tuning: fewer workgroups than CUs) */ L.cheb = c.cheb; L.f16 = c.f16; L.prep_weights = true;
