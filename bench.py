@@ -49,13 +49,16 @@ CONFIGS = {
     # n_neighbors = 20) at configs[1]'s map and channel counts: ELL width 11 / 23
     "knn8": (256, 5, 16, 32, 8),
     "knn20": (256, 5, 16, 32, 8),
+    # the headline SHAPE (K 5, 64 -> 64) on the reference's own kind of graph (healpy_networks.py:110-118: symmetrised 8 nearest
+    # neighbours) at nside 512, batch 16: as many (map, pixel) units per forward as the headline config
+    "knn8h": (512, 5, 64, 64, 16),
     # a layer of the reference's quick-start model (examples/quick_start.ipynb:118-127,142-147): K = 10, five channels,
     # 20 neighbours, batch 16 -- at nside 256
     "qs": (256, 10, 5, 5, 16),
     "qs1": (256, 10, 1, 5, 16),  # its first layer: one input channel
 }
 MASKED = {"c5"}
-KNN = {"knn8": 8, "knn20": 20, "qs": 20, "qs1": 20}
+KNN = {"knn8": 8, "knn20": 20, "qs": 20, "qs1": 20, "knn8h": 8}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 
@@ -204,6 +207,8 @@ def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1, split="auto"):
     n_struct, n_bfs = plan.tile_counts(K)
     n_strip = plan.strip_tiles(Fin, Fout, K, prec_code, N=N)
     parts = []
+    if n_strip and K == 8:  # (round 6: the three-role quad strips of the K = 8, 32 -> 32 shape; the other tiles stay on the tile kernel)
+        return f"cheb_qstrip8_kernel ({n_strip} tiles) + cheb_fused_kernel ({n_struct + n_bfs - n_strip} tiles)"
     if n_strip:
         parts.append(f"{'cheb_istrip1_kernel' if Fin <= 2 else ('cheb_istrip_kernel' if Fin <= 16 else ('cheb_qstrip5_kernel' if STRIP_FORM == 'quad' else 'cheb_strip5_kernel'))} ({n_strip} tiles)")
     if n_struct - n_strip:

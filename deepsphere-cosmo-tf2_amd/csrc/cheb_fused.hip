@@ -37,6 +37,7 @@
 
 #include "cheb_fused_kernel.h"
 #include "cheb_istrip_kernel.h"
+#include "cheb_qstrip8_kernel.h"
 #include "cheb_qstrip_kernel.h"
 #include "cheb_strip_kernel.h"
 #include "cheb_struct_kernel.h"
@@ -92,6 +93,16 @@ struct FusedTiles {
   int32_t* d_qtab = nullptr;               // tile-base tables of all rectangles, back to back (row numbers)
   std::vector<int32_t> h_qtab;
   int64_t n_qstrip_tiles = 0;              // tiles the quad strips take
+  // K = 8 quad strips (cheb_qstrip8_kernel.h; the tables of depth 7 only): rectangles of the tiles whose 7-ring region is a regular
+  // square of the Morton plane, and the tiles they leave to the breadth-first tile kernel (interior first, the order of d_part)
+  QStrip* d_q8strips = nullptr;
+  int32_t* d_q8prefix = nullptr;
+  int32_t* d_q8tab = nullptr;
+  int32_t* d_q8rest = nullptr;
+  int n_q8strips = 0, n_q8rest = 0, n_q8rest_interior = 0;  // (the rest list: interior tiles first, like d_part)
+  int64_t q8tape_rows = 0, n_q8_tiles = 0;
+  std::vector<QStrip> h_q8strips;
+  std::vector<int32_t> h_q8tab;
   // what the quad strips leave to the structured kernel: class-R tiles (interior first) and class-T tiles with their tables
   int32_t* d_qrrest = nullptr;
   int n_qrrest = 0, n_qrrest_interior = 0;
@@ -204,6 +215,10 @@ static void free_tiles(FusedTiles& ft) {
   if (ft.d_qstrips) (void)hipFree(ft.d_qstrips);
   if (ft.d_qprefix) (void)hipFree(ft.d_qprefix);
   if (ft.d_qtab) (void)hipFree(ft.d_qtab);
+  if (ft.d_q8strips) (void)hipFree(ft.d_q8strips);
+  if (ft.d_q8prefix) (void)hipFree(ft.d_q8prefix);
+  if (ft.d_q8tab) (void)hipFree(ft.d_q8tab);
+  if (ft.d_q8rest) (void)hipFree(ft.d_q8rest);
   if (ft.d_qrrest) (void)hipFree(ft.d_qrrest);
   if (ft.d_qtlist) (void)hipFree(ft.d_qtlist);
   if (ft.d_qtabrow) (void)hipFree(ft.d_qtabrow);
@@ -657,8 +672,12 @@ static bool links_from_table(const int32_t* row, int D, int32_t ntiles, int32_t 
 
 // What a rectangle of w x h tiles saves against the tile kernels, in units of 0.1 us of one CU and one map (the constants of
 // strips_apply: 18.7 us per tile, 2.8 us per strip step): strips of 56 output columns, 2 D + 1 run-in steps each.
+// (the K = 8 strips -- cheb_qstrip8_kernel.h, D = 7 -- have 50 output columns, 16 run-in steps, ~2.6 us a step, against 27.5 us
+// per tile on the breadth-first tile kernel with its 7-ring halo)
 static int64_t qt_gain(int w, int h, int D) {
-  const int64_t ns = (16 * (int64_t)w + QS_USE - 1) / QS_USE;
+  const int use = D == Q8_D ? Q8_USE : QS_PX - 2 * D;
+  const int64_t ns = (16 * (int64_t)w + use - 1) / use;
+  if (D == Q8_D) return (int64_t)w * h * 275 - ns * (16 * (int64_t)h + Q8_RUNIN) * 26;
   return (int64_t)w * h * 187 - ns * (16 * (int64_t)h + 2 * D + 1) * 28;
 }
 
@@ -781,9 +800,12 @@ static void build_qtstrips(std::vector<QCand>& cands, int32_t ntiles, int D, std
         }
       *n_taken += (int64_t)bw * bh;
       const int X0 = 16, X1 = 16 + 16 * bw, Y0 = 16, Y1 = 16 + 16 * bh;
-      for (int x0 = X0; x0 < X1; x0 += QS_USE) {
+      // output columns of a strip, and how far left of the first one its lane 0 stands: the kernels take a lane's four pixels
+      // for one aligned group of four inside one tile, so both are multiples of four (D = 7: 48 columns behind 8 of lead-in)
+      const int use = D == Q8_D ? Q8_USE : QS_PX - 2 * D, lead = D == Q8_D ? 8 : D;
+      for (int x0 = X0; x0 < X1; x0 += use) {
         QStrip q{};
-        q.x0 = x0; q.w = std::min(QS_USE, X1 - x0); q.xs = x0 - D;
+        q.x0 = x0; q.w = std::min(use, X1 - x0); q.xs = x0 - lead;
         q.y0 = Y0; q.y1 = Y1;
         q.xlo = X0 - D; q.xhi = X1 - 1 + D; q.ylo = Y0 - D; q.yhi = Y1 - 1 + D;
         q.tab = toff; q.tws = TW;
@@ -871,6 +893,26 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
     }
     if (fp->d_rowflag && struct_classify_tiles(plan, fp->d_rowflag, ntiles, D, out_rows, cls.data()) != DSPH_OK)
       std::fill(cls.begin(), cls.end(), 0);
+  }
+  // K = 8 quad strips: which tiles' 7-ring regions are regular squares of the Morton plane (the same row flags, a deeper ring).
+  // Every tile still gets its breadth-first tables (other shapes and the weight gradient run on them).  On a sharded plan
+  // the candidates are the INTERIOR tiles (region inside the rank's own rows): they run with the interior part of a forward.
+  std::vector<unsigned char> cls8;
+  if (D == Q8_D && plan->opt.use_struct && plan->opt.strips != 2 && plan->opt.strip_form == 0 && !fp->wide) {
+    if (!fp->rows_tried) {
+      fp->rows_tried = true;
+      if (struct_build_rows(plan, &fp->d_gvals8, &fp->d_gdiag, &fp->d_rowflag) != DSPH_OK) {
+        if (fp->d_gvals8) (void)hipFree(fp->d_gvals8);
+        if (fp->d_gdiag) (void)hipFree(fp->d_gdiag);
+        if (fp->d_rowflag) (void)hipFree(fp->d_rowflag);
+        fp->d_gvals8 = fp->d_gdiag = nullptr;
+        fp->d_rowflag = nullptr;
+      }
+    }
+    if (fp->d_rowflag) {
+      cls8.assign((size_t)ntiles, 0);
+      if (struct_classify_tiles(plan, fp->d_rowflag, ntiles, D, out_rows, cls8.data(), Q8_D) != DSPH_OK) cls8.clear();
+    }
   }
   // class-T candidates: whatever the classification left over, when the structured kernel is in play at all
   const bool try_tables = !full && D <= ST_DMAX && plan->opt.use_struct && plan->opt.use_tables && fp->d_rowflag != nullptr;
@@ -1151,6 +1193,45 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
     qt_rows.insert(qt_rows.end(), trow_b.begin(), trow_b.end());
     qt_vals.insert(qt_vals.end(), tval_b.begin(), tval_b.end());
   }
+  // K = 8: rectangles of the depth-7 regular tiles (virtual Morton neighbours: what the classification verified)
+  std::vector<QStrip> q8strips;
+  std::vector<int32_t> q8tab, q8rest;
+  ft.n_q8_tiles = 0;
+  if (!cls8.empty()) {
+    std::vector<QCand> cands;
+    static const int ddx[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, ddy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+    for (int32_t t = 0; t < ntiles; ++t) {
+      if ((cls8[(size_t)t] & 3) != 3) continue;
+      QCand c{};
+      c.tile = t; c.tix = -1; c.taken = false;
+      const int tx = (int)st_compress((unsigned)t), ty = (int)st_compress((unsigned)t >> 1);
+      for (int d = 0; d < 8; ++d) {
+        const int nx = tx + ddx[d], ny = ty + ddy[d];
+        const int64_t nt = nx < 0 || ny < 0 ? -1 : (int64_t)st_morton((unsigned)nx, (unsigned)ny);
+        c.nbr[d] = nt >= 0 && nt < ntiles ? (int32_t)nt : -1;
+      }
+      cands.push_back(c);
+    }
+    build_qtstrips(cands, ntiles, D, q8strips, q8tab, &ft.n_q8_tiles);
+    std::vector<unsigned char> took((size_t)ntiles, 0);
+    for (const QCand& c : cands)
+      if (c.taken) took[(size_t)c.tile] = 1;
+    for (int i = 0; i < ft.n_part; ++i) {
+      if (i == ft.n_interior) ft.n_q8rest_interior = (int)q8rest.size();
+      if (!took[(size_t)interior[(size_t)i]]) q8rest.push_back(interior[(size_t)i]);
+    }
+    if (ft.n_interior >= ft.n_part) ft.n_q8rest_interior = (int)q8rest.size();
+  }
+  ft.n_q8strips = (int)q8strips.size();
+  ft.h_q8strips = q8strips;
+  ft.h_q8tab = q8tab;
+  ft.n_q8rest = (int)q8rest.size();
+  std::vector<int32_t> q8prefix(1, 0);
+  for (const QStrip& q : q8strips) q8prefix.push_back(q8prefix.back() + (q.y1 - q.y0));
+  ft.q8tape_rows = q8prefix.back();
+  if (q8strips.empty()) q8strips.push_back(QStrip());
+  if (q8rest.empty()) q8rest.push_back(0);
+  q8tab.resize(q8tab.size() + 8, 0);
   ft.n_qrrest = (int)qrrest.size();
   ft.n_qt = (int)qt_list.size();
   if (qrrest.empty()) qrrest.push_back(0);
@@ -1219,6 +1300,10 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
               up((void**)&ft.d_qstrips, qstrips.data(), qstrips.size() * sizeof(QStrip)) &&
               up((void**)&ft.d_qprefix, qprefix.data(), qprefix.size() * 4) &&
               up((void**)&ft.d_qtab, qtab.data(), qtab.size() * 4) &&
+              up((void**)&ft.d_q8strips, q8strips.data(), q8strips.size() * sizeof(QStrip)) &&
+              up((void**)&ft.d_q8prefix, q8prefix.data(), q8prefix.size() * 4) &&
+              up((void**)&ft.d_q8tab, q8tab.data(), q8tab.size() * 4) &&
+              up((void**)&ft.d_q8rest, q8rest.data(), q8rest.size() * 4) &&
               up((void**)&ft.d_qrrest, qrrest.data(), qrrest.size() * 4) &&
               up((void**)&ft.d_qtlist, qt_list.data(), qt_list.size() * 4) &&
               up((void**)&ft.d_qtabrow, qt_rows.data(), qt_rows.size() * 4) &&
@@ -1255,7 +1340,7 @@ static size_t wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
 static size_t all_frag_bytes(int32_t Fin, int32_t Fout, int32_t K) {
   return wfrag_bytes(Fin, Fout, K) + struct_wfrag_bytes(Fin, Fout, K) + strip_wimg_bytes(Fin, Fout, K) +
          2 * istrip_wimg_bytes(K, DSPH_PREC_BF16X6) +  // (the largest of the three arithmetics, two 32-column blocks)
-         (qstrip_shape_ok(Fin, Fout, K) ? qstrip_wimg_bytes() : 0);
+         (qstrip_shape_ok(Fin, Fout, K) ? qstrip_wimg_bytes() : 0) + (qstrip8_shape_ok(Fin, Fout, K) ? qstrip8_wimg_bytes() : 0);
 }
 
 // The structured-tile kernel addresses x by 32-bit byte offsets inside a map: larger maps take BFS tables throughout.
@@ -1399,6 +1484,18 @@ static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fi
   return span * 30 * 103 < ft.n_strip_tiles * N * 187 / fp->num_cu * 100;
 }
 
+// The K = 8 quad strips take their rectangles for a whole-map forward of their shape (32 -> 32, three-term bf16, Chebyshev basis,
+// bias / ReLU epilogue) when the strips pay for the batch by the same kind of rule (a step 2.6 us, a tile on the breadth-first
+// kernel 27.5 us of a CU); DSPH_OPT_STRIPS 1 / 2: always / never.
+static bool q8_applies(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t N,
+                       int32_t ld) {
+  // (no limit on the size of a map: this kernel forms its addresses in 64 bits -- configs[3] is 6.4 GB of x)
+  if (ft.n_q8strips == 0 || !qstrip8_shape_ok(Fin, Fout, K) || precision != DSPH_PREC_BF16X3 || ld % 4 != 0 || N < 1) return false;
+  if (plan->opt.strips == 1) return true;
+  const int64_t span = qstrip8_split(plan->fused->num_cu, ft.q8tape_rows, N, ft.q8tape_rows / std::max(1, ft.n_q8strips), nullptr, nullptr, nullptr);
+  return span * 26 * 103 < ft.n_q8_tiles * N * 275 / plan->fused->num_cu * 100;
+}
+
 // The input-side strip kernel takes the rectangles of every layer with at most 16 input channels (any arithmetic, K = 2 .. 5,
 // any output width), unless DSPH_OPT_STRIPS says never.  No cost rule: its workers are single waves and the kernel cuts the
 // strips into as many row segments as the batch needs, so small maps fill the device too (istrip_segments).
@@ -1437,6 +1534,10 @@ int64_t fused_strip_tiles(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t
     const FusedTiles& fti = get_tiles(plan, K - 1, want_full(plan, pad4(Fin), false));
     return fti.ok && istrips_apply(plan, fti, pad4(Fin), K, std::min(Fout, 64), Fout) ? fti.n_strip_tiles : 0;
   }
+  if (qstrip8_shape_ok(Fin, Fout, K)) {
+    const FusedTiles& ft8 = get_tiles(plan, K - 1, want_full(plan, Fin, false));
+    return ft8.ok && q8_applies(plan, ft8, Fin, Fout, K, precision, N, Fout) ? ft8.n_q8_tiles : 0;
+  }
   if (Fin != pad4(Fin) || Fout < 64) return 0;
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fin, false));
   if (!ft.ok) return 0;
@@ -1450,10 +1551,11 @@ int64_t fused_strip_pairs(const dsph_plan* plan, int32_t K, int32_t* out, int64_
   const FusedTiles& ft = get_tiles(plan, K - 1, false);
   if (!ft.ok) return -1;
   static_assert(sizeof(StripPair) == 12 * sizeof(int32_t), "StripPair is twelve int32");
-  if (plan->opt.strip_form == 0 && K == 5 && !ft.h_qstrips.empty()) {  // the quad strips, in the same record: one strip, the second empty
-    const int64_t n = (int64_t)ft.h_qstrips.size();
+  if (plan->opt.strip_form == 0 && ((K == 5 && !ft.h_qstrips.empty()) || (K == Q8_K && !ft.h_q8strips.empty()))) {  // the quad strips, in the same record: one strip, the second empty
+    const std::vector<QStrip>& hq = K == Q8_K ? ft.h_q8strips : ft.h_qstrips;
+    const int64_t n = (int64_t)hq.size();
     for (int64_t i = 0; i < n && i < cap; ++i) {
-      const QStrip& q = ft.h_qstrips[(size_t)i];
+      const QStrip& q = hq[(size_t)i];
       const int32_t rec[12] = {q.x0, q.x0, q.w, 0, q.xs, q.xs, q.y0, q.y1, q.xlo, q.xhi, q.ylo, q.yhi};
       memcpy(out + 12 * i, rec, sizeof(rec));
     }
@@ -1470,12 +1572,14 @@ int64_t fused_strip_rows(const dsph_plan* plan, int32_t K, int64_t strip, int64_
   if (!plan->fused || K < 2 || K - 1 > FUSED_DMAX) return -1;
   const FusedTiles& ft = get_tiles(plan, K - 1, false);
   if (!ft.ok || strip < 0) return -1;
-  if (plan->opt.strip_form == 0 && K == 5 && !ft.h_qstrips.empty()) {
-    if (strip >= (int64_t)ft.h_qstrips.size()) return -1;
-    const QStrip& q = ft.h_qstrips[(size_t)strip];
+  if (plan->opt.strip_form == 0 && ((K == 5 && !ft.h_qstrips.empty()) || (K == Q8_K && !ft.h_q8strips.empty()))) {
+    const std::vector<QStrip>& hq = K == Q8_K ? ft.h_q8strips : ft.h_qstrips;
+    const std::vector<int32_t>& htab = K == Q8_K ? ft.h_q8tab : ft.h_qtab;
+    if (strip >= (int64_t)hq.size()) return -1;
+    const QStrip& q = hq[(size_t)strip];
     for (int64_t i = 0; i < n; ++i) {
       const int x = std::min(std::max(xy[2 * i], q.xlo), q.xhi), y = std::min(std::max(xy[2 * i + 1], q.ylo), q.yhi);
-      rows[i] = (int64_t)ft.h_qtab[(size_t)(q.tab + (y >> 4) * q.tws + (x >> 4))] + (int64_t)st_morton((unsigned)x & 15u, (unsigned)y & 15u);
+      rows[i] = (int64_t)htab[(size_t)(q.tab + (y >> 4) * q.tws + (x >> 4))] + (int64_t)st_morton((unsigned)x & 15u, (unsigned)y & 15u);
     }
     return n;
   }
@@ -2021,6 +2125,24 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     DSPH_HIP(hipGetLastError());
   }
 
+  // K = 8, 32 -> 32: the rectangles of depth-7 regular tiles on the quad strips, the rest of the tiles below
+  const bool q8 = !planes_mode && part != 2 && pool == nullptr && only == 0 && Fin_w == Fin && beta_rest != 0.f &&
+                  (act == DSPH_ACT_NONE || act == DSPH_ACT_RELU) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                  q8_applies(plan, ft, Fin, Fout, K, precision, N, ld);
+  if (q8) {
+    QStrip8Launch q;
+    q.x = x; q.w = w; q.bias = bias; q.y = y;
+    q.wimg = static_cast<unsigned char*>(workspace) + all_frag_bytes(Fin, Fout, K) - qstrip8_wimg_bytes();
+    q.strips = ft.d_q8strips; q.tab = ft.d_q8tab; q.prefix = ft.d_q8prefix; q.tape_rows = ft.q8tape_rows;
+    q.gvals8 = plan->fused->d_gvals8; q.gdiag = plan->fused->d_gdiag;
+    q.x_rows = plan->n_cols; q.y_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0]; q.N = N;
+    q.nstrips = ft.n_q8strips; q.act = act; q.ld = ld; q.ld_w = ld; q.num_cu = plan->fused->num_cu;
+    q.prep_weights = fused_images_claim(plan, workspace, IMG_Q8);
+    const int rc = launch_cheb_qstrip8(q, stream);
+    if (rc != DSPH_OK) return rc;
+    if ((part == 0 ? ft.n_q8rest : ft.n_q8rest_interior) == 0) return DSPH_OK;
+  }
+
   FusedArgs args;
   args.planes_out = planes_out;
   args.dy = dy;
@@ -2056,6 +2178,10 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   // the BFS-tile kernel handles the tiles of d_part (every tile of a full table, the class-G ones otherwise)
   args.tile_list = part == 0 ? (ft.n_part == ft.ntiles ? nullptr : ft.d_part) : (part == 1 ? ft.d_part : ft.d_part + ft.n_interior);
   args.ntiles = part == 0 ? ft.n_part : (part == 1 ? ft.n_interior : ft.n_part - ft.n_interior);
+  if (q8) {  // (part 0: every tile the strips leave; part 1: the interior ones of them -- the boundary tiles are never the strips')
+    args.tile_list = ft.d_q8rest;
+    args.ntiles = part == 0 ? ft.n_q8rest : ft.n_q8rest_interior;
+  }
   if (wgrad_mode && wg_ntiles >= 0) {  // (the strips' pixels go to cheb_qwgrad.hip: launch_cheb_fused_qwgrad)
     args.tile_list = wg_tiles;
     args.ntiles = wg_ntiles;

@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void struct_rows_kernel(const int32_t* __restr
 // One 256-row tile: cls[t] bit 0 = class R for depth D, bit 1 = interior (every region cell is an
 // output row of the plan, i.e. no halo row of another rank is read).
 __host__ __device__ inline unsigned char struct_tile_body(int t, const unsigned char* __restrict__ flag, int D, int64_t n_rows,
-                                                          int64_t n_cols, int64_t out_rows) {
+                                                          int64_t n_cols, int64_t out_rows, int dlimit) {
   const int64_t row0 = (int64_t)t * 256;
-  bool ok = D >= 1 && D <= ST_DMAX && row0 + 256 <= out_rows && row0 + 256 <= 0xffffffffLL;
+  bool ok = D >= 1 && D <= dlimit && row0 + 256 <= out_rows && row0 + 256 <= 0xffffffffLL;
   bool interior = true;
   if (ok) {
     const int X0 = (int)st_compress((unsigned)row0), Y0 = (int)st_compress((unsigned)row0 >> 1);
@@ -83,10 +83,10 @@ __host__ __device__ inline unsigned char struct_tile_body(int t, const unsigned 
 }
 __global__ __launch_bounds__(256) void struct_tiles_kernel(const unsigned char* __restrict__ flag, int ntiles, int D,
                                                            int64_t n_rows, int64_t n_cols, int64_t out_rows,
-                                                           unsigned char* __restrict__ cls) {
+                                                           unsigned char* __restrict__ cls, int dlimit) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= ntiles) return;
-  cls[t] = struct_tile_body(t, flag, D, n_rows, n_cols, out_rows);
+  cls[t] = struct_tile_body(t, flag, D, n_rows, n_cols, out_rows, dlimit);
 }
 
 // Weight fragments of the structured kernel, one 2 KiB block per (slice c, order k, column block nb), a slice
@@ -181,14 +181,14 @@ int struct_patch_rows(const dsph_plan* plan, float* gvals8, float* gdiag, const 
 
 // cls (host, ntiles bytes) <- classification of every 256-row tile for depth D
 int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, int ntiles, int D, int64_t out_rows,
-                          unsigned char* h_cls) {
+                          unsigned char* h_cls, int dlimit) {
   unsigned char* d_cls = nullptr;
   DSPH_HIP(hipMalloc((void**)&d_cls, (size_t)ntiles));
 #ifdef DSPH_HOST_EMU
-  for (int t = 0; t < ntiles; ++t) d_cls[t] = struct_tile_body(t, d_flag, D, plan->n_rows, plan->n_cols, out_rows);
+  for (int t = 0; t < ntiles; ++t) d_cls[t] = struct_tile_body(t, d_flag, D, plan->n_rows, plan->n_cols, out_rows, dlimit);
 #else
   hipLaunchKernelGGL(struct_tiles_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, 0, d_flag, ntiles, D, plan->n_rows,
-                     plan->n_cols, out_rows, d_cls);
+                     plan->n_cols, out_rows, d_cls, dlimit);
 #endif
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(h_cls, d_cls, (size_t)ntiles, hipMemcpyDeviceToHost);

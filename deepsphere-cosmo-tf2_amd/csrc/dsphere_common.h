@@ -132,7 +132,7 @@ int launch_cheb_fused_wgrad(const dsph_plan* plan, const float* x, const float* 
 size_t fused_workspace_bytes(const dsph_plan* plan, int64_t N, int32_t Fin, int32_t Fout, int32_t K,
                              int32_t precision);
 // which packed weight images a workspace block holds (DSPH_FWD_KEEP_WEIGHTS; FusedPlan::images)
-enum : uint32_t { IMG_BFS = 1, IMG_STRUCT = 2, IMG_STRIP = 4, IMG_ISTRIP = 8, IMG_QSTRIP = 16, IMG_SPLIT = 32 };
+enum : uint32_t { IMG_BFS = 1, IMG_STRUCT = 2, IMG_STRIP = 4, IMG_ISTRIP = 8, IMG_QSTRIP = 16, IMG_SPLIT = 32, IMG_Q8 = 64 };
 void fused_images_begin(const dsph_plan* plan, const void* ws, uint64_t key, bool keep);
 bool fused_images_claim(const dsph_plan* plan, const void* ws, uint32_t bit);
 void fused_images_forget(const dsph_plan* plan, const void* ws);
@@ -182,7 +182,7 @@ int struct_build_rows(const dsph_plan* plan, float** gvals8, float** gdiag, unsi
 // class-T tiles that the table-addressed quad strips evaluate, by the directions of the tile's verified embedding
 int struct_patch_rows(const dsph_plan* plan, float* gvals8, float* gdiag, const int32_t* rows, const float* vals, int64_t n);
 int struct_classify_tiles(const dsph_plan* plan, const unsigned char* d_flag, int ntiles, int D, int64_t out_rows,
-                          unsigned char* h_cls);
+                          unsigned char* h_cls, int dlimit = 4 /* ST_DMAX; 7 for the K = 8 quad strips' rectangles */);
 bool struct_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
 size_t struct_wfrag_bytes(int32_t Fin, int32_t Fout, int32_t K);
 int launch_cheb_struct(const StructLaunch& s, hipStream_t stream);
@@ -229,6 +229,22 @@ bool qstrip_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
 size_t qstrip_wimg_bytes();
 int64_t qstrip_split(int num_cu, int64_t tape_rows, int64_t N, int64_t mean_height, int* grid, int* pieces, int* wg_per_piece);
 int launch_cheb_qstrip(const QStripLaunch& s, hipStream_t stream);
+
+// K = 8, 32 -> 32 quad strips (cheb_qstrip8.hip, round 6)
+struct QStrip8Launch {
+  const float* x; const float* w; const float* bias; float* y;
+  unsigned char* wimg;       // workspace: qstrip8_wimg_bytes()
+  const QStrip* strips; const int32_t* tab; const int32_t* prefix;
+  int64_t tape_rows;
+  const float* gvals8; const float* gdiag;
+  int64_t x_rows, y_rows, N;
+  int32_t nstrips, act, ld, ld_w, num_cu;
+  bool prep_weights = true;
+};
+bool qstrip8_shape_ok(int32_t Fin, int32_t Fout, int32_t K);
+size_t qstrip8_wimg_bytes();
+int64_t qstrip8_split(int num_cu, int64_t tape_rows, int64_t N, int64_t mean_height, int* grid, int* pieces, int* wg_per_piece);
+int launch_cheb_qstrip8(const QStrip8Launch& s, hipStream_t stream);
 
 // quad-strip weight gradient (cheb_qwgrad.hip, round 5): dW of a K = 5, 64 -> 64 layer on the strips of the quad-strip kernel
 struct QWgradLaunch {

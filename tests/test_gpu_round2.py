@@ -292,11 +292,18 @@ def test_config4_full_size():
     cols, vals = _grid_ell(nside)
     M = cols.shape[0]
     plan, x, W, b, y, s = _headline_check(cols, vals, N, Fin, Fout, K, _native.PREC_BF16X3, seed=4)
-    centres = _special_rows(nside, M, np.random.default_rng(4))
+    # round 6: the tiles whose 7-ring region stays inside a base pixel run on the K = 8 quad strips (csrc/cheb_qstrip8_kernel.h):
+    # centres on the strips' seams in x (every 48 columns), on their first and last rows, on tile-row seams of the tables
+    n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
+    assert n_strip == 12 * (nside // 16 - 2) ** 2, "12 base pixels x (126 x 126) tiles on the strips, as bench.py --config c4 times it"
+    pairs = plan.strip_pairs(K)
+    seams = _strip_seam_rows(plan, K, pairs, stride=5)
+    assert seams.size > 2000 and seams.max() < M
+    centres = np.unique(np.concatenate([_special_rows(nside, M, np.random.default_rng(4)), seams[::3]]))
     ref = _patch_reference(cols, vals, x, W, K, centres, bias=b, activation="relu")
     got = y[:, torch.as_tensor(centres).cuda()].cpu().numpy()
     err = np.abs(got - ref).max() / s
-    print(f"config 4 full size: M = {M}, err {err:.2e}")
+    print(f"config 4 full size: M = {M}, {n_strip} tiles on {len(pairs)} K = 8 quad strips, {centres.size} centres, err {err:.2e}")
     assert err < TOL
 
 

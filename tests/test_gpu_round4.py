@@ -74,8 +74,10 @@ def test_config2_as_benchmarked():
 
 def test_config4_shards_at_full_size():
     """nside 2048, K 8, 32 -> 32, batch 1, split over 4 ranks (3 base pixels each, 7-ring halo): every rank's local plan run
-    on this GPU with its halo rows taken from the global map must reproduce the unsharded rows BIT FOR BIT (both sides on
-    the breadth-first-table kernel: DSPH_OPT_SPLIT = never on the unsharded plan, a plan with levels never splits)."""
+    on this GPU with its halo rows taken from the global map must reproduce the unsharded rows BIT FOR BIT (DSPH_OPT_SPLIT =
+    never on the unsharded plan, a plan with levels never splits).  Round 6: both sides run the K = 8 quad strips on the tiles
+    whose 7-ring region stays inside a base pixel -- a rank owns whole base pixels, so its rectangles are the unsharded plan's
+    and every output is summed in the same order -- and the breadth-first tile kernel on the base pixels' border tiles."""
     from deepsphere import sharding
 
     nside, N, Fin, Fout, K, world = 2048, 1, 32, 32, 8, 4
@@ -87,12 +89,14 @@ def test_config4_shards_at_full_size():
     W = _dev((rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32))
     plan = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_SPLIT: _native.SPLIT_NEVER})
     full, _ = _native.cheb_forward(plan, x, W, None, K, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    assert plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N) == 12 * (nside // 16 - 2) ** 2
     plan.close()
     for r in range(world):
         lay = sharding.ShardLayout(cols, vals, K, r, world)
         a, e = lay.own
         assert e - a == 3 * nside * nside and lay.n_cols > lay.n_own
         lp = _native.LaplacianPlan(lay.local_cols, lay.local_vals, n_cols=lay.n_cols, device=0, levels=lay.levels)
+        assert lp.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N) == 3 * (nside // 16 - 2) ** 2, "the rank's base pixels' interiors on the strips"
         xl = x[:, torch.as_tensor(lay.local_ids).cuda()].contiguous()
         y, _ = _native.cheb_forward(lp, xl, W, None, K, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
         same = bool(torch.equal(y, full[:, a:e]))

@@ -140,6 +140,76 @@ def test_inference_batch_norm_is_folded_into_the_kernel_epilogue(shape):
     assert rel_err(y3.cpu().numpy(), ref3) < 2e-5
 
 
+@pytest.mark.parametrize("nside,N,act", [(128, 1, "relu"), (256, 3, None)])
+def test_k8_quad_strips_whole_map(nside, N, act):
+    """K = 8, 32 -> 32 (BASELINE configs[3]'s shape) on the three-role quad strips (csrc/cheb_qstrip8_kernel.h):
+    whole maps against the float64 oracle -- every row: the strips' seams in x, the run-time cuts of the tape, the rectangles' edges
+    against the breadth-first tiles that keep the base-pixel borders -- and against the same plan with the strips switched off
+    (the tile kernel sums in forward order: equal to rounding)."""
+    K, Fin, Fout = 8, 32, 32
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(nside + N)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    ref = orc.chebyshev_forward(_csr(cols, vals), x, W, K, bias=b, activation=act)
+    kw = dict(act=_native.ACT_RELU if act == "relu" else _native.ACT_NONE, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    ys = {}
+    for strips in (_native.STRIPS_ALWAYS, _native.STRIPS_NEVER):
+        plan = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_STRIPS: strips})
+        plan.prepare(K, Fin, Fout=Fout)
+        n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
+        nt = nside // 16
+        if strips == _native.STRIPS_ALWAYS:
+            assert n_strip == 12 * (nt - 2) ** 2, "the tiles whose 7-ring region stays inside their base pixel"
+            rec = plan.strip_pairs(K)
+            assert rec.shape[1] == 12 and np.all(rec[:, 2] <= 48) and np.all(rec[:, 0] - rec[:, 4] == 8), "48 output columns behind 8 of lead-in"
+        else:
+            assert n_strip == 0
+        y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, **kw)
+        y2, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, **kw)
+        assert torch.equal(y, y2), "two launches of the same inputs must agree bit for bit"
+        err = rel_err(y.cpu().numpy(), ref)
+        print(f"K 8 strips {strips} nside {nside} N {N}: {n_strip} strip tiles, rel err {err:.2e}")
+        assert err < 1e-5
+        ys[strips] = y
+    assert rel_err(ys[_native.STRIPS_ALWAYS].cpu().numpy(), ys[_native.STRIPS_NEVER].cpu().numpy()) < 2e-5
+
+
+def test_headline_shape_on_the_reference_graph_as_benchmarked():
+    """the headline shape (K 5, 64 -> 64, three-term split) on the graph a user of the reference's HealpyGCNN
+    gets (healpy_networks.py:110-118: symmetrised 8 nearest neighbours, ELL width 11) at the size bench.py --config knn8h times it
+    (nside 512, batch 16): the patch oracle at the twelve base pixels' corners and borders, tile corners and random rows, in the
+    first, a middle and the last map."""
+    import bench
+    from test_gpu_round2 import _patch_reference, _special_rows
+
+    nside, K, Fin, Fout, N = bench.CONFIGS["knn8h"]
+    dev = torch.device("cuda", 0)
+    cols, vals, lmax = bench.build_laplacian_knn(nside, dev, bench.KNN["knn8h"])
+    M = cols.shape[0]
+    rng = np.random.default_rng(8)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    plan = _native.LaplacianPlan(cols, vals, device=0)
+    plan.prepare(K, Fin, Fout=Fout)
+    x = torch.randn((N, M, Fin), device=dev, generator=torch.Generator(device=dev).manual_seed(8))
+    y, _ = _native.cheb_forward(plan, x, _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    s = float(y.abs().max())
+    n_struct, n_bfs = plan.tile_counts(K)
+    n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
+    centres = np.unique(np.concatenate([_special_rows(nside, M, rng), rng.integers(0, M, size=300)]))
+    sel = [0, N // 2, N - 1]
+    ref = _patch_reference(cols, vals, x[sel], W, K, centres, bias=b, activation="relu")
+    got = y[sel][:, torch.as_tensor(centres).cuda()].cpu().numpy()
+    err = float(np.abs(got - ref).max() / s)
+    print(f"knn8h: M {M}, ELL width {cols.shape[1]}, tiles: {n_strip} on the quad strips, {n_struct - n_strip} structured, {n_bfs} class G "
+          f"({100.0 * n_bfs / (M // 256):.1f} %); {centres.size} rows x {len(sel)} maps: err {err:.2e}")
+    assert err < 1e-5
+    assert n_struct + n_bfs == M // 256
+
+
 def test_bench_gpus_2_as_given():
     """`python3 bench.py --gpus 2 ...` without a launcher (the form the driver uses): bench.py starts its own ranks as a child job
     and relays rank 0's line.  On a one-GPU box the two ranks share the GPU and stage halo rows through the host (--backend gloo)."""

@@ -333,4 +333,5 @@ def test_plan_builders_under_sanitizers():
     # borders -- with every strip's table of tile bases verified against the graph itself by the driver)
     assert "grid nside 128: K 5 64->64: tile_counts rc 0 struct 744 bfs 24, fused_ok 1, strip tiles [588, 588, 588]" in r.stdout
     assert "grid nside 128: 18 strips, 150528 output pixels = 588 tiles, tables verified against the graph" in r.stdout
+    assert "grid nside 128 K 8: 24 strips, 110592 output pixels = 432 tiles, tables verified against the graph" in r.stdout
     assert "cap nside 128 superpixels 8: " in r.stdout and "tables verified against the graph" in r.stdout.split("cap nside 128 superpixels 8: ")[1]

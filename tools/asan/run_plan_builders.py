@@ -85,15 +85,15 @@ def look(h, K, Fin, Fout, name, flags=1, N=(1, 3, 16)):
     return a.value, b.value, strips
 
 
-def check_strip_tables(h, K, cols, vals, name):
+def check_strip_tables(h, K, cols, vals, name, D=4):
     """Every quad strip's table against the graph itself: a pixel's row, looked up through dsph_plan_strip_rows, must have its
     non-zeros of L~ exactly on the rows of the eight neighbouring pixels of the strip's plane (and itself) -- for every output
-    pixel and every halo pixel a level is evaluated on (rings 0 .. 3 of the rectangle); output pixels are covered once."""
+    pixel and every halo pixel a level is evaluated on (rings 0 .. D - 1 of the rectangle); output pixels are covered once."""
     rec = look.records
     seen = np.zeros(cols.shape[0], np.int32)
     for s, r in enumerate(rec):
         x0, w, y0, y1, xlo, xhi, ylo, yhi = int(r[0]), int(r[2]), int(r[6]), int(r[7]), int(r[8]), int(r[9]), int(r[10]), int(r[11])
-        xa, xb = max(x0 - 3, xlo + 1), min(x0 + w + 3, xhi)          # evaluated columns of this strip (its neighbours cover the rest)
+        xa, xb = max(x0 - (D - 1), xlo + 1), min(x0 + w + (D - 1), xhi)  # evaluated columns of this strip (its neighbours cover the rest)
         ys = np.arange(ylo, yhi + 1)
         xs = np.arange(xa - 1, xb + 1)
         X, Y = np.meshgrid(xs, ys, indexing="ij")
@@ -102,7 +102,7 @@ def check_strip_tables(h, K, cols, vals, name):
         assert LIB.dsph_plan_strip_rows(h, K, s, xy.shape[0], xy.ctypes.data, rows.ctypes.data) == 0
         R = rows.reshape(X.shape)
         assert R.min() >= 0 and R.max() < cols.shape[0]
-        inner = R[1:-1, 1:-1]                                          # rings 0 .. 3
+        inner = R[1:-1, 1:-1]                                          # rings 0 .. D - 1
         nb = np.stack([R[1 + dx: R.shape[0] - 1 + dx, 1 + dy: R.shape[1] - 1 + dy] for dx in (-1, 0, 1) for dy in (-1, 0, 1)], -1)
         c = cols[inner.ravel()]
         v = vals[inner.ravel()]
@@ -153,6 +153,9 @@ def main():
             assert check_strip_tables(h, 5, cols, vals, f"grid nside {nside}") == st[0]
         look(h, 5, 16, 32, f"grid nside {nside}")
         look(h, 3, 1, 16, f"grid nside {nside}")
+        if nside == 128:  # the K = 8, 32 -> 32 quad strips: rectangles of the tiles whose 7-ring region stays inside a base pixel
+            _, _, st8 = look(h, 8, 32, 32, f"grid nside {nside}")
+            assert st8[0] == 12 * 36 and check_strip_tables(h, 8, cols, vals, f"grid nside {nside} K 8", D=7) == st8[0]
         if nside == 64:
             look(h, 8, 32, 32, f"grid nside {nside}")          # 7-ring BFS tables
             look(h, 10, 16, 32, f"grid nside {nside}")         # the chain of passes
