@@ -474,11 +474,11 @@ class Chebyshev(torch.nn.Module):
 
     def forward_pool(self, input_tensor, pool_type="MAX"):
         """``HealpyPool(p=1, pool_type)(self(input_tensor))`` in ONE pass where the kernels can (``dsph_poly_forward_pool``: a
-        layer without batch norm, activation none or ReLU, a width that is a multiple of four, inference, whole unsharded maps --
+        layer with activation none or ReLU (batch norm, if any, with its moving statistics: folded), a width that is a multiple of four, inference, whole unsharded maps --
         every shape but 64 -> 64 on maps large enough for the Clenshaw strips): the strip kernel reduces the four NEST children in its epilogue and the full-resolution output, 16 times the
         input of a 1 -> 16 layer, is never written.  Returns ``None`` when it cannot -- the caller then runs the two layers
         (``HealpyGCNN.forward`` does).  Same values as the two layers (bit for bit for "MAX")."""
-        if pool_type not in ("MAX", "AVG") or self.use_bn or not isinstance(input_tensor, torch.Tensor) or input_tensor.dim() != 3:
+        if pool_type not in ("MAX", "AVG") or not isinstance(input_tensor, torch.Tensor) or input_tensor.dim() != 3:
             return None
         if self._act_code not in (_native.ACT_NONE, _native.ACT_RELU) or getattr(self, "_use_graph", False):
             return None
@@ -501,10 +501,13 @@ class Chebyshev(torch.nn.Module):
             return None
         x = input_tensor.detach().to(device=self._device, dtype=torch.float32).contiguous()
         bias = self.bias.detach().reshape(-1).contiguous() if self.use_bias else None
-        wkey = (self.kernel.data_ptr(), self.kernel._version, self._prec_code(), (self.algo, N > 1),
+        kernel, kver = self.kernel.detach(), self.kernel._version
+        if self.use_bn:  # (inference: the moving statistics folded into weights and bias, as in forward)
+            kernel, bias, kver = self._folded_bn()
+        wkey = (kernel.data_ptr(), kver, self._prec_code(), (self.algo, N > 1),
                 None if self._workspace is None else self._workspace.data_ptr())
         y, self._workspace = _native.cheb_forward_pool(
-            plan, x, self.kernel.detach(), bias, self.K, pool_type=_native.POOL_MAX if pool_type == "MAX" else _native.POOL_AVG,
+            plan, x, kernel, bias, self.K, pool_type=_native.POOL_MAX if pool_type == "MAX" else _native.POOL_AVG,
             act=self._act_code, precision=self._prec_code(), workspace=self._workspace,
             basis=self._basis, keep_weights=getattr(self, "_wkey", None) == wkey)
         self._wkey = wkey[:4] + (self._workspace.data_ptr() if self._workspace is not None else None,)

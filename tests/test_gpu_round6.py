@@ -125,6 +125,20 @@ def test_inference_batch_norm_is_folded_into_the_kernel_epilogue(shape):
         print(f"BN folded, nside {nside} {Fin}->{Fout} trial {trial}: rel err {err:.2e}")
         assert err < 2e-5  # (the three-term bf16 split's tolerance, TOL_BF16X3 of the other tests: max|y| after the ELU is small)
         assert torch.equal(y, y2)
+    # ... and with the pooling in the same pass (dsph_poly_forward_pool) where the kernels can: HealpyPool(MAX)(layer(x)), bit for bit
+    if layer._act_code in (_native.ACT_NONE, _native.ACT_RELU):
+        pass  # (this layer's ELU is not a pooled epilogue; the ReLU variant below)
+    relu = gnn_layers.Chebyshev.from_prepared_ell(cols, vals, K, Fout=Fout, device="cuda:0", use_bn=True, use_bias=True, activation="relu",
+                                                  initializer=lambda t: t.copy_(torch.from_numpy(W)))
+    relu.build((N, M, Fin))
+    with torch.no_grad():
+        relu.bn.running_mean.copy_(layer.bn.running_mean)
+        relu.bn.running_var.copy_(layer.bn.running_var)
+        yp = relu.forward_pool(_dev(x), "MAX")
+        yf = relu(_dev(x))
+    if yp is not None:
+        assert torch.equal(yp, yf.reshape(N, M // 4, 4, Fout).amax(dim=2)), "conv + BN + bias + ReLU + pool in one pass"
+        print(f"BN folded, pooled epilogue: {tuple(yp.shape)}")
     # batch statistics (training=True) stay in the host framework: same layer, reference semantics
     with torch.no_grad():
         yt = layer(_dev(x), training=True)

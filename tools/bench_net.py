@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """A DeepSphere-style stack end to end (SURVEY 8 f: the callers either side of the path): Chebyshev layers with NEST max-pooling
 between them, from nside 512 down to nside 8 -- the shapes a network has, first layers to the small maps at its end.
-    python tools/bench_net.py [batch] [knn] [nofuse]   (knn: the reference's 8-neighbour k-NN graphs instead of the grid stencil;
-                                                        nofuse: no conv + pool fusion)
+    python tools/bench_net.py [batch] [knn] [nofuse] [bn]   (knn: the reference's 8-neighbour k-NN graphs instead of the grid stencil;
+                                                        nofuse: no conv + pool fusion; bn: every layer with use_bn=True, the
+                                                        reference models' pattern -- inference, moving statistics folded)
 Prints one JSON line: ms per layer (HIP events) and for the whole forward."""
 import json
 import os
@@ -19,13 +20,14 @@ from deepsphere import gnn_layers, healpy_layers  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 knn = "knn" in sys.argv[2:]
+use_bn = "bn" in sys.argv[2:]
 nofuse = "nofuse" in sys.argv[2:]  # every layer and every pooling on its own (default: conv + pool in one pass where the kernels can)
 dev = torch.device("cuda", 0)
 STACK = [(512, 1, 16), (256, 16, 32), (128, 32, 64), (64, 64, 64), (32, 64, 64), (16, 64, 128), (8, 128, 128)]
 layers = []
 for nside, Fin, Fout in STACK:
     cols, vals, lmax = bench.build_laplacian_knn(nside, dev, 8) if knn else bench.build_laplacian(nside, dev)
-    layers.append(gnn_layers.Chebyshev.from_prepared_ell(cols, vals, 5, lmax=lmax, Fout=Fout, device=dev, use_bias=True, activation="relu"))
+    layers.append(gnn_layers.Chebyshev.from_prepared_ell(cols, vals, 5, lmax=lmax, Fout=Fout, device=dev, use_bias=True, activation="relu", use_bn=use_bn))
 pool = healpy_layers.HealpyPool(p=1, pool_type="MAX")
 x0 = torch.randn((N, 12 * 512 * 512, 1), device=dev)
 
@@ -70,5 +72,5 @@ with torch.no_grad():
 print(json.dumps({"stack": [f"nside {n}: {fi}->{fo}" for n, fi, fo in STACK], "K": 5, "batch": N, "graph": "knn8" if knn else "grid",
                   "layer_ms": [round(float(v), 3) for v in per], "forward_ms": round(total, 3),
                   "forward_ms_min_max": [round(each[0], 3), round(each[-1], 3)],
-                  "fused_pooling": not nofuse,
+                  "fused_pooling": not nofuse, "use_bn": use_bn,
                   "note": "Chebyshev (bias, ReLU) + HealpyPool(MAX, p=1) between layers; layer_ms by one event pair per layer (a layer that pools in its own epilogue: incl. the pooling)"}))
