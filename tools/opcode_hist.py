@@ -6,8 +6,8 @@ loop body: which instructions the shipped cheb_qstrip5_kernel issues per step, b
           --offload-device-only -S deepsphere-cosmo-tf2_amd/csrc/cheb_qstrip.hip -o /tmp/q.s
     python3 tools/opcode_hist.py /tmp/q.s _ZN4dsph19cheb_qstrip5_kernelILb1ELb0EEEvNS_10QStripArgsE
 
-A loop = the lines between a label and the LAST backward branch to it; the two largest loops of the quad-strip kernel are the
-H role's and the L role's three-step bodies (the step is unrolled three times)."""
+A loop = the lines between a label and the LAST backward branch to it; the innermost loops of the quad-strip kernel are the H
+role's (288 matrix instructions) and the L role's (72, and the y stores) three-step bodies (the step is unrolled three times)."""
 import collections
 import re
 import sys
@@ -86,10 +86,19 @@ def main():
             tgt = t.split()[-1]
             if tgt in labels and labels[tgt] <= i:
                 loops[tgt] = max(loops.get(tgt, 0), i)
-    big = sorted(((e - labels[l] + 1, l, labels[l], e) for l, e in loops.items()), reverse=True)[:4]
-    for n, l, a, e in big:
+    # the step bodies: loops of at least 1,000 instructions that hold no other such loop (the kernel's innermost loops are three
+    # steps each; with uniform branches inside a step the compiler makes several back edges of one loop: variants are listed once
+    # per distinct size class)
+    big = sorted((e - labels[l] + 1, l, labels[l], e) for l, e in loops.items() if e - labels[l] + 1 >= 1000)
+    inner = [b for b in big if not any(o is not b and o[2] >= b[2] and o[3] <= b[3] and (o[2], o[3]) != (b[2], b[3]) for o in big)]
+    seen = set()
+    for n, l, a, e in inner:
         h = collections.Counter(classify(op, t) for op, t in insts[a:e + 1])
-        show(h, f"loop {l}: {n} instructions")
+        key = (h["mfma"], h["vmem_store"], n // 64)
+        if key in seen:
+            continue
+        seen.add(key)
+        show(h, f"innermost loop {l}: {n} instructions")
         if "-v" in sys.argv:
             other = collections.Counter(op for op, t in insts[a:e + 1] if classify(op, t) in ("valu_other", "valu_mov", "valu_cvt_bit", "valu_int_addr", "valu_cmp_sel"))
             print("    non-stencil vector opcodes: " + ", ".join(f"{k} {v}" for k, v in other.most_common(30)))
