@@ -80,7 +80,11 @@ int launch_cheb_qstrip8(const QStrip8Launch& s, hipStream_t stream) {
   a.act = s.act;
   int grid;
   (void)qstrip8_split(s.num_cu, s.tape_rows, s.N, s.tape_rows / std::max(1, s.nstrips), &grid, &a.pieces, &a.wg_per_piece);
+#ifdef DSPH_Q8_SIX_WAVES  // (tuning: the six-wave variant, `top` fetching)
   hipLaunchKernelGGL(cheb_qstrip8_kernel<0>, dim3(grid), dim3(Q8_THREADS), 0, stream, a);
+#else
+  hipLaunchKernelGGL(cheb_qstrip8_kernel<1>, dim3(grid), dim3(512), 0, stream, a);
+#endif
   DSPH_HIP(hipGetLastError());
   return DSPH_OK;
 }

@@ -60,8 +60,12 @@ __device__ __forceinline__ void q8_mc(qs_f4& acc, const qs_bf8& wa, const qs_bf8
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(wa), "v"(bb), "v"(c) : "memory");
 }
 
-template <int VARIANT>  // (a template so that the header can be included where only its constants are needed)
-__global__ __launch_bounds__(Q8_THREADS, 1) void cheb_qstrip8_kernel(Q8Args a) {
+// VARIANT 0: six waves, the two `top` waves fetch x and L~; 1: eight waves -- two helper waves on SIMDs 2 and 3 (beside `middle`) do
+// the fetching, splitting and filing, which takes ~80 vector instructions a step off the SIMDs that carry two roles
+template <int VARIANT>
+__global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstrip8_kernel(Q8Args a) {
+  constexpr bool HELP = VARIANT == 1;
+  constexpr int NTHREADS = HELP ? 512 : Q8_THREADS;
   constexpr int K = Q8_K, D = Q8_D, RING = 11, CRING = 10;
   constexpr int ROWB = 2 * 4 * QS_FRAG;          // 8 KiB: one ring row of x ([hi | lo][tile] fragments of the 32 channels)
   constexpr int RINGB = RING * ROWB;             // 88 KiB
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(Q8_THREADS, 1) void cheb_qstrip8_kernel(Q8Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // waves 0, 1: top (quarters 0, 1); 2, 3: middle; 4, 5: bottom -- wave w runs on SIMD w & 3
+  // waves 0, 1: top (quarters 0, 1); 2, 3: middle; 4, 5: bottom; (6, 7: helpers) -- wave w runs on SIMD w & 3
   const int role = wave >> 1, oq = wave & 1;
   const int p = lane & 15, q4 = lane >> 4;
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(Q8_THREADS, 1) void cheb_qstrip8_kernel(Q8Args a) {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     return v;
   };
-  for (int i = tid; i < (LDS_FLAG + 64) / 16; i += Q8_THREADS) reinterpret_cast<qs_f4*>(smem)[i] = qs_f4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < (LDS_FLAG + 64) / 16; i += NTHREADS) reinterpret_cast<qs_f4*>(smem)[i] = qs_f4{0.f, 0.f, 0.f, 0.f};
 
   const int G = gridDim.x, ord = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   const int piece = ord / a.wg_per_piece, map0 = ord - piece * a.wg_per_piece;
@@ -292,9 +296,9 @@ __global__ __launch_bounds__(Q8_THREADS, 1) void cheb_qstrip8_kernel(Q8Args a) {
         auto cw_wait = [&](qs_f4 (&cv)[2], float (&cd)[2]) __attribute__((always_inline)) {
           asm volatile("" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cd[0]), "+v"(cd[1]) : : "memory");
         };
-        bases_x(ytop);
-        bases_c(ytop - 1);
-        {
+        if (!HELP) {
+          bases_x(ytop);
+          bases_c(ytop - 1);
           qs_f4 cv[2], xv[4];
           float cd[2];
           fetch_c(ytop - 1, cv, cd);
@@ -304,9 +308,9 @@ __global__ __launch_bounds__(Q8_THREADS, 1) void cheb_qstrip8_kernel(Q8Args a) {
           cstore(CRING - 1, oq + 2, cv[1], cd[1]);
           xw_wait(xv);
           xstore(0, xv);
+          bases_c(ytop);
+          bases_x(ytop + 1);
         }
-        bases_c(ytop);
-        bases_x(ytop + 1);
         step_barrier();
         auto step = [&](auto ph_c) __attribute__((always_inline)) {
           constexpr int PH = decltype(ph_c)::value;
@@ -317,10 +321,12 @@ __global__ __launch_bounds__(Q8_THREADS, 1) void cheb_qstrip8_kernel(Q8Args a) {
           auto cslot_ix = [&](int back) __attribute__((always_inline)) -> int { int s = cs_top - back; s += s < 0 ? CRING : 0; return s; };
           qs_f4 xv[4], cv[2];
           float cd[2];
-          if (tab_new_row(st, ytop + 1)) bases_x(ytop + 1);
-          if (tab_new_row(st, ytop)) bases_c(ytop);
-          fetch_x(ytop + 1, xv);
-          fetch_c(ytop, cv, cd);
+          if (!HELP) {
+            if (tab_new_row(st, ytop + 1)) bases_x(ytop + 1);
+            if (tab_new_row(st, ytop)) bases_c(ytop);
+            fetch_x(ytop + 1, xv);
+            fetch_c(ytop, cv, cd);
+          }
           const unsigned f0 = (unsigned)slot_top * ROWB + lane16, f1 = (unsigned)slot_ix(1) * ROWB + lane16, f2 = (unsigned)slot_ix(2) * ROWB + lane16;
           qs_bf8 fr[2][2][2];
           const QCoefLo c6 = clo_read(cslot_ix(1));  // row ytop-1: level 6
@@ -355,11 +361,13 @@ __global__ __launch_bounds__(Q8_THREADS, 1) void cheb_qstrip8_kernel(Q8Args a) {
             }
           }
           ++handed;
-          xw_wait(xv);
-          cw_wait(cv, cd);
-          cstore(cs_top, oq, cv[0], cd[0]);
-          cstore(cs_top, oq + 2, cv[1], cd[1]);
-          xstore(snew, xv);
+          if (!HELP) {
+            xw_wait(xv);
+            cw_wait(cv, cd);
+            cstore(cs_top, oq, cv[0], cd[0]);
+            cstore(cs_top, oq + 2, cv[1], cd[1]);
+            xstore(snew, xv);
+          }
           slot_top = snew;
           cs_top = cs_top + 1 == CRING ? 0 : cs_top + 1;
           ++ytop;
@@ -486,6 +494,80 @@ __global__ __launch_bounds__(Q8_THREADS, 1) void cheb_qstrip8_kernel(Q8Args a) {
           step(std::integral_constant<int, 0>{});
           step(std::integral_constant<int, 1>{});
           step(std::integral_constant<int, 2>{});
+        }
+      }
+    }
+  } else if (role == 3) {
+    // =================================================================================================================
+    // helpers (VARIANT 1): fetch, split and file the rows of x and L~ that `top` otherwise fetches -- nothing else.
+    // =================================================================================================================
+    for (int64_t tr = tape_begin; tr < tape_end;) {
+      QStrip st;
+      tr += locate(tr, tape_end, st);
+      for (int nq = map0; nq < a.N; nq += a.wg_per_piece) {
+        const int tc0 = max(st.xs, st.xlo) >> 4;
+        unsigned pkC[2], pkF[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int X = min(max(st.xs + 4 * p + oq + 2 * i, st.xlo), st.xhi);
+          pkC[i] = ((unsigned)((X >> 4) - tc0) << 8) | st_spread((unsigned)X & 15u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int X = min(max(st.xs + 4 * (((lane >> 1) & 7) + 8 * (i & 1)) + 2 * oq + (i >> 1), st.xlo), st.xhi);
+          pkF[i] = ((unsigned)((X >> 4) - tc0) << 8) | st_spread((unsigned)X & 15u);
+        }
+        const int T3 = ((st.y1 - st.y0) + Q8_RUNIN + 2) / 3;
+        const char* __restrict__ xmap = reinterpret_cast<const char*>(a.x) + (size_t)nq * a.x_rows * xrowb;
+        int ytop = st.y0 - D, slot_top = 0, cs_top = 0;
+        step_barrier();
+        unsigned bF[4], bC[2];
+        auto bases_x = [&](int yrow) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bF[i] = tab_lane(st, pkF[i] >> 8, yrow);
+        };
+        auto bases_c = [&](int yrow) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) bC[i] = tab_lane(st, pkC[i] >> 8, yrow);
+        };
+        auto fetch_x = [&](int yrow, qs_f4 (&xv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const qs_f4*>(xmap + ((size_t)row_in(st, bF[i], pkF[i] & 255u, yrow) * xrowb + x_goff));
+        };
+        auto fetch_c = [&](int yrow, qs_f4 (&cv)[2], float (&cd)[2]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) cfetch(row_in(st, bC[i], pkC[i] & 255u, yrow), cv[i], cd[i]);
+        };
+        bases_x(ytop);
+        bases_c(ytop - 1);
+        {
+          qs_f4 cv[2], xv[4];
+          float cd[2];
+          fetch_c(ytop - 1, cv, cd);
+          fetch_x(ytop, xv);
+          cstore(CRING - 1, oq, cv[0], cd[0]);
+          cstore(CRING - 1, oq + 2, cv[1], cd[1]);
+          xstore(0, xv);
+        }
+        bases_c(ytop);
+        bases_x(ytop + 1);
+        step_barrier();
+        for (int t = 0; t < 3 * T3; ++t) {
+          int snew = slot_top + 1;
+          snew = snew == RING ? 0 : snew;
+          qs_f4 xv[4], cv[2];
+          float cd[2];
+          if (tab_new_row(st, ytop + 1)) bases_x(ytop + 1);
+          if (tab_new_row(st, ytop)) bases_c(ytop);
+          fetch_x(ytop + 1, xv);
+          fetch_c(ytop, cv, cd);
+          cstore(cs_top, oq, cv[0], cd[0]);
+          cstore(cs_top, oq + 2, cv[1], cd[1]);
+          xstore(snew, xv);
+          slot_top = snew;
+          cs_top = cs_top + 1 == CRING ? 0 : cs_top + 1;
+          ++ytop;
+          step_barrier();
         }
       }
     }
