@@ -667,7 +667,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
 #pragma unroll
           for (int h = 0; h < 2; ++h) wr[l][kb][h] = *reinterpret_cast<const qs_bf8*>(wp + ((size_t)(l * 2 + kb) * 2 + h) * QS_FRAG);
     }
-    const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
+    const bool relu = a.act == DSPH_ACT_RELU;
     // (the f16 image carries its weights times a power of two, qstrip_wprep_kernel: the store takes it out again)
     const float ysc = (CHEB ? 0.5f : 1.f) * (F16 ? *reinterpret_cast<const float*>(a.wimg + 2 * 4 * 3 * 2 * 2 * QS_FRAG) * a.xsc_inv : 1.f);
 #ifdef DSPH_QS_LPRIO  // (tuning: the L waves are the younger ones of their SIMDs and lose the issue arbitration to their H partner)
@@ -754,6 +754,35 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         QS_FR0(f0)
         QCoefLo c0;
         QCoefHi c0h;
+#ifdef DSPH_QS_LBARE
+        // (tuning build: L's stencil units first and bare, its one chain of matrix instructions last -- away from H's first two chains)
+        if (CHEB && H1) {
+          c0 = clo_read(cslot_ix(5));
+          c0h = chi_read(cslot_ix(5));
+#pragma unroll
+          for (int qq = 0; qq < 3 * QS_UPR; ++qq) {
+            if (qq < QS_UPR) QS_UNIT<false, N1>(R[1][L2], R[0][L0], qq, QS_LO0(c1));
+            else if (qq < 2 * QS_UPR) QS_UNIT<false, N1>(R[1][L2], R[0][L1], qq - QS_UPR, QS_LO1(c1));
+            else QS_UNIT<false, N1>(R[1][L2], R[0][L2], qq - 2 * QS_UPR, QS_HI(c1h));
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Y.t[t] = R[0][L0].t[t] + R[0][L0].t[t];
+          qs_settle<1>(Y);
+#pragma unroll
+          for (int qq = 0; qq < 2 * QS_UPR; ++qq) {
+            if (qq < QS_UPR) QS_UNIT<false, false>(Y, R[1][L0], qq, QS_LO0(c0)); else QS_UNIT<false, false>(Y, R[1][L1], qq - QS_UPR, QS_LO1(c0));
+          }
+          qs_settle<1>(R[1][L2]);
+#pragma unroll
+          for (int qq = 0; qq < QS_UPR; ++qq) QS_UNIT<false, false>(Y, R[1][L2], qq, QS_HI(c0h));
+          qs_settle<1>(Y);
+          QS_STAMP(2);
+          QS_CHAIN(Y, false, 1, f0, 0, {}, {})
+          qs_settle<9>(Y);
+          QS_STAMP(3);
+        } else
+#endif
+        {
         if (CHEB) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) Y.t[t] = R[0][L0].t[t] + R[0][L0].t[t];
@@ -783,6 +812,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         // s2: Y += b1[new]: y of row ytop - K
 #pragma unroll
         for (int qq = 0; qq < QS_UPR; ++qq) QS_UNIT<false, false>(Y, R[1][L2], qq, QS_HI(c0h));
+        }
         QS_STAMP(4);
         if (!X_BY_H) xw_wait(xv);  // (here, in front of this step's y stores: the wait is for everything in flight)
         QS_STAMP(5);
@@ -799,7 +829,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
               for (int e = 0; e < 4; ++e) {
                 const float v = fmaf(Y.t[t][e], ysc, bv[e]);
                 // (f16: an input beyond the f16 range has become a NaN by now -- it must reach y, not be floored away by the ReLU)
-                o[e] = F16 ? (v < floor_v ? floor_v : v) : fmaxf(v, floor_v);
+                o[e] = !relu ? v : (F16 ? (v < 0.f ? 0.f : v) : fmaxf(v, 0.f));  // (`relu` is uniform: no maximum without one)
               }
               *reinterpret_cast<qs_f4*>(ymap + (size_t)(rowg + (unsigned)((t & 1) + 4 * (t >> 1))) * yrowb + (unsigned)(16 * oq + 4 * q4) * 4u) = o;
             }
