@@ -1492,7 +1492,9 @@ static bool strips_apply(const dsph_plan* plan, const FusedTiles& ft, int32_t Fi
 static bool q8_applies(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin, int32_t Fout, int32_t K, int32_t precision, int64_t N,
                        int32_t ld) {
   // (no limit on the size of a map: this kernel forms its addresses in 64 bits -- configs[3] is 6.4 GB of x)
-  if (ft.n_q8strips == 0 || !qstrip8_shape_ok(Fin, Fout, K) || precision != DSPH_PREC_BF16X3 || ld % 4 != 0 || N < 1) return false;
+  // (ld == Fout: the layer IS 32 columns wide -- the last 32 columns of a wider layer would find no room for this kernel's weight
+  // image in their block of the workspace, which is sized for 64-column blocks)
+  if (ft.n_q8strips == 0 || !qstrip8_shape_ok(Fin, Fout, K) || precision != DSPH_PREC_BF16X3 || ld != Fout || N < 1) return false;
   if (plan->opt.strips == 1) return true;
   const int64_t span = qstrip8_split(plan->fused->num_cu, ft.q8tape_rows, N, ft.q8tape_rows / std::max(1, ft.n_q8strips), nullptr, nullptr, nullptr);
   return span * 26 * 103 < ft.n_q8_tiles * N * 275 / plan->fused->num_cu * 100;

@@ -191,6 +191,22 @@ def test_k8_quad_strips_whole_map(nside, N, act):
     assert rel_err(ys[_native.STRIPS_ALWAYS].cpu().numpy(), ys[_native.STRIPS_NEVER].cpu().numpy()) < 2e-5
 
 
+def test_k8_layer_wider_than_the_strips_shape_stays_on_the_tile_kernel():
+    """K = 8, 32 -> 96: the last 32 columns of a wider layer have the strips' shape but no room for their weight image in a
+    workspace cut into 64-column blocks -- the whole layer runs on the tile kernel (and says so), correctly."""
+    K, Fin, Fout, nside, N = 8, 32, 96, 128, 1
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0]
+    rng = np.random.default_rng(96)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    plan = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
+    plan.prepare(K, Fin, Fout=Fout)
+    assert plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N) == 0
+    y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), None, K, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    assert rel_err(y.cpu().numpy(), orc.chebyshev_forward(_csr(cols, vals), x, W, K)) < 1e-5
+
+
 def test_headline_shape_on_the_reference_graph_as_benchmarked():
     """the headline shape (K 5, 64 -> 64, three-term split) on the graph a user of the reference's HealpyGCNN
     gets (healpy_networks.py:110-118: symmetrised 8 nearest neighbours, ELL width 11) at the size bench.py --config knn8h times it
