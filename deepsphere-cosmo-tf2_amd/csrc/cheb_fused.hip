@@ -741,7 +741,9 @@ static void build_qtstrips(std::vector<QCand>& cands, int32_t ntiles, int D, std
     for (int32_t i : mem) grid[(size_t)((cands[(size_t)i].v - v0) * GW + (cands[(size_t)i].u - u0))] = i;
     std::vector<int32_t> hgt((size_t)GW);
     std::vector<std::pair<int, int>> stack;  // (start column, height)
-    for (;;) {
+    // (every extraction sweeps the sheet once: a budget of sweeps bounds the set-up time on ragged masks -- what is not taken
+    // by then stays with the tile kernels)
+    for (int64_t sweeps = 0; sweeps * GW * GH < (3ll << 28) && sweeps < 8192; ++sweeps) {
       // the best (gain) rectangle of free cells: histogram of free runs along v, one sweep per row
       int64_t best = 0;
       int bu = 0, bv = 0, bw = 0, bh = 0;
