@@ -40,6 +40,10 @@ CONFIGS = {
     # configs[4] on ONE GPU (BASELINE quotes it on 8): partial sky, a spherical cap of 1/3 of the sphere padded to
     # nside-8 superpixels like utils.extend_indices, ragged tiles and border rows
     "c5": (1024, 5, 64, 64, 16),
+    # configs[4]'s cap padded the way a network pads it (utils.extend_indices to the nside of its coarsest layer: nside-32 superpixels,
+    # 32 x 32 pixels = 2 x 2 tiles each): no tile has its 4-ring region inside its superpixel -- until round 6 every tile of such a map
+    # was class T; the quad strips' rectangles on the logical tile grid take them
+    "c5s": (1024, 5, 64, 64, 16),
     # beyond BASELINE.json (side lines, never the headline): the order of the reference's tutorial layers
     # (examples/quick_start.ipynb:118-127, HealpyChebyshev(K=10, ...)) at configs[1]'s map and channel counts
     "k10": (256, 10, 16, 32, 8),
@@ -57,7 +61,7 @@ CONFIGS = {
     "qs": (256, 10, 5, 5, 16),
     "qs1": (256, 10, 1, 5, 16),  # its first layer: one input channel
 }
-MASKED = {"c5"}
+MASKED = {"c5": 8, "c5s": 32}  # config -> nside of the superpixels the mask is padded to
 KNN = {"knn8": 8, "knn20": 20, "qs": 20, "qs1": 20, "knn8h": 8}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
@@ -81,11 +85,11 @@ def build_laplacian(nside, device):
     return cols, vals, lmax
 
 
-def build_laplacian_masked(nside, device, fraction=1.0 / 3.0):
-    """Partial-sky version: NEST indices of a cap around (1, 0, 0), padded to nside-8 superpixels, sorted."""
+def build_laplacian_masked(nside, device, fraction=1.0 / 3.0, nside_super=8):
+    """Partial-sky version: NEST indices of a cap around (1, 0, 0), padded to nside-`nside_super` superpixels, sorted."""
     from deepsphere import _native, healpix, utils
 
-    idx = healpix.extend_indices(healpix.cap_indices(nside, fraction=fraction), nside, 8)
+    idx = healpix.extend_indices(healpix.cap_indices(nside, fraction=fraction), nside, nside_super)
     L = healpix.healpix_laplacian(nside, indices=idx, mode="grid")
     cols, vals64 = utils.csr_to_ell(L)
     plan_L = _native.LaplacianPlan(cols, vals64.astype(np.float32), device=device.index)
@@ -344,7 +348,7 @@ def main():
     if args.config in KNN:
         cols, vals, lmax = build_laplacian_knn(nside, device, KNN[args.config])
     else:
-        cols, vals, lmax = build_laplacian_masked(nside, device) if args.config in MASKED else build_laplacian(nside, device)
+        cols, vals, lmax = build_laplacian_masked(nside, device, nside_super=MASKED[args.config]) if args.config in MASKED else build_laplacian(nside, device)
     M, W_ell = cols.shape
     w_np = (np.random.default_rng(13).standard_normal((Fin * K, Fout)) / np.sqrt(Fin * (K + 0.5) / 2)).astype(np.float32)
 
@@ -514,7 +518,7 @@ def main():
                       + (f"; {err_note})" if err_note else ")")),
             "data": "synthetic",
             "config": {
-                "workload": f"nside={nside} {'partial sky (cap of 1/3 of the sphere, nside-8 superpixels)' if args.config in MASKED else 'full-sphere'}, K={K}, Fin={Fin}, Fout={Fout}, batch={N} ({args.config})",
+                "workload": f"nside={nside} {f'partial sky (cap of 1/3 of the sphere, nside-{MASKED[args.config]} superpixels)' if args.config in MASKED else 'full-sphere'}, K={K}, Fin={Fin}, Fout={Fout}, batch={N} ({args.config})",
                 "pixels": M,
                 "ell_width": W_ell,
                 "graph": (f"symmetrised {KNN[args.config]}-nearest-neighbour Gaussian-kernel graph on the HEALPix pixel centres" if args.config in KNN

@@ -207,6 +207,35 @@ def test_k8_layer_wider_than_the_strips_shape_stays_on_the_tile_kernel():
     assert rel_err(y.cpu().numpy(), orc.chebyshev_forward(_csr(cols, vals), x, W, K)) < 1e-5
 
 
+def test_finely_padded_mask_runs_on_the_strips():
+    """A survey mask padded the way a network pads it (utils.extend_indices to the nside of its coarsest layer -- nside-32 superpixels:
+    2 x 2 tiles each, no tile's 4-ring region inside its superpixel): until round 6 every tile of such a map was class T or G; the quad
+    strips' rectangles on the logical tile grid now take most of them (bench.py --config c5s: 21.6 -> 15.7 ms).  The patch oracle on
+    rows of the mask border, on the strips' seams (through dsph_plan_strip_rows: every one crosses superpixel borders) and at random."""
+    import bench
+    from test_gpu_round2 import _headline_check, _patch_reference, _strip_seam_rows, _tape_cut_rows
+
+    nside, N, Fin, Fout, K = 1024, 4, 64, 64, 5
+    cols, vals, _ = bench.build_laplacian_masked(nside, torch.device("cuda", 0), nside_super=32)
+    M = cols.shape[0]
+    plan, x, W, b, y, s = _headline_check(cols, vals, N, Fin, Fout, K, _native.PREC_BF16X3, seed=32)
+    n_struct, n_bfs = plan.tile_counts(K)
+    n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
+    assert n_strip > 0.9 * n_struct, f"{n_strip} of {n_struct} structured tiles on the strips"
+    pairs = plan.strip_pairs(K)
+    deg = (vals != 0).sum(axis=1)
+    border = np.nonzero(deg < 9)[0]
+    rng = np.random.default_rng(32)
+    seams = _strip_seam_rows(plan, K, pairs, stride=max(1, len(pairs) // 40))
+    cuts = _tape_cut_rows(plan, K, pairs, N)[0][::4]
+    centres = np.unique(np.concatenate([border[rng.integers(0, border.size, size=60)], rng.integers(0, M, size=60), seams[::2], cuts]))
+    centres = centres[centres < M]
+    ref = _patch_reference(cols, vals, x[:2], W, K, centres, bias=b, activation="relu")
+    err = float(np.abs(y[:2, torch.as_tensor(centres).cuda()].cpu().numpy() - ref).max() / s)
+    print(f"c5s: M {M}, tiles: {n_strip} strips on {len(pairs)} records, {n_struct - n_strip} structured, {n_bfs} class G; {centres.size} centres, err {err:.2e}")
+    assert err < 1e-5
+
+
 def test_headline_shape_on_the_reference_graph_as_benchmarked():
     """the headline shape (K 5, 64 -> 64, three-term split) on the graph a user of the reference's HealpyGCNN
     gets (healpy_networks.py:110-118: symmetrised 8 nearest neighbours, ELL width 11) at the size bench.py --config knn8h times it

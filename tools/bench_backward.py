@@ -20,7 +20,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 nside, K, Fin, Fout, N = bench.CONFIGS[cfg]
 dev = torch.device("cuda", 0)
-cols, vals, lmax = bench.build_laplacian_masked(nside, dev) if cfg in bench.MASKED else bench.build_laplacian(nside, dev)
+cols, vals, lmax = bench.build_laplacian_masked(nside, dev, nside_super=bench.MASKED[cfg]) if cfg in bench.MASKED else bench.build_laplacian(nside, dev)
 M = cols.shape[0]
 w_np = (np.random.default_rng(13).standard_normal((Fin * K, Fout)) / np.sqrt(Fin * (K + 0.5) / 2)).astype(np.float32)
 prec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"

@@ -22,7 +22,7 @@ dev = torch.device("cuda", 0)
 if cfg in bench.KNN:
     cols, vals, lmax = bench.build_laplacian_knn(nside, dev, bench.KNN[cfg])
 else:
-    cols, vals, lmax = bench.build_laplacian_masked(nside, dev) if cfg in bench.MASKED else bench.build_laplacian(nside, dev)
+    cols, vals, lmax = bench.build_laplacian_masked(nside, dev, nside_super=bench.MASKED[cfg]) if cfg in bench.MASKED else bench.build_laplacian(nside, dev)
 plan = _native.LaplacianPlan(cols, vals, device=0)
 M = cols.shape[0]
 x = torch.randn((N, M, Fin), device=dev)
