@@ -734,6 +734,14 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         if (!X_BY_H && tab_new_row(st, ytop + 1)) bXf = tab_lane(st, ciF, ytop + 1);
         if (ytop - K > st.y0 && tab_new_row(st, ytop - K)) bY = tab_lane(st, ciY, ytop - K);
         if (!X_BY_H) xfetch(xmap, row_in(st, bXf, mXf, ytop + 1), xv);
+#ifdef DSPH_QS_LEARLY
+        constexpr bool LE = CHEB && H1;  // (tuning: level 0's lower source rows first -- they need nothing H hands over)
+#else
+        constexpr bool LE = false;
+#endif
+        QCoefLo c0;
+        QCoefHi c0h;
+        if (LE) c0 = clo_read(cslot_ix(5));  // (requested before the hand-over rows: the first units then wait for these alone)
         // the rows H left at the end of the previous step: b2[new] -> R[0][L2] (the set that died then), b3 -> R[1][L2]
         if (!(QS_ABL & 2048)) {
           const unsigned char* hp = smem + hand;
@@ -749,11 +757,19 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         constexpr bool N1 = CHEB;  // level 1 enters with -2 L~, level 0 with +2 L~ into the doubled Y
         QS_STAMP(1);
         qs_bf8 fr[2][2][2];
+        if (LE) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Y.t[t] = R[0][L0].t[t] + R[0][L0].t[t];
+          qs_settle<1>(Y);
+#pragma unroll
+          for (int qq = 0; qq < 2 * QS_UPR; ++qq) {
+            if (qq < QS_UPR) QS_UNIT<false, false>(Y, R[1][L0], qq, QS_LO0(c0)); else QS_UNIT<false, false>(Y, R[1][L1], qq - QS_UPR, QS_LO1(c0));
+          }
+          qs_settle<1>(Y);
+        }
         const QCoefLo c1 = clo_read(cslot_ix(4));  // row ytop-4: level 1
         const QCoefHi c1h = chi_read(cslot_ix(4));
         QS_FR0(f0)
-        QCoefLo c0;
-        QCoefHi c0h;
 #ifdef DSPH_QS_LBARE
         // (tuning build: L's stencil units first and bare, its one chain of matrix instructions last -- away from H's first two chains)
         if (CHEB && H1) {
@@ -783,13 +799,13 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         } else
 #endif
         {
-        if (CHEB) {
+        if (CHEB && !LE) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) Y.t[t] = R[0][L0].t[t] + R[0][L0].t[t];
           qs_settle<1>(Y);
         }
         // s0: 2 z_0 (+ 2 b2[-1]) -> Y | b1[new] (= b3 row from H) -+= (b2[-1], b2[0], b2[+1])
-        QS_CHAIN(Y, !CHEB, 1, f0, 3 * QS_UPR, { c0 = clo_read(cslot_ix(5)); if (!H1) { QS_FR0(f1) } },
+        QS_CHAIN(Y, !CHEB, 1, f0, 3 * QS_UPR, { if (!LE) c0 = clo_read(cslot_ix(5)); else c0h = chi_read(cslot_ix(5)); if (!H1) { QS_FR0(f1) } },
                  { if (qq < QS_UPR) QS_UNIT<!CHEB, N1>(R[1][L2], R[0][L0], qq, QS_LO0(c1));
                    else if (qq < 2 * QS_UPR) QS_UNIT<false, N1>(R[1][L2], R[0][L1], qq - QS_UPR, QS_LO1(c1));
                    else QS_UNIT<false, N1>(R[1][L2], R[0][L2], qq - 2 * QS_UPR, QS_HI(c1h)); })
@@ -797,7 +813,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         qs_settle<1>(R[1][L2]);
         QS_STAMP(2);
         // s1: z_1 -> b1[new] | Y += (b1[-2], b1[-1])   (c0: row ytop-5, level 0)
-        if (H1) {  // (z_1 is in the row H handed over)
+        if (H1 && LE) {  // (the lower rows went first)
+        } else if (H1) {  // (z_1 is in the row H handed over)
           c0h = chi_read(cslot_ix(5));
 #pragma unroll
           for (int qq = 0; qq < 2 * QS_UPR; ++qq) {
