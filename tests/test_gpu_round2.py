@@ -295,7 +295,7 @@ def test_config4_full_size():
     # round 6: the tiles whose 7-ring region stays inside a base pixel run on the K = 8 quad strips (csrc/cheb_qstrip8_kernel.h):
     # centres on the strips' seams in x (every 48 columns), on their first and last rows, on tile-row seams of the tables
     n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
-    assert n_strip == 12 * (nside // 16 - 2) ** 2, "12 base pixels x (126 x 126) tiles on the strips, as bench.py --config c4 times it"
+    assert n_strip >= 12 * (nside // 16 - 2) ** 2, "12 base pixels x (126 x 126) tiles and translated border tiles on the strips, as bench.py --config c4 times it"
     pairs = plan.strip_pairs(K)
     seams = _strip_seam_rows(plan, K, pairs, stride=5)
     assert seams.size > 2000 and seams.max() < M

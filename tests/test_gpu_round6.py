@@ -176,7 +176,7 @@ def test_k8_quad_strips_whole_map(nside, N, act):
         n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
         nt = nside // 16
         if strips == _native.STRIPS_ALWAYS:
-            assert n_strip == 12 * (nt - 2) ** 2, "the tiles whose 7-ring region stays inside their base pixel"
+            assert 12 * (nt - 2) ** 2 <= n_strip <= 12 * nt * nt - 24, "the tiles whose 7-ring region stays inside their base pixel, and translated border tiles"
             rec = plan.strip_pairs(K)
             assert rec.shape[1] == 12 and np.all(rec[:, 2] <= 48) and np.all(rec[:, 0] - rec[:, 4] == 8), "48 output columns behind 8 of lead-in"
         else:

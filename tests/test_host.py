@@ -336,5 +336,6 @@ def test_plan_builders_under_sanitizers():
     m = re.search(r"grid nside 128: K 5 64->64: tile_counts rc 0 struct 744 bfs 24, fused_ok 1, strip tiles \[(\d+), ", r.stdout)
     assert m and 432 < int(m.group(1)) <= 744, r.stdout[-2000:]
     assert re.search(r"grid nside 128: \d+ strips, \d+ output pixels = %s tiles, tables verified against the graph" % m.group(1), r.stdout)
-    assert "grid nside 128 K 8: 24 strips, 110592 output pixels = 432 tiles, tables verified against the graph" in r.stdout
+    m8 = re.search(r"grid nside 128 K 8: \d+ strips, \d+ output pixels = (\d+) tiles, tables verified against the graph", r.stdout)
+    assert m8 and int(m8.group(1)) >= 432, "the K = 8 strips: the tiles regular to depth 7 and the translated border tiles"
     assert "cap nside 128 superpixels 8: " in r.stdout and "tables verified against the graph" in r.stdout.split("cap nside 128 superpixels 8: ")[1]

@@ -155,7 +155,7 @@ def main():
         look(h, 3, 1, 16, f"grid nside {nside}")
         if nside == 128:  # the K = 8, 32 -> 32 quad strips: rectangles of the tiles whose 7-ring region stays inside a base pixel
             _, _, st8 = look(h, 8, 32, 32, f"grid nside {nside}")
-            assert st8[0] == 12 * 36 and check_strip_tables(h, 8, cols, vals, f"grid nside {nside} K 8", D=7) == st8[0]
+            assert st8[0] >= 12 * 36 and check_strip_tables(h, 8, cols, vals, f"grid nside {nside} K 8", D=7) == st8[0]
         if nside == 64:
             look(h, 8, 32, 32, f"grid nside {nside}")          # 7-ring BFS tables
             look(h, 10, 16, 32, f"grid nside {nside}")         # the chain of passes
