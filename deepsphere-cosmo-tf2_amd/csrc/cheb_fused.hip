@@ -1496,7 +1496,7 @@ static bool q8_applies(const dsph_plan* plan, const FusedTiles& ft, int32_t Fin,
   // (no limit on the size of a map: this kernel forms its addresses in 64 bits -- configs[3] is 6.4 GB of x)
   // (ld == Fout: the layer IS 32 columns wide -- the last 32 columns of a wider layer would find no room for this kernel's weight
   // image in their block of the workspace, which is sized for 64-column blocks)
-  if (ft.n_q8strips == 0 || !qstrip8_shape_ok(Fin, Fout, K) || precision != DSPH_PREC_BF16X3 || ld != Fout || N < 1) return false;
+  if (ft.n_q8strips == 0 || !qstrip8_shape_ok(Fin, Fout, K) || (precision != DSPH_PREC_BF16X3 && precision != DSPH_PREC_F16X3) || ld != Fout || N < 1) return false;
   if (plan->opt.strips == 1) return true;
   const int64_t span = qstrip8_split(plan->fused->num_cu, ft.q8tape_rows, N, ft.q8tape_rows / std::max(1, ft.n_q8strips), nullptr, nullptr, nullptr);
   return span * 26 * 103 < ft.n_q8_tiles * N * 275 / plan->fused->num_cu * 100;
@@ -2134,7 +2134,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   // K = 8, 32 -> 32: the rectangles of depth-7 regular tiles on the quad strips, the rest of the tiles below
   const bool q8 = !planes_mode && part != 2 && pool == nullptr && only == 0 && Fin_w == Fin && beta_rest != 0.f &&
                   (act == DSPH_ACT_NONE || act == DSPH_ACT_RELU) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
-                  q8_applies(plan, ft, Fin, Fout, K, precision, N, ld);
+                  q8_applies(plan, ft, Fin, Fout, K, strip_precision, N, ld);
   if (q8) {
     QStrip8Launch q;
     q.x = x; q.w = w; q.bias = bias; q.y = y;
@@ -2143,6 +2143,8 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
     q.gvals8 = plan->fused->d_gvals8; q.gdiag = plan->fused->d_gdiag;
     q.x_rows = plan->n_cols; q.y_rows = plan->levels.empty() ? plan->n_rows : plan->levels[0]; q.N = N;
     q.nstrips = ft.n_q8strips; q.act = act; q.ld = ld; q.ld_w = ld; q.num_cu = plan->fused->num_cu;
+    q.f16 = f16;
+    q.f16_xexp = plan->opt.f16_xexp;
     q.prep_weights = fused_images_claim(plan, workspace, IMG_Q8);
     const int rc = launch_cheb_qstrip8(q, stream);
     if (rc != DSPH_OK) return rc;

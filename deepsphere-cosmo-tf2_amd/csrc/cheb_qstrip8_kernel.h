@@ -38,7 +38,7 @@ constexpr int Q8_D = 7;                        // halo columns / rows on either 
 constexpr int Q8_USE = 48;                     // output columns of a strip's 64: 8 columns of lead-in (a multiple of four), 48, 8 behind
 constexpr int Q8_THREADS = 384;                // six waves
 constexpr int Q8_RUNIN = 2 * Q8_D + 2;         // steps before the first output row of a run of rows (y leaves at lag K + 1)
-constexpr int Q8_WIMG = 3 * 2 * 3 * 2 * QS_FRAG;  // [role][quarter][level of the role][hi | lo] 1 KiB A fragments: 36 KiB
+constexpr int Q8_WIMG = 3 * 2 * 3 * 2 * QS_FRAG;  // [role][quarter][level of the role][hi | lo] 1 KiB A fragments: 36 KiB (+ 256 B: the f16 image's factor)
 
 struct Q8Args {
   const float* x;
@@ -53,6 +53,7 @@ struct Q8Args {
   int64_t x_rows, y_rows;
   int nstrips, N, ld, act;
   int pieces, wg_per_piece;
+  float xsc, xsc_inv;  // f16 arithmetic: x is split as x * xsc (a power of two), the store multiplies by xsc_inv
 };
 
 // acc = wa . bb + c  (the first product of a chain that starts from another row's registers)
@@ -62,7 +63,9 @@ __device__ __forceinline__ void q8_mc(qs_f4& acc, const qs_bf8& wa, const qs_bf8
 
 // VARIANT 0: six waves, the two `top` waves fetch x and L~; 1: eight waves -- two helper waves on SIMDs 2 and 3 (beside `middle`) do
 // the fetching, splitting and filing, which takes ~80 vector instructions a step off the SIMDs that carry two roles
-template <int VARIANT>
+// F16: the three-term split on f16 pairs (DSPH_PREC_F16X3: 11 + 11 mantissa bits of both operands, fp32-equivalent) -- x times the
+// caller's power of two (DSPH_OPT_F16_XEXP), the weights times the image's, both taken out again in the store; as cheb_qstrip_kernel.h
+template <int VARIANT, bool F16>
 __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstrip8_kernel(Q8Args a) {
   constexpr bool HELP = VARIANT == 1;
   constexpr int NTHREADS = HELP ? 512 : Q8_THREADS;
@@ -155,13 +158,22 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
       qs_u2 hi, lo;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float a0 = xv[i][2 * j], a1 = xv[i][2 * j + 1];
-        const bf16x2 h = __builtin_convertvector(f32x2{a0, a1}, bf16x2);
-        const unsigned hu = __builtin_bit_cast(unsigned, h);
-        const float h0 = __builtin_bit_cast(float, hu << 16), h1 = __builtin_bit_cast(float, hu & 0xffff0000u);
-        const bf16x2 l = __builtin_convertvector(f32x2{a0 - h0, a1 - h1}, bf16x2);
-        hi[j] = hu;
-        lo[j] = __builtin_bit_cast(unsigned, l);
+        const float a0 = F16 ? xv[i][2 * j] * a.xsc : xv[i][2 * j], a1 = F16 ? xv[i][2 * j + 1] * a.xsc : xv[i][2 * j + 1];
+        if (F16) {  // (a value beyond the f16 range becomes an infinity here and a NaN row in y: loud, not wrong)
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          const f16x2 h = __builtin_convertvector(f32x2{a0, a1}, f16x2);
+          const f32x2 hf = __builtin_convertvector(h, f32x2);
+          const f16x2 l = __builtin_convertvector(f32x2{a0 - hf[0], a1 - hf[1]}, f16x2);
+          hi[j] = __builtin_bit_cast(unsigned, h);
+          lo[j] = __builtin_bit_cast(unsigned, l);
+        } else {
+          const bf16x2 h = __builtin_convertvector(f32x2{a0, a1}, bf16x2);
+          const unsigned hu = __builtin_bit_cast(unsigned, h);
+          const float h0 = __builtin_bit_cast(float, hu << 16), h1 = __builtin_bit_cast(float, hu & 0xffff0000u);
+          const bf16x2 l = __builtin_convertvector(f32x2{a0 - h0, a1 - h1}, bf16x2);
+          hi[j] = hu;
+          lo[j] = __builtin_bit_cast(unsigned, l);
+        }
       }
       *reinterpret_cast<qs_u2*>(q) = hi;
       *reinterpret_cast<qs_u2*>(q + 4 * QS_FRAG) = lo;
@@ -222,9 +234,9 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
           const int tt = s * 2 + u;                                                                                       \
           const qs_bf8& wa_ = wr[WLEV][j == 1 ? 1 : 0];                                                                   \
           const qs_bf8& bb_ = fr[(BUFS) == 2 ? s : 0][u][j == 0 ? 1 : 0];                                                 \
-          if ((FIRST) == 1 && j == 0) qs_m0<false>((ROW).t[tt], wa_, bb_);                                                \
+          if ((FIRST) == 1 && j == 0) qs_m0<F16>((ROW).t[tt], wa_, bb_);                                                \
           else if ((FIRST) == 2 && j == 0) q8_mc((ROW).t[tt], wa_, bb_, (CROW).t[tt]);                                    \
-          else qs_m<false>((ROW).t[tt], wa_, bb_);                                                                        \
+          else qs_m<F16>((ROW).t[tt], wa_, bb_);                                                                        \
           _Pragma("unroll") for (int qq = (m * (NU)) / 9; qq < ((m + 1) * (NU)) / 9 && m < 9; ++qq) { __VA_ARGS__; }      \
         }                                                                                                                 \
       }                                                                                                                   \
@@ -583,7 +595,8 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
 #pragma unroll
         for (int h = 0; h < 2; ++h) wr[l][h] = *reinterpret_cast<const qs_bf8*>(wp + (size_t)(l * 2 + h) * QS_FRAG);
     }
-    const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
+    const bool relu = a.act == DSPH_ACT_RELU;
+    const float ysc = 0.5f * (F16 ? *reinterpret_cast<const float*>(a.wimg + Q8_WIMG) * a.xsc_inv : 1.f);
     qs_f4 bv = qs_f4{0.f, 0.f, 0.f, 0.f};
     if (a.bias != nullptr) bv = *reinterpret_cast<const qs_f4*>(a.bias + 16 * oq + 4 * q4);
     int taken = 0;
@@ -662,7 +675,10 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
               if (row_ok && c >= cfirst && c < clast) {
                 qs_f4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaf(Y.t[t][e], 0.5f, bv[e]), floor_v);
+                for (int e = 0; e < 4; ++e) {
+                  const float v = fmaf(Y.t[t][e], ysc, bv[e]);
+                  o[e] = !relu ? v : (F16 ? (v < 0.f ? 0.f : v) : fmaxf(v, 0.f));  // (f16: a NaN must reach y, not be floored away)
+                }
                 *reinterpret_cast<qs_f4*>(ymap + (size_t)(rowg + (unsigned)((t & 1) + 4 * (t >> 1))) * yrowb + (unsigned)(16 * oq + 4 * q4) * 4u) = o;
               }
             }

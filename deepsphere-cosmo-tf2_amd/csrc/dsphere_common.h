@@ -239,6 +239,8 @@ struct QStrip8Launch {
   const float* gvals8; const float* gdiag;
   int64_t x_rows, y_rows, N;
   int32_t nstrips, act, ld, ld_w, num_cu;
+  bool f16 = false;          // DSPH_PREC_F16X3
+  int f16_xexp = 0;
   bool prep_weights = true;
 };
 bool qstrip8_shape_ok(int32_t Fin, int32_t Fout, int32_t K);

@@ -53,8 +53,8 @@ extern "C" {
  * fp32 rounding.  A third of the matrix-pipe time of DSPH_PREC_FP32.  The structured-tile kernel implements it; every
  * other kernel (BFS tiles, unfused, weight gradient) runs DSPH_PREC_FP32 when asked for it. */
 #define DSPH_PREC_BF16X6 2
-/* fp32-equivalent at the three-term split's price, where the quad-strip kernel runs (csrc/cheb_qstrip_kernel.h: K = 5, 64 input
- * and 64 output channels per column block, the rectangles of a HEALPix map): both operands split hi + lo into f16 (11 + 11
+/* fp32-equivalent at the three-term split's price, where the quad-strip kernels run (csrc/cheb_qstrip_kernel.h: K = 5, 64 input
+ * and 64 output channels per column block; csrc/cheb_qstrip8_kernel.h: K = 8, 32 -> 32; the rectangles of a HEALPix map): both operands split hi + lo into f16 (11 + 11
  * mantissa bits), hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16, fp32 accumulate: what is dropped is 2^-22 of a product.
  * The weights go in times a power of two of the library's choosing (taken out again in the store); x goes in times 2^e, e =
  * DSPH_OPT_F16_XEXP of the plan (default 0), taken out again in the store as well.  The RANGE CONDITION is the caller's to meet:

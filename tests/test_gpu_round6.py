@@ -189,6 +189,15 @@ def test_k8_quad_strips_whole_map(nside, N, act):
         assert err < 1e-5
         ys[strips] = y
     assert rel_err(ys[_native.STRIPS_ALWAYS].cpu().numpy(), ys[_native.STRIPS_NEVER].cpu().numpy()) < 2e-5
+    # the fp32-equivalent f16 three-term split on the same strips (x times 2^11: max |x| ~ 5 lands in [2^13, 2^14))
+    plan = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_STRIPS: _native.STRIPS_ALWAYS, _native.OPT_F16_XEXP: 11})
+    plan.prepare(K, Fin, Fout=Fout)
+    assert plan.strip_tiles(Fin, Fout, K, _native.PREC_F16X3, N=N) > 0
+    kw["precision"] = _native.PREC_F16X3
+    y16, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, **kw)
+    e16 = rel_err(y16.cpu().numpy(), ref)
+    print(f"K 8 f16x3 nside {nside} N {N}: rel err {e16:.2e}")
+    assert e16 < TOL_FP32_EQUIV
 
 
 def test_k8_layer_wider_than_the_strips_shape_stays_on_the_tile_kernel():
