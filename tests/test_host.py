@@ -339,3 +339,68 @@ def test_plan_builders_under_sanitizers():
     m8 = re.search(r"grid nside 128 K 8: \d+ strips, \d+ output pixels = (\d+) tiles, tables verified against the graph", r.stdout)
     assert m8 and int(m8.group(1)) >= 432, "the K = 8 strips: the tiles regular to depth 7 and the translated border tiles"
     assert "cap nside 128 superpixels 8: " in r.stdout and "tables verified against the graph" in r.stdout.split("cap nside 128 superpixels 8: ")[1]
+
+
+def test_folded_batch_norm_parameters_and_their_cache():
+    """Inference batch norm folded into the layer's parameters (gnn_layers.Chebyshev._folded_bn; reference order BN -> bias ->
+    activation, gnn_layers.py:152-159): kernel * s, bias - mean * s with s = 1 / sqrt(var + eps); rebuilt when the kernel, the bias or
+    the moving statistics move (a training-mode BN call moves num_batches_tracked, not running_mean._version), into the same tensors."""
+    import torch
+    from scipy import sparse
+
+    from deepsphere import gnn_layers
+
+    layer = gnn_layers.Chebyshev(L=sparse.identity(12, format="csr"), K=3, Fout=4, use_bn=True, use_bias=True, device="cpu")
+    layer.build((2, 12, 5))
+    with torch.no_grad():
+        layer.bn.running_mean.copy_(torch.tensor([0.5, -1.0, 0.0, 2.0]))
+        layer.bn.running_var.copy_(torch.tensor([4.0, 1.0, 0.25, 9.0]))
+    k, b, ver = layer._folded_bn()
+    s = 1.0 / np.sqrt(np.array([4.0, 1.0, 0.25, 9.0]) + 1e-5)
+    assert np.allclose(k.numpy(), layer.kernel.detach().numpy() * s, rtol=1e-6)
+    assert np.allclose(b.numpy(), layer.bias.detach().numpy().reshape(-1) - np.array([0.5, -1.0, 0.0, 2.0]) * s, rtol=1e-6, atol=1e-7)
+    k2, b2, ver2 = layer._folded_bn()
+    assert k2 is k and b2 is b and ver2 == ver, "nothing moved: the cached tensors, the same fold counter"
+    with torch.no_grad():
+        layer.kernel.mul_(2.0)
+    k3, _, ver3 = layer._folded_bn()
+    assert k3 is k and ver3 != ver and np.allclose(k3.numpy(), layer.kernel.detach().numpy() * s, rtol=1e-6), "re-folded in place"
+    layer.bn.train()
+    layer.bn(torch.randn(3, 4, 7))  # a training-mode call updates the moving statistics natively
+    layer.bn.eval()
+    _, b4, ver4 = layer._folded_bn()
+    s4 = torch.rsqrt(layer.bn.running_var + layer.bn.eps)
+    assert ver4 != ver3 and torch.allclose(b4, layer.bias.detach().reshape(-1) - layer.bn.running_mean * s4, rtol=1e-6, atol=1e-7)
+
+
+def test_precision_rules_of_the_backward_and_the_f16_scale():
+    """dx of an "f16x3" layer runs the six-term bf16 split and its dW exact fp32; one threshold for the weight
+    gradient's three-term split; the power of two of the f16 input scale puts max|x| in [2^13, 2^14)."""
+    from deepsphere import _native, gnn_layers
+
+    assert gnn_layers.resolve_dx_precision("f16x3", 64, 5) == "bf16x6"
+    assert gnn_layers.resolve_dx_precision("auto", 64, 5) == "bf16x3" and gnn_layers.resolve_dx_precision("auto", 1, 5) == "bf16x6"
+    assert gnn_layers.resolve_wgrad_precision("f16x3", 10 ** 7) == "fp32" and gnn_layers.resolve_wgrad_precision("bf16x6", 10 ** 7) == "fp32"
+    n = gnn_layers.WGRAD_SPLIT_MIN_PIXELS
+    assert n == 4096 and gnn_layers.resolve_wgrad_precision("auto", n) == "bf16x3" and gnn_layers.resolve_wgrad_precision("auto", n - 1) == "fp32"
+
+    class _Plan:  # (records what the layer asks of dsph_plan_set_option)
+        def __init__(self):
+            self.calls = []
+
+        def set_option(self, opt, value):
+            self.calls.append((opt, value))
+
+    layer = gnn_layers.Chebyshev.from_prepared_ell(np.zeros((4, 1), np.int32), np.ones((4, 1), np.float32), 5, precision="f16x3", device="cpu")
+    for amax in (1e-3, 0.7, 5.4, 3.0e4):
+        plan = _Plan()
+        layer.x_absmax, layer._f16_xexp = amax, None
+        layer._set_f16_scale(plan, None)
+        (opt, e), = plan.calls
+        assert opt == _native.OPT_F16_XEXP and 2.0 ** 13 <= amax * 2.0 ** e < 2.0 ** 14, (amax, e)
+        layer._set_f16_scale(plan, None)
+        assert len(plan.calls) == 1, "the same exponent is not set twice"
+    layer.precision = "bf16x3"
+    plan = _Plan()
+    layer._set_f16_scale(plan, None)
+    assert plan.calls == []
