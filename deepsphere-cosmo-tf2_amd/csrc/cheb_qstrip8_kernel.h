@@ -244,6 +244,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
   }
 #define Q8_CHAIN(ROW, FIRST, CROW, WLEV, FADDR, NU, ...) Q8_CHAIN_B(2, ROW, FIRST, CROW, WLEV, FADDR, NU, __VA_ARGS__)
 #define Q8_CHAIN1(ROW, FIRST, CROW, WLEV, FADDR, NU, ...) Q8_CHAIN_B(1, ROW, FIRST, CROW, WLEV, FADDR, NU, __VA_ARGS__)
+#define Q8_CHAINM(ROW, FIRST, CROW, WLEV, FADDR, NU, ...) Q8_CHAIN_B((HELP ? 2 : 1), ROW, FIRST, CROW, WLEV, FADDR, NU, __VA_ARGS__)
 
   __syncthreads();
 
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
           ++taken;
           flag_set(flag_at(0), taken);  // (LDS operations of a wave complete in order: the reads above are done first)
           const unsigned f4 = (unsigned)slot_ix(4) * ROWB + lane16, f5 = (unsigned)slot_ix(5) * ROWB + lane16, f6 = (unsigned)slot_ix(6) * ROWB + lane16;
-          qs_bf8 fr[1][2][2];  // (one set of B fragments: 16 registers that the three windows need)
+          qs_bf8 fr[HELP ? 2 : 1][2][2];  // (six waves: one set of B fragments -- 16 registers that the three windows need; eight: two)
           // Rows of this step: B5 window = rows ytop-5, -4, -3 (R[0][L0..L2]); B4[new] = row ytop-4; B3[new] = row ytop-5;
           // B2[new] = row ytop-6.  A row takes its stencil units and its chain of matrix instructions in DIFFERENT slots
           // (the asm statements hide both from the hazard recogniser), and a slot's units use one row's coefficients (registers).
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
           {
             const QCoefLo c3 = clo_read(cslot_ix(5));  // row ytop-5: level 3
             // m0: z_4 -> B4[new] (onto the B6 row) | B3[new] -= (B4[-2], B4[-1])                  (level 3 enters with -2 L~)
-            Q8_CHAIN1(R[1][L2], 0, R[1][L2], 0, f4, 2 * QS_UPR,
+            Q8_CHAINM(R[1][L2], 0, R[1][L2], 0, f4, 2 * QS_UPR,
                      { if (qq < QS_UPR) QS_UNIT<false, true>(R[2][L2], R[1][L0], qq, Q8_LO0(c3)); else QS_UNIT<false, true>(R[2][L2], R[1][L1], qq - QS_UPR, Q8_LO1(c3)); })
           }
           qs_settle<9>(R[1][L2]);
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
             const QCoefLo c4 = clo_read(cslot_ix(4));  // row ytop-4: level 4
             const QCoefHi c4h = chi_read(cslot_ix(4));
             // m1: z_3 -> B3[new] | B4[new] += (B5[-1], B5[0], B5[+1])                             (level 4 enters with +2 L~)
-            Q8_CHAIN1(R[2][L2], 0, R[2][L2], 1, f5, 3 * QS_UPR,
+            Q8_CHAINM(R[2][L2], 0, R[2][L2], 1, f5, 3 * QS_UPR,
                      { if (qq < QS_UPR) QS_UNIT<false, false>(R[1][L2], R[0][L0], qq, Q8_LO0(c4));
                        else if (qq < 2 * QS_UPR) QS_UNIT<false, false>(R[1][L2], R[0][L1], qq - QS_UPR, Q8_LO1(c4));
                        else QS_UNIT<false, false>(R[1][L2], R[0][L2], qq - 2 * QS_UPR, Q8_HI(c4h)); })
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
           {
             const QCoefHi c3h = chi_read(cslot_ix(5));
             // m2: z_2 -> B2[new], in place on the dying B4 row | B3[new] -= B4[new] (its row y+1)
-            Q8_CHAIN1(R[1][L0], 0, R[1][L0], 2, f6, QS_UPR, { QS_UNIT<false, true>(R[2][L2], R[1][L2], qq, Q8_HI(c3h)); })
+            Q8_CHAINM(R[1][L0], 0, R[1][L0], 2, f6, QS_UPR, { QS_UNIT<false, true>(R[2][L2], R[1][L2], qq, Q8_HI(c3h)); })
           }
           qs_settle<9>(R[1][L0]);
           qs_settle<1>(R[2][L2]);
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
   }
 #undef Q8_CHAIN
 #undef Q8_CHAIN1
+#undef Q8_CHAINM
 #undef Q8_CHAIN_B
 #undef Q8_FR
 #undef Q8_LO0
