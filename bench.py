@@ -284,6 +284,8 @@ def main():
     ap.add_argument("--strip-form", default="quad", choices=["quad", "pairs"],
                     help="plan option DSPH_OPT_STRIP_FORM: quad strips (round 5) or the strip pairs of round 3")
     ap.add_argument("--tstep", default="on", choices=["on", "off"], help="plan option DSPH_OPT_TSTEP (wide graphs: tiled step)")
+    ap.add_argument("--struct", default="on", choices=["on", "off"],
+                    help="plan option DSPH_OPT_STRUCT (off: every tile on the breadth-first tile kernel)")
     ap.add_argument("--fork", default="on", choices=["on", "off"],
                     help="plan option DSPH_OPT_FORK (the BFS-tile launch beside the structured ones, on the plan's side stream)")
     ap.add_argument("--quick", action="store_true", help="the headline leg only: no side legs in the other arithmetics, no CPU baseline")
@@ -337,6 +339,8 @@ def main():
                     _native.OPT_STRIP_FORM: _native.STRIP_FORM_QUAD if args.strip_form == "quad" else _native.STRIP_FORM_PAIRS,
                     _native.OPT_TSTEP: 1 if args.tstep == "on" else 0,
                     _native.OPT_FORK: 1 if args.fork == "on" else 0}
+    if args.struct == "off":
+        plan_options[_native.OPT_STRUCT] = 0
     nside, K, Fin, Fout, N = CONFIGS[args.config]
     # what is timed is what a user of the layer gets: the layer's default arithmetic unless --precision says otherwise
     layer_default = args.precision is None

@@ -1159,7 +1159,8 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
       cands.push_back(c);
     }
     const size_t n_rc = cands.size();
-    for (size_t i = 0; i < t_interior.size(); ++i) {
+    const bool only_r = getenv("DSPH_QT_ONLY_R") != nullptr;  // (measurement knob: the strips of round 5's tile set)
+    for (size_t i = 0; i < t_interior.size() && !only_r; ++i) {
       QCand c{};
       c.tile = t_interior[i]; c.tix = (int32_t)i; c.taken = false;
       if (links_from_table(&trow_i[i * ST_CELLS], D, ntiles, c.nbr)) cands.push_back(c);

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
 #pragma unroll
         for (int h = 0; h < 2; ++h) wr[l][h] = *reinterpret_cast<const qs_bf8*>(wp + (size_t)(l * 2 + h) * QS_FRAG);
     }
-    const bool relu = a.act == DSPH_ACT_RELU;
+    const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
     const float ysc = 0.5f * (F16 ? *reinterpret_cast<const float*>(a.wimg + Q8_WIMG) * a.xsc_inv : 1.f);
     qs_f4 bv = qs_f4{0.f, 0.f, 0.f, 0.f};
     if (a.bias != nullptr) bv = *reinterpret_cast<const qs_f4*>(a.bias + 16 * oq + 4 * q4);
@@ -623,6 +623,8 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
         int ytop = st.y0 - D, slot_top = 0, cs_top = 0;
         step_barrier();
         unsigned bY = tab_lane(st, ciY, st.y0);
+        // (the stored row's Morton bits inside its tile, stepped with the row: cheb_qstrip_kernel.h, my_next)
+        unsigned myY = st_spread((unsigned)(ytop - (K + 1)) & 15u) << 1;
         step_barrier();
         auto step = [&](auto ph_c) __attribute__((always_inline)) {
           constexpr int PH = decltype(ph_c)::value;
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
           auto slot_ix = [&](int back) __attribute__((always_inline)) -> int { int s = slot_top - back; s += s < 0 ? RING : 0; return s; };
           auto cslot_ix = [&](int back) __attribute__((always_inline)) -> int { int s = cs_top - back; s += s < 0 ? CRING : 0; return s; };
           const int yr = ytop - (K + 1);
-          if (yr > st.y0 && tab_new_row(st, yr)) bY = tab_lane(st, ciY, yr);
+          if (myY == 0) bY = tab_lane(st, ciY, yr);
           // the rows `middle` left at the end of the previous step: B2[new] -> R[0][L2], the dying B3 row -> R[1][L2] (= B1[new] so far)
           {
             const unsigned char* hp = smem + hand_at(1);
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
           for (int qq = 0; qq < QS_UPR; ++qq) QS_UNIT<false, false>(Y, R[1][L2], qq, Q8_HI(c0h));
           {
             const bool row_ok = yr >= st.y0 && yr < st.y1;
-            const unsigned rowg = bY + (mXg | (st_spread((unsigned)max(yr, 0) & 15u) << 1));
+            const unsigned rowg = bY + (mXg | myY);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               const int c = 4 * p + t;
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   const float v = fmaf(Y.t[t][e], ysc, bv[e]);
-                  o[e] = !relu ? v : (F16 ? (v < 0.f ? 0.f : v) : fmaxf(v, 0.f));  // (f16: a NaN must reach y, not be floored away)
+                  o[e] = F16 ? (v < floor_v ? floor_v : v) : fmaxf(v, floor_v);  // (f16: a NaN must reach y, not be floored away)
                 }
                 *reinterpret_cast<qs_f4*>(ymap + (size_t)(rowg + (unsigned)((t & 1) + 4 * (t >> 1))) * yrowb + (unsigned)(16 * oq + 4 * q4) * 4u) = o;
               }
@@ -687,6 +689,7 @@ __global__ __launch_bounds__(VARIANT == 1 ? 512 : Q8_THREADS, 1) void cheb_qstri
           slot_top = snew;
           cs_top = cs_top + 1 == CRING ? 0 : cs_top + 1;
           ++ytop;
+          myY = ((myY | 0x55u) + 1u) & 0xaau;
           step_barrier();
         };
         for (int t3 = 0; t3 < T3; ++t3) {

@@ -348,9 +348,14 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
     asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(b), "=&s"(b4) : "s"(trow) : "memory");
     return (unsigned)(ci == 0 ? b[0] : ci == 1 ? b[1] : ci == 2 ? b[2] : ci == 3 ? b[3] : b4);
   };
-  auto tab_new_row = [&](const QStrip& st, int yrow) __attribute__((always_inline)) -> bool {  // does row yrow start a tile row of the table
-    return yrow > st.ylo && yrow <= st.yhi && (yrow & 15) == 0;
-  };
+  // A row's Morton bits inside its tile, spread(y & 15) << 1, are kept as wave-uniform state and stepped with the row:
+  // (m | 0x55) + 1 & 0xaa counts in the odd bits and wraps to zero where a row enters a new tile row -- the moment for the
+  // look-up (three scalar instructions per row and step; clamping y, spreading its bits and three range tests per row took
+  // fifty, and at ~ 4 cycles of a wave's issue each that was 2 % of the forward).  Rows need no clamp to the strip's halo:
+  // the table has a ring of one tile around the rectangle, the steps of a run stay inside it, and what lies beyond the halo
+  // feeds no output.
+  auto my_of = [&](int yrow) __attribute__((always_inline)) -> unsigned { return st_spread((unsigned)yrow & 15u) << 1; };
+  auto my_next = [&](unsigned m) __attribute__((always_inline)) -> unsigned { return ((m | 0x55u) + 1u) & 0xaau; };
   auto row_in = [&](const QStrip& st, unsigned base, unsigned mX, int yrow) __attribute__((always_inline)) -> unsigned {
     const int yc = min(max(yrow, st.ylo), st.yhi);
     return base + (mX | (st_spread((unsigned)yc & 15u) << 1));
@@ -558,6 +563,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       }
       // the lane's tile bases of the rows the steps ask for: x of row ytop + 1, L~ of row ytop
       unsigned bXf = tab_lane(st, ciF, ytop + 1), bXc = tab_lane(st, ciC, ytop);
+      unsigned myX = my_of(ytop + 1), myC = my_of(ytop);
       step_barrier();
       auto step = [&](auto ph_c) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_c)::value;
@@ -578,9 +584,9 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         QS_STAMP(0);
         qs_f4 xv[XN];
         constexpr bool XLATE = H1;  // (the row's registers are H1's weights' in the slots s0, s1: requested behind s1 instead)
-        if (tab_new_row(st, ytop + 1)) bXf = tab_lane(st, ciF, ytop + 1);
-        if (tab_new_row(st, ytop)) bXc = tab_lane(st, ciC, ytop);
-        if (!XLATE) xfetch(xmap, row_in(st, bXf, mXf, ytop + 1), xv);
+        if (myX == 0) bXf = tab_lane(st, ciF, ytop + 1);
+        if (myC == 0) bXc = tab_lane(st, ciC, ytop);
+        if (!XLATE) xfetch(xmap, bXf + (mXf | myX), xv);
         const unsigned f0 = (unsigned)slot_top * ROWB + lane16, f1 = (unsigned)slot_ix(1) * ROWB + lane16, f2 = (unsigned)slot_ix(2) * ROWB + lane16;
         const unsigned f3 = (unsigned)slot_ix(3) * ROWB + lane16;
         constexpr bool N3 = CHEB;  // level 3 enters with -2 L~ (Chebyshev), level 2 with +2 L~
@@ -602,11 +608,11 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
                  { if (qq < QS_UPR) QS_UNIT<!CHEB, false>(R[0][L0], R[1][L0], qq, QS_LO0(c2)); else QS_UNIT<false, false>(R[0][L0], R[1][L1], qq - QS_UPR, QS_LO1(c2)); })
         qs_settle<9>(R[1][L2]);
         qs_settle<1>(R[0][L0]);
-        if (XLATE) xfetch(xmap, row_in(st, bXf, mXf, ytop + 1), xv);  // (two thirds of a step ahead of its use: still more than the memory's latency)
+        if (XLATE) xfetch(xmap, bXf + (mXf | myX), xv);  // (two thirds of a step ahead of its use: still more than the memory's latency)
         QS_STAMP(2);
         // s2: z_2 -> b2[new] | b3[new] += b4[new]
         // (the row ytop of L~ is requested in the tail as well: its latency is H's to wait out, H reaches the barrier before L)
-        QS_CHAIN(R[0][L0], false, 2, f2, QS_UPR, { c2h = chi_read(cslot_ix(2)); cfetch(row_in(st, bXc, mXc, ytop), cv, cd); if (H1) { QS_FR0(f3) } },
+        QS_CHAIN(R[0][L0], false, 2, f2, QS_UPR, { c2h = chi_read(cslot_ix(2)); cfetch(bXc + (mXc | myC), cv, cd); if (H1) { QS_FR0(f3) } },
                  { QS_UNIT<false, N3>(R[1][L2], R[0][L2], qq, QS_HI(c3h)); })
         qs_settle<9>(R[0][L0]);
         qs_settle<1>(R[1][L2]);
@@ -641,6 +647,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         slot_top = snew;
         cs_top = cs_top + 1 == CRING ? 0 : cs_top + 1;
         ++ytop;
+        myX = my_next(myX);
+        myC = my_next(myC);
         step_barrier();
         QS_STAMP(8);
       };
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
 #pragma unroll
           for (int h = 0; h < 2; ++h) wr[l][kb][h] = *reinterpret_cast<const qs_bf8*>(wp + ((size_t)(l * 2 + kb) * 2 + h) * QS_FRAG);
     }
-    const bool relu = a.act == DSPH_ACT_RELU;
+    const float floor_v = a.act == DSPH_ACT_RELU ? 0.f : -__builtin_huge_valf();
     // (the f16 image carries its weights times a power of two, qstrip_wprep_kernel: the store takes it out again)
     const float ysc = (CHEB ? 0.5f : 1.f) * (F16 ? *reinterpret_cast<const float*>(a.wimg + 2 * 4 * 3 * 2 * 2 * QS_FRAG) * a.xsc_inv : 1.f);
 #ifdef DSPH_QS_LPRIO  // (tuning: the L waves are the younger ones of their SIMDs and lose the issue arbitration to their H partner)
@@ -712,6 +720,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
       }
       // the lane's tile bases: x of row ytop + 1 (when all eight waves fetch x), y of row ytop - K
       unsigned bXf = X_BY_H ? 0u : tab_lane(st, ciF, ytop + 1), bY = tab_lane(st, ciY, st.y0);
+      unsigned myX = my_of(ytop + 1), myY = my_of(ytop - K);
       step_barrier();
       auto step = [&](auto ph_c) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_c)::value;
@@ -731,9 +740,11 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         QS_STAMP_DECL
         QS_STAMP(0);
         qs_f4 xv[XN];
-        if (!X_BY_H && tab_new_row(st, ytop + 1)) bXf = tab_lane(st, ciF, ytop + 1);
-        if (ytop - K > st.y0 && tab_new_row(st, ytop - K)) bY = tab_lane(st, ciY, ytop - K);
-        if (!X_BY_H) xfetch(xmap, row_in(st, bXf, mXf, ytop + 1), xv);
+        if (!X_BY_H && myX == 0) bXf = tab_lane(st, ciF, ytop + 1);
+        // (a row under the run's first one looks its tile row up too: the base is the right one by the time a row is stored --
+        // the look-up of the last multiple of sixteen up to y0, or the one made before the steps)
+        if (myY == 0) bY = tab_lane(st, ciY, ytop - K);
+        if (!X_BY_H) xfetch(xmap, bXf + (mXf | myX), xv);
 #ifdef DSPH_QS_LEARLY
         constexpr bool LE = CHEB && H1;  // (tuning: level 0's lower source rows first -- they need nothing H hands over)
 #else
@@ -836,7 +847,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         {
           const int yr = ytop - K;
           const bool row_ok = yr >= st.y0 && yr < ((QS_ABL & 16) ? st.y0 + 1 : st.y1);
-          const unsigned rowg = bY + (mXg | (st_spread((unsigned)max(yr, 0) & 15u) << 1));
+          const unsigned rowg = bY + (mXg | myY);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int c = 4 * p + t;
@@ -846,7 +857,7 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
               for (int e = 0; e < 4; ++e) {
                 const float v = fmaf(Y.t[t][e], ysc, bv[e]);
                 // (f16: an input beyond the f16 range has become a NaN by now -- it must reach y, not be floored away by the ReLU)
-                o[e] = !relu ? v : (F16 ? (v < 0.f ? 0.f : v) : fmaxf(v, 0.f));  // (`relu` is uniform: no maximum without one)
+                o[e] = F16 ? (v < floor_v ? floor_v : v) : fmaxf(v, floor_v);
               }
               *reinterpret_cast<qs_f4*>(ymap + (size_t)(rowg + (unsigned)((t & 1) + 4 * (t >> 1))) * yrowb + (unsigned)(16 * oq + 4 * q4) * 4u) = o;
             }
@@ -858,6 +869,8 @@ __global__ __launch_bounds__(QS_THREADS, 2) void cheb_qstrip5_kernel(QStripArgs 
         slot_top = snew;
         cs_top = cs_top + 1 == CRING ? 0 : cs_top + 1;
         ++ytop;
+        myX = my_next(myX);
+        myY = my_next(myY);
         step_barrier();
         QS_STAMP(8);
       };
