@@ -1159,7 +1159,11 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
       cands.push_back(c);
     }
     const size_t n_rc = cands.size();
-    const bool only_r = getenv("DSPH_QT_ONLY_R") != nullptr;  // (measurement knob: the strips of round 5's tile set)
+#ifdef DSPH_ABLATE  // (diagnostic build only -- make ABLATE=1: the shipped library reads no environment variable)
+    const bool only_r = getenv("DSPH_QT_ONLY_R") != nullptr;  // (the strips of round 5's tile set on this round's kernel: tools/ab_r5_r6.sh)
+#else
+    const bool only_r = false;
+#endif
     for (size_t i = 0; i < t_interior.size() && !only_r; ++i) {
       QCand c{};
       c.tile = t_interior[i]; c.tix = (int32_t)i; c.taken = false;

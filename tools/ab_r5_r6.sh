@@ -1,7 +1,8 @@
 #!/bin/bash
 # One box, one clock: the headline forward on round 5's tree (built by hand into build_ab/r5: `git archive <round-5 commit> |
 # tar -x -C build_ab/r5; make -C build_ab/r5/deepsphere-cosmo-tf2_amd/csrc`) and on this tree, alternating; and this tree with
-# the class-T tiles kept off the strips (DSPH_QT_ONLY_R: round 5's tile set on this round's kernel).
+# the class-T tiles kept off the strips (DSPH_QT_ONLY_R: round 5's tile set on this round's kernel; honoured by a
+# `make ABLATE=1` build of the library only -- the shipped one reads no environment variable, that leg then equals the second).
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/ab56; mkdir -p $O
 line() { python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel'])"; }
