@@ -647,6 +647,7 @@ struct QCand {
   int32_t tix;       // position in the class-T list (tables), -1 for a class-R tile
   int32_t sheet, u, v;
   bool taken;
+  bool barred;       // stays with the tile kernels whatever the rectangles would gain (a cell no rectangle may cover)
 };
 
 static bool links_from_table(const int32_t* row, int D, int32_t ntiles, int32_t nbr[8]) {
@@ -738,7 +739,7 @@ static void build_qtstrips(std::vector<QCand>& cands, int32_t ntiles, int D, std
     const int64_t GW = (int64_t)u1 - u0 + 1, GH = (int64_t)v1 - v0 + 1;
     if (GW * GH > (1ll << 26)) continue;  // (a sheet that sprawls: left to the tile kernels)
     std::vector<int32_t> grid((size_t)(GW * GH), -1);  // candidate index, -1 empty, -2 blocked
-    for (int32_t i : mem) grid[(size_t)((cands[(size_t)i].v - v0) * GW + (cands[(size_t)i].u - u0))] = i;
+    for (int32_t i : mem) grid[(size_t)((cands[(size_t)i].v - v0) * GW + (cands[(size_t)i].u - u0))] = cands[(size_t)i].barred ? -2 : i;
     std::vector<int32_t> hgt((size_t)GW);
     std::vector<std::pair<int, int>> stack;  // (start column, height)
     // (every extraction sweeps the sheet once: a budget of sweeps bounds the set-up time on ragged masks -- what is not taken
@@ -1159,6 +1160,17 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
       cands.push_back(c);
     }
     const size_t n_rc = cands.size();
+    // The kernel does not clamp a row to the strip's halo (cheb_qstrip_kernel.h, "rows need no clamp"): past the halo it reads
+    // rows of the table's ring tiles that feed nothing -- rows that must exist.  The one tile whose rows may not is the map's
+    // last, incomplete one: no tile beside it is a candidate, so it is in no rectangle's ring.
+    const int32_t ragged = out_rows % FUSED_P != 0 ? ntiles - 1 : -1;
+    auto beside_ragged = [&](const QCand& c) {
+      if (ragged < 0) return false;
+      if (c.tile == ragged) return true;
+      for (int d = 0; d < 8; ++d)
+        if (c.nbr[d] == ragged) return true;
+      return false;
+    };
 #ifdef DSPH_ABLATE  // (diagnostic build only -- make ABLATE=1: the shipped library reads no environment variable)
     const bool only_r = getenv("DSPH_QT_ONLY_R") != nullptr;  // (the strips of round 5's tile set on this round's kernel: tools/ab_r5_r6.sh)
 #else
@@ -1169,6 +1181,7 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
       c.tile = t_interior[i]; c.tix = (int32_t)i; c.taken = false;
       if (links_from_table(&trow_i[i * ST_CELLS], D, ntiles, c.nbr)) cands.push_back(c);
     }
+    for (QCand& c : cands) c.barred = beside_ragged(c);
     build_qtstrips(cands, ntiles, D, qstrips, qtab, &ft.n_qstrip_tiles);
     std::vector<unsigned char> t_taken(t_interior.size(), 0);
     for (size_t i = 0; i < cands.size(); ++i) {
@@ -1588,8 +1601,11 @@ int64_t fused_strip_rows(const dsph_plan* plan, int32_t K, int64_t strip, int64_
     const std::vector<int32_t>& htab = K == Q8_K ? ft.h_q8tab : ft.h_qtab;
     if (strip >= (int64_t)hq.size()) return -1;
     const QStrip& q = hq[(size_t)strip];
+    // (K = 5: the kernel steps a row's bits without clamping it to the halo -- a run of steps reads rows ylo - 1 .. yhi + 6 of
+    // the table's ring tiles, beyond the halo for nothing: they are answered as the kernel reads them)
+    const int ya = K == 5 ? q.ylo - 1 : q.ylo, yb = K == 5 ? q.yhi + 6 : q.yhi;
     for (int64_t i = 0; i < n; ++i) {
-      const int x = std::min(std::max(xy[2 * i], q.xlo), q.xhi), y = std::min(std::max(xy[2 * i + 1], q.ylo), q.yhi);
+      const int x = std::min(std::max(xy[2 * i], q.xlo), q.xhi), y = std::min(std::max(xy[2 * i + 1], ya), yb);
       rows[i] = (int64_t)htab[(size_t)(q.tab + (y >> 4) * q.tws + (x >> 4))] + (int64_t)st_morton((unsigned)x & 15u, (unsigned)y & 15u);
     }
     return n;

@@ -223,7 +223,8 @@ int dsph_plan_strip_split(const dsph_plan* plan, int64_t N, int32_t* grid, int32
  * a pure translation -- and a strip's record is in the coordinates of its rectangle's plane: the rectangle's first pixel is
  * (16, 16), one ring of tiles around it is addressable.  Which ROW of the map a pixel of that plane is, the strip's table says:
  * this call looks up n pixels xy[2 i], xy[2 i + 1] of record `strip` (clamped to the rectangle and its halo as the kernel clamps
- * them) into rows[i].  For the strip pairs (DSPH_OPT_STRIP_FORM 1) the plane is the virtual Z-order plane of the row index itself.) */
+ * them; K = 5: y to [ylo - 1, yhi + 6] -- that kernel reads a row as it comes, a run of steps touches these rows of the ring
+ * tiles, past the halo for nothing) into rows[i].  For the strip pairs (DSPH_OPT_STRIP_FORM 1) the plane is the virtual Z-order plane of the row index itself.) */
 int dsph_plan_strip_rows(const dsph_plan* plan, int32_t K, int64_t strip, int64_t n, const int32_t* xy, int64_t* rows);
 
 /* Bytes of scratch dsph_cheb_forward needs for this call shape (0 is possible). */

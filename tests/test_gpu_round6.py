@@ -245,6 +245,42 @@ def test_finely_padded_mask_runs_on_the_strips():
     assert err < 1e-5
 
 
+@pytest.mark.parametrize("drop", [100, 200, 256 + 37])
+def test_quad_strips_on_a_map_with_an_incomplete_last_tile(drop):
+    """The K = 5 quad-strip kernel reads a row as it comes (no clamp to the strip's halo: a run of steps touches a few rows of the
+    table's ring tiles past the halo, for nothing) -- so those rows must exist, and the plan keeps every tile beside the map's last,
+    incomplete tile off the strips (cheb_fused.hip, `barred`).  A sphere cut off `drop` pixels before its end: whole maps against
+    the float64 oracle, every row."""
+    nside, K, Fin, Fout, N = 128, 5, 64, 64, 2
+    cols, vals = _grid_ell(nside)
+    M = cols.shape[0] - drop
+    cols, vals = cols[:M].copy(), vals[:M].copy()
+    gone = cols >= M
+    vals[gone] = 0.0
+    cols[gone] = np.broadcast_to(np.arange(M, dtype=cols.dtype)[:, None], cols.shape)[gone]
+    rng = np.random.default_rng(drop)
+    x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+    W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+    b = rng.standard_normal(Fout).astype(np.float32)
+    ref = orc.chebyshev_forward(_csr(cols, vals), x, W, K, bias=b, activation="relu")
+    plan = _native.LaplacianPlan(cols, vals, device=0, options={_native.OPT_STRIPS: _native.STRIPS_ALWAYS})
+    plan.prepare(K, Fin, Fout=Fout)
+    n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
+    assert n_strip > 0
+    last = (M - 1) // 256  # the incomplete tile: no strip record's table may lead a pixel of its rectangle, halo or ring rows there ...
+    rec = plan.strip_pairs(K)
+    for s_ in range(rec.shape[0]):
+        r = rec[s_]
+        xs, ys = np.arange(int(r[8]), int(r[9]) + 1), np.arange(int(r[10]) - 1, int(r[11]) + 7)
+        X, Y = np.meshgrid(xs, ys, indexing="ij")
+        rows = plan.strip_rows(K, s_, X.ravel(), Y.ravel())
+        assert rows.min() >= 0 and rows.max() < M, "a row the kernel reads does not exist"
+    y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), _dev(b), K, act=_native.ACT_RELU, precision=_native.PREC_BF16X3, algo=_native.ALGO_FUSED)
+    err = rel_err(y.cpu().numpy(), ref)
+    print(f"sphere without its last {drop} pixels: {n_strip} strip tiles on {rec.shape[0]} records (last tile {last}), rel err {err:.2e}")
+    assert err < 1e-5
+
+
 def test_headline_shape_on_the_reference_graph_as_benchmarked():
     """the headline shape (K 5, 64 -> 64, three-term split) on the graph a user of the reference's HealpyGCNN
     gets (healpy_networks.py:110-118: symmetrised 8 nearest neighbours, ELL width 11) at the size bench.py --config knn8h times it

@@ -110,6 +110,13 @@ def check_strip_tables(h, K, cols, vals, name, D=4):
         assert ok.all(), f"{name}: strip {s}: a non-zero of L~ off the 3 x 3 window of the strip's plane"
         out = R[(x0 - (xa - 1)): (x0 - (xa - 1)) + w, (y0 - ylo): (y0 - ylo) + (y1 - y0)]
         np.add.at(seen, out.ravel(), 1)
+        if K == 5:  # the rows a run of steps reads past the halo (the kernel does not clamp y): they must exist
+            xs2, ys2 = np.arange(xlo, xhi + 1), np.concatenate([np.arange(ylo - 1, ylo), np.arange(yhi + 1, yhi + 7)])
+            X2, Y2 = np.meshgrid(xs2, ys2, indexing="ij")
+            xy2 = np.ascontiguousarray(np.stack([X2.ravel(), Y2.ravel()], 1), np.int32)
+            rows2 = np.zeros(xy2.shape[0], np.int64)
+            assert LIB.dsph_plan_strip_rows(h, K, s, xy2.shape[0], xy2.ctypes.data, rows2.ctypes.data) == 0
+            assert rows2.min() >= 0 and rows2.max() < cols.shape[0], f"{name}: strip {s}: a row past the halo does not exist ({rows2.max()} of {cols.shape[0]})"
     assert seen.max() <= 1, f"{name}: an output pixel in two strips"
     print(f"{name}: {len(rec)} strips, {int(seen.sum())} output pixels = {int(seen.sum()) // 256} tiles, tables verified against the graph", flush=True)
     return int(seen.sum()) // 256
@@ -190,6 +197,15 @@ def main():
             h = plan_of(lc, lv, n_cols=n_cols, levels=levels)
             look(h, K, 32, 32, f"shard rows [{lo}, {hi}) K {K}: {lc.shape[0]} rows, {n_cols} columns")
             LIB.dsph_plan_destroy(h)
+    # a map whose last tile is incomplete, with strips: no rectangle may have that tile in its ring (the kernel reads rows of the
+    # ring tiles past the halo)
+    M = 12 * 64 * 64
+    for drop in (100, 200, 256 + 37):
+        cols, vals = ell_of(healpix.healpix_laplacian(64, indices=np.arange(M - drop), mode="grid"))
+        h = plan_of(cols, vals, options={OPT_STRIPS: 1})
+        _, _, st = look(h, 5, 64, 64, f"grid nside 64 without its last {drop} pixels ({cols.shape[0]} rows)")
+        assert st[0] > 0 and check_strip_tables(h, 5, cols, vals, f"grid nside 64 without its last {drop} pixels") == st[0]
+        LIB.dsph_plan_destroy(h)
     # a ragged tail (rows not a multiple of 256) and a tiny graph
     cols, vals = ell_of(healpix.healpix_laplacian(8, mode="grid"))
     h = plan_of(cols[:700].clip(max=699), vals[:700])
