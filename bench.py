@@ -197,7 +197,7 @@ def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1, split="auto"):
     """Which kernels one fused forward launches: the strip kernel on the rectangles of plain structured tiles it takes for this
     shape (dsph_plan_strip_tiles), the structured-tile kernel on the other structured tiles, the BFS-tile kernel on the rest
     (dsph_plan_tile_counts)."""
-    if K > 5 and (split == "always" or (split == "auto" and K > 9)):
+    if K > 5 and (split == "always" or (split == "auto" and plan.uses_chain(Fin, Fout, K))):
         terms, k = [], K
         while k > 5:
             k -= 4
@@ -206,7 +206,7 @@ def fused_kernel_name(plan, K, Fin, Fout, prec_code, N=1, split="auto"):
         cz = (Fin + Fout + 3) // 4 * 4
         return (f"{len(terms)} passes of {' / '.join(str(t) for t in reversed(terms))} terms (T_(4+j) = 2 T_4 T_j - T_|4-j|) through [x | u] of "
                 f"{cz} channels; last pass: " + fused_kernel_name(plan, 5, cz, Fout, prec_code, N))
-    if K > 9:
+    if K > 10:
         return f"cheb_step_kernel x{K - 1} + cheb_contract_f32_kernel"
     n_struct, n_bfs = plan.tile_counts(K)
     n_strip = plan.strip_tiles(Fin, Fout, K, prec_code, N=N)
@@ -370,6 +370,9 @@ def main():
             with torch.no_grad():  # inference forward: bias/activation fused in the kernel epilogue
                 return layer(x)
         fused = layer._get_plan().fused_ok(Fin, Fout, K) and args.algo != "unfused"
+        if K > 9:  # (the layer's "auto" arithmetic follows the plan's route: one pass -- K = 10 on the grid -- or the chain of passes)
+            resolved = gnn_layers.resolve_precision(args.precision, Fin, K, layer._get_plan().uses_chain(Fin, Fout, K))
+            prec_code = gnn_layers._PRECISIONS[resolved]
         step_name = "cheb_tstep_kernel" if (12 < W_ell <= 32 and args.tstep == "on") else "cheb_step_kernel"
         kernel_name = fused_kernel_name(layer._get_plan(), K, Fin, Fout, prec_code, N, args.split) if fused else f"{step_name} x{K - 1} + cheb_contract_f32_kernel"
     else:

@@ -1347,7 +1347,8 @@ static int plane_rows_for(int rmax, int emax) {
   if (rmax <= 576 && emax <= 512) return 576;
   if (rmax <= 768 && emax <= 768) return 768;
   if (rmax <= 928 && emax <= 928) return 928;
-  return (rmax <= 1024 && emax <= 1024) ? 1024 : 0;
+  if (rmax <= 1024 && emax <= 1024) return 1024;
+  return (rmax <= 1168 && emax <= 1024) ? 1168 : 0;  // (K = 10 on the 8-neighbour grid: 34 x 34 rows, ELL rows on the inner 32 x 32)
 }
 
 // Layers the BFS-tile kernel runs with four maps per item (FusedArgs::pack): at most four input channels (padded to four),
@@ -2240,6 +2241,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
       DSPH_FUSED_CASE(768, 9)
       DSPH_FUSED_CASE(928, 9)
       DSPH_FUSED_CASE(1024, 9)
+      DSPH_FUSED_CASE(1168, 9)
       DSPH_FUSED_CASE(576, 12)
       DSPH_FUSED_CASE(768, 12)
       DSPH_FUSED_CASE(928, 12)
@@ -2294,6 +2296,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
   DSPH_FUSED_CASE(768, 9)
   DSPH_FUSED_CASE(928, 9)
   DSPH_FUSED_CASE(1024, 9)
+  DSPH_FUSED_CASE(1168, 9)
   DSPH_FUSED_CASE(576, 12)
   DSPH_FUSED_CASE(768, 12)
   DSPH_FUSED_CASE(928, 12)

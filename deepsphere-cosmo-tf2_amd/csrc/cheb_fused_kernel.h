@@ -11,7 +11,7 @@ namespace dsph {
 
 constexpr int FUSED_P = 256;        // rows per tile
 constexpr int FUSED_CH = 16;        // channels per slice
-constexpr int FUSED_DMAX = 8;       // deepest halo supported (K <= 9)
+constexpr int FUSED_DMAX = 9;       // deepest halo supported (K <= 10: the 9-ring region of a 16 x 16 tile is 34 x 34 = 1,156 rows, two planes of 1,168 fill the LDS)
 constexpr int FUSED_THREADS = 512;  // 8 waves, 2 per SIMD
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int FUSED_BIAS_BYTES = 256;  // the bias (<= 64 floats, zero-padded) sits in the last bytes of the LDS
@@ -572,6 +572,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void cheb_fused_kernel(FusedArgs 
           for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
       }
       DSPH_STAMP(5);
+      // (WG: a level's fragments come from global memory behind that level's x prefetch, and the memory counter is in order --
+      // the wait for them at the level's barrier is a trip to HBM at every level.  Requesting them a level ahead needs a second
+      // set of fragment registers: tried in round 6 on the 1,168-row variant, 24 -> 59 spilled registers and K = 10 slower, 2.26
+      // against 2.10 ms; 64 -> 64: 7.1 against 4.6)
       const unsigned char* __restrict__ wblk = (WG ? a.wfrag : sW) + (size_t)c * NB * 2048;
       WFrag<NB, PREC> wf;
       load_wfrag<NB, PREC>(wblk, lane, wf);
@@ -774,6 +778,7 @@ DSPH_FUSED_DECL(576, 9)
 DSPH_FUSED_DECL(768, 9)
 DSPH_FUSED_DECL(928, 9)
 DSPH_FUSED_DECL(1024, 9)
+DSPH_FUSED_DECL(1168, 9)
 DSPH_FUSED_DECL(576, 12)
 DSPH_FUSED_DECL(768, 12)
 DSPH_FUSED_DECL(928, 12)

@@ -234,6 +234,10 @@ int dsph_plan_fused_ok(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K)
   return (p && (fused_supported(p, Fin, Fout, K) || use_split(p, Fin, Fout, K, DSPH_ALGO_AUTO, DSPH_PART_ALL))) ? 1 : 0;
 }
 
+int dsph_plan_uses_chain(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K) {
+  return (p && Fin >= 1 && Fout >= 1 && use_split(p, Fin, Fout, K, DSPH_ALGO_AUTO, DSPH_PART_ALL)) ? 1 : 0;
+}
+
 int dsph_plan_tile_counts(const dsph_plan* p, int32_t K, int64_t* n_struct, int64_t* n_bfs) {
   if (!p || !n_struct || !n_bfs) { set_error("plan_tile_counts: NULL argument"); return DSPH_E_BADARG; }
   *n_struct = *n_bfs = 0;
@@ -253,6 +257,10 @@ int dsph_plan_strip_tiles(const dsph_plan* p, int64_t N, int32_t Fin, int32_t Fo
 static bool use_split(const dsph_plan* p, int32_t Fin, int32_t Fout, int32_t K, int32_t algo, int32_t part) {
   if (K <= 5 || algo == DSPH_ALGO_UNFUSED || part != DSPH_PART_ALL || p->opt.split_order == 2) return false;
   if (p->opt.split_order == 0 && K - 1 <= fused_dmax() && fused_weights_resident(p, Fin, Fout, K)) return false;
+  // K = 10 (round 6): one pass over 9-ring regions -- two planes of 1,168 rows fill the LDS, the weights are never resident --
+  // beats the chain of three passes at the layers' default arithmetic wherever it exists (tools/k10_routes.py: 16 -> 32 at
+  // nside 256 2.10 against 3.71 ms, 64 -> 64 4.64 / 8.00, 32 -> 32 at nside 512 4.03 / 4.90, 8 -> 8 at nside 128 0.38 / 0.58)
+  if (p->opt.split_order == 0 && K - 1 == fused_dmax() && fused_supported(p, Fin, Fout, K)) return false;
   return split_applicable(p, Fin, Fout, K);
 }
 

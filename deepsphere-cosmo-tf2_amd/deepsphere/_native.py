@@ -53,6 +53,7 @@ SIGNATURES = {
     "dsph_plan_ell_width": (_c_i32, [_c_vp]),
     "dsph_plan_out_rows": (_c_i64, [_c_vp, _c_i32]),
     "dsph_plan_fused_ok": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
+    "dsph_plan_uses_chain": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
     "dsph_plan_prepare": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32]),
     "dsph_plan_prepare_layer": (ctypes.c_int, [_c_vp, _c_i32, _c_i32, _c_i32, _c_i32]),
     "dsph_plan_tile_counts": (ctypes.c_int, [_c_vp, _c_i32, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
@@ -206,6 +207,10 @@ class LaplacianPlan:
 
     def fused_ok(self, Fin, Fout, K):
         return bool(lib().dsph_plan_fused_ok(self.handle, int(Fin), int(Fout), int(K)))
+
+    def uses_chain(self, Fin, Fout, K):
+        """``dsph_plan_uses_chain``: does a forward of this shape run as the chain of <= 5-term passes (K > 5)."""
+        return bool(lib().dsph_plan_uses_chain(self.handle, int(Fin), int(Fout), int(K)))
 
     def prepare(self, K, Fin, backward=False, release_host=False, Fout=None):
         """Build the fused kernels' tables for a K-term layer now (``dsph_plan_prepare_layer``; without ``Fout`` the width is

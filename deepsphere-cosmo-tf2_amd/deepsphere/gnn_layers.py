@@ -79,19 +79,22 @@ def _resolve_activation(activation):
 DEFAULT_PRECISION = "auto"
 
 
-def resolve_precision(precision, Fin, K=None):
+def resolve_precision(precision, Fin, K=None, chain=None):
     """The arithmetic a contraction over ``Fin`` input channels runs for ``precision`` ("auto" | "fp32" | "bf16x3" |
     "bf16x6").  "auto" is resolved PER CONTRACTION: the forward with the layer's Fin, the input gradient -- the forward of
     the transposed layer on dy -- with the layer's Fout (a 64 -> 1 layer runs its dx through the six-term split).  A layer
     with more than nine terms runs as a chain of passes (csrc/cheb_split.hip), each of which rounds its input to bf16
     hi + lo again under the three-term split (1.0e-5 measured at K = 10, three passes): "auto" gives those the
-    fp32-equivalent six-term split."""
+    fp32-equivalent six-term split.  ``chain``: whether the plan runs this shape as that chain (``LaplacianPlan.uses_chain``;
+    None = not known: every K > 9 is taken for one) -- K = 10 on the 8-neighbour grid is ONE pass over 9-ring regions since
+    round 6 and keeps the three-term split (3 - 5e-6 measured)."""
     if precision == "auto":
-        return "bf16x3" if (Fin >= 16 and (K is None or K <= 9)) else "bf16x6"
+        chained = (K is not None and K > 9) if chain is None else bool(chain)
+        return "bf16x3" if (Fin >= 16 and not chained) else "bf16x6"
     return precision
 
 
-def resolve_dx_precision(precision, Fout, K=None):
+def resolve_dx_precision(precision, Fout, K=None, chain=None):
     """The arithmetic of the input gradient -- the forward of the transposed layer on dy, a contraction over ``Fout`` channels.
     As ``resolve_precision`` except for "f16x3": the quad strips split their x operand (here dy) into f16 pairs as it is, and
     upstream gradients are routinely far below the f16 range (a mean loss over 12.6 M pixels gives dy ~ 1e-8, the smallest f16
@@ -99,7 +102,7 @@ def resolve_dx_precision(precision, Fout, K=None):
     "f16x3" runs its dx on the six-term bf16 split (same accuracy, the exponent range of fp32)."""
     if precision == "f16x3":
         return "bf16x6"
-    return resolve_precision(precision, Fout, K)
+    return resolve_precision(precision, Fout, K, chain)
 
 
 # the weight gradient takes the three-term split from this many pixels (N * M) on; the one statement of the rule -- DESIGN.md 4.1,
@@ -161,7 +164,7 @@ class _ChebConvFunction(torch.autograd.Function):
             kernel_t = kernel.detach().reshape(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()
             dx, layer._workspace_t = _native.cheb_forward(
                 plan_t, dy, kernel_t, None, K, act=_native.ACT_NONE,
-                precision=_PRECISIONS[resolve_dx_precision(layer.precision, Fout, K)],
+                precision=_PRECISIONS[resolve_dx_precision(layer.precision, Fout, K, plan_t.uses_chain(Fout, Fin, K) if K > 9 else None)],
                 algo=_ALGOS[layer.algo], workspace=layer._workspace_t, basis=layer._basis)
         if ctx.needs_input_grad[1]:
             plan = layer._get_plan()
@@ -330,7 +333,16 @@ class Chebyshev(torch.nn.Module):
 
     def _prec_code(self):
         """C-ABI code of the contraction arithmetic of this (built) layer: ``precision="auto"`` resolved with its Fin."""
-        return _PRECISIONS[resolve_precision(self.precision, self._Fin, self.K)]
+        return _PRECISIONS[resolve_precision(self.precision, self._Fin, self.K, self._chained())]
+
+    def _chained(self, transposed=False):
+        """Does the plan run this layer's forward (``transposed``: its input gradient, Fout -> Fin on the transposed plan) as the
+        chain of <= 5-term passes?  None below K = 10 (no plan is asked: resolve_precision's rule needs nothing there)."""
+        if self.K <= 9 or getattr(self, "_plan", None) is None:
+            return None
+        if transposed:
+            return self._get_plan(transposed=True).uses_chain(self.Fout, self._Fin, self.K)
+        return self._plan.uses_chain(self._Fin, self.Fout, self.K)
 
     # -- forward --------------------------------------------------------------------------------
     def forward(self, input_tensor, training=False):

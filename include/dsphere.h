@@ -187,6 +187,12 @@ int64_t dsph_plan_out_rows(const dsph_plan* plan, int32_t K); /* rows y is produ
 /* 1 if the fused kernels can run this (plan, shape) -- in one forward, or, for K > 5 where the plan's options allow it, as the
  * chain of <= 5-term passes; 0 otherwise (the unfused kernels then serve dsph_cheb_forward under DSPH_ALGO_AUTO) */
 int dsph_plan_fused_ok(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
+/* 1 if a forward of this (plan, shape) runs as the chain of <= 5-term passes (K > 5: the product identity, csrc/cheb_split.hip) --
+ * every pass of the chain rounds its input to bf16 hi + lo again under DSPH_PREC_BF16X3, so a caller that wants 1e-5 asks for the
+ * six-term split there; 0 if one pass of the fused kernels (K <= 10 on the 8-neighbour grid) or the unfused kernels serve it.
+ * (Round 6: K = 10 -- the reference tutorials' order -- runs in ONE pass of the breadth-first tile kernel over 9-ring regions
+ * where the plan's regions fit its 1,168-row planes, i.e. on the 8-neighbour grid stencil; on wider graphs it stays the chain.) */
+int dsph_plan_uses_chain(const dsph_plan* plan, int32_t Fin, int32_t Fout, int32_t K);
 
 /* How the fused forward with K terms splits the plan's 256-row tiles between its two kernels: *n_struct tiles whose
  * (K-1)-ring region was verified to be a square of a 2-D 9-point stencil (structured-tile kernel,

@@ -380,6 +380,11 @@ def test_precision_rules_of_the_backward_and_the_f16_scale():
 
     assert gnn_layers.resolve_dx_precision("f16x3", 64, 5) == "bf16x6"
     assert gnn_layers.resolve_dx_precision("auto", 64, 5) == "bf16x3" and gnn_layers.resolve_dx_precision("auto", 1, 5) == "bf16x6"
+    # K > 9: the three-term split only where the plan runs ONE pass (K = 10 on the grid: dsph_plan_uses_chain); a chain of passes
+    # re-rounds its input per pass and gets the six-term split; unknown route = taken for a chain
+    assert gnn_layers.resolve_precision("auto", 16, 10) == "bf16x6" and gnn_layers.resolve_precision("auto", 16, 10, chain=True) == "bf16x6"
+    assert gnn_layers.resolve_precision("auto", 16, 10, chain=False) == "bf16x3" and gnn_layers.resolve_precision("auto", 4, 10, chain=False) == "bf16x6"
+    assert gnn_layers.resolve_dx_precision("auto", 32, 10, chain=False) == "bf16x3" and gnn_layers.resolve_precision("auto", 16, 9) == "bf16x3"
     assert gnn_layers.resolve_wgrad_precision("f16x3", 10 ** 7) == "fp32" and gnn_layers.resolve_wgrad_precision("bf16x6", 10 ** 7) == "fp32"
     n = gnn_layers.WGRAD_SPLIT_MIN_PIXELS
     assert n == 4096 and gnn_layers.resolve_wgrad_precision("auto", n) == "bf16x3" and gnn_layers.resolve_wgrad_precision("auto", n - 1) == "fp32"

@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "measure6")
 PRO = os.path.join(ROOT, "profiles")
 KEYS = {"c3": "c3:bf16x3:fused:1", "c5": "c5:bf16x3:fused:1", "c4": "c4:bf16x3:fused:1", "c1": "c1:bf16x6:fused:1", "c2": "c2:bf16x3:fused:1",
-        "k10": "k10:bf16x6:fused:1", "in1": "in1:bf16x6:fused:1"}
+        "k10": "k10:bf16x6:fused:1", "in1": "in1:bf16x6:fused:1",
+        "k10b": "k10:bf16x3:fused:1"}  # (k10b: K = 10 in one pass of the breadth-first tile kernel, the default route since round 6's last build)
+ONLY = sys.argv[1:]  # tags to fold (default: all): `fold_round6.py k10b` adds one entry and leaves the others' build stamps alone
 FORWARD = ("cheb_qstrip5_kernel", "cheb_qstrip8_kernel", "cheb_strip5_kernel", "cheb_strip_kernel", "cheb_istrip_kernel", "cheb_istrip1_kernel", "cheb_struct_kernel",
            "cheb_fused_kernel", "fused_pad_kernel")
 # what the issue model of bench.py needs to know about the dominant kernel of a config (static: read off the kernel source)
@@ -28,14 +30,16 @@ except Exception:  # noqa: BLE001
     build = "unknown"
 build = "round-6 build, measured at commit " + build
 
-for name in os.listdir(SRC):
+for name in ([] if ONLY else os.listdir(SRC)):
     if name.startswith("bench_") and name.endswith(".json") and os.path.getsize(os.path.join(SRC, name)) > 10:
         shutil.copy(os.path.join(SRC, name), os.path.join(PRO, "r6_" + name))
     if name.startswith("kernel_stats_"):
         shutil.copy(os.path.join(SRC, name), os.path.join(PRO, "r6_fused_" + name.replace("kernel_stats_", "").replace(".csv", "") + "_kernel_stats.csv"))
-pmc = {}
+pmc = json.load(open(os.path.join(PRO, "r6_fused_pmc.json"))) if ONLY else {}
 traffic = json.load(open(os.path.join(PRO, "hbm_traffic.json")))
 for tag, key in KEYS.items():
+    if ONLY and tag not in ONLY:
+        continue
     p = os.path.join(SRC, "pmc_%s.json" % tag)
     if not os.path.exists(p):
         print("missing", p, file=sys.stderr)
@@ -48,7 +52,7 @@ for tag, key in KEYS.items():
         continue
     total = int(sum((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) for v in fwd.values()) * 1024)
     kernels = None
-    bl = os.path.join(SRC, "bench_%s.json" % tag)
+    bl = os.path.join(SRC, "bench_%s.json" % tag.replace("k10b", "k10"))
     if os.path.exists(bl) and os.path.getsize(bl) > 10:
         kernels = json.loads(open(bl).read().strip().split("\n")[-1])["roofline"]["kernel"]
     entry = {"FETCH_SIZE_KiB": {k: v["FETCH_SIZE"] for k, v in fwd.items()}, "WRITE_SIZE_KiB": {k: v["WRITE_SIZE"] for k, v in fwd.items()},
