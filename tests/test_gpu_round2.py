@@ -307,11 +307,11 @@ def test_config4_full_size():
     assert err < TOL
 
 
-@pytest.mark.parametrize("world,K,nside", [(4, 8, 64), (8, 5, 64)])
+@pytest.mark.parametrize("world,K,nside", [(4, 8, 64), (8, 5, 64), (2, 10, 64)])
 def test_sharded_plans_bigger(world, K, nside):
     """Every rank's local plan on this GPU, halo taken from the global map by indexing: stitched == unsharded bit for
     bit.  (4, 8): BASELINE configs[3]'s split (3 base pixels per rank, 7-ring halo); (8, 5): quarter base pixels, with
-    structured tiles inside the ranks' own rows."""
+    structured tiles inside the ranks' own rows; (2, 10): the tutorials' order in one pass over 9-ring regions (round 6)."""
     from deepsphere import sharding
 
     cols, vals = _grid_ell(nside)
