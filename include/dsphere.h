@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DSPH_ABI_VERSION 3  /* 3: DSPH_OPT_F16_XEXP, dsph_plan_strip_rows (round 6); 2: dsph_plan_prepare_layer; the entry points added
+#define DSPH_ABI_VERSION 3  /* 3: DSPH_OPT_F16_XEXP, dsph_plan_strip_rows, dsph_plan_uses_chain (round 6); 2: dsph_plan_prepare_layer; the entry points added
                               * since version 1 (set_option, forward_ex, forward_pool, healpix_pool, strip_pairs) are part of it */
 
 /* error codes */
