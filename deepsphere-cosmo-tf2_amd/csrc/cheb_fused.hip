@@ -365,11 +365,17 @@ static bool embed_tile(const dsph_plan* plan, const int32_t* cols, const float* 
           nc = m;
         }
       }
-    return nc == 1 ? cand[0] : -1;
+    return nc == 1 ? cand[0] : (nc > 1 ? -1 : -2);  // -1: ambiguous; -2: no row belongs here
   };
+  // A cell no row belongs to is a HOLE (round 6: the edge of a survey mask -- the pixel beyond it does not exist): it stays
+  // negative in A (never an anchor), its table entry is the tile's first row with nine zeros -- what a step computes there is
+  // finite and no row of the map has a non-zero towards it.  Nothing is taken on trust: the verification below still demands
+  // that every non-zero of every evaluated row lands on a placed cell at one of the eight offsets, so a row left out by
+  // mistake (or a vertex where three base pixels meet, whose far seam is not a 3 x 3 neighbourhood) fails the tile as before.
   auto place = [&](int x, int y) -> bool {
     const int32_t r = propose(x, y);
-    if (r < 0) return false;
+    if (r == -1) return false;
+    if (r == -2) { A[x][y] = -2; return true; }
     A[x][y] = r;
     hput(r, x + S * y);
     return true;
@@ -398,6 +404,7 @@ static bool embed_tile(const dsph_plan* plan, const int32_t* cols, const float* 
     for (int x = blo; x <= bhi; ++x) {
       const int32_t r = A[x][y];
       const unsigned p = st_cell_off((unsigned)x, (unsigned)y) / 64u;
+      if (r < 0) continue;  // a hole: the tile's first row, all zeros (set above)
       row[p] = r;
       if (r >= out_rows) *interior = false;
       if (x == blo || x == bhi || y == blo || y == bhi) continue;  // outermost ring: input only
@@ -1343,12 +1350,12 @@ static const FusedTiles& get_tiles(const dsph_plan* plan, int D, bool full = fal
 }
 
 // LDS planes are sized at compile time: 576 rows (a 16x16 tile with a 4-ring halo), 768 or 1024
-static int plane_rows_for(int rmax, int emax) {
+static int plane_rows_for(int rmax, int emax, int wt) {
   if (rmax <= 576 && emax <= 512) return 576;
   if (rmax <= 768 && emax <= 768) return 768;
   if (rmax <= 928 && emax <= 928) return 928;
   if (rmax <= 1024 && emax <= 1024) return 1024;
-  return (rmax <= 1168 && emax <= 1024) ? 1168 : 0;  // (K = 10 on the 8-neighbour grid: 34 x 34 rows, ELL rows on the inner 32 x 32)
+  return (rmax <= 1168 && emax <= 1024 && wt == 9) ? 1168 : 0;  // (K = 10 on the 8-neighbour grid: 34 x 34 rows, ELL rows on the inner 32 x 32; width 9 only)
 }
 
 // Layers the BFS-tile kernel runs with four maps per item (FusedArgs::pack): at most four input channels (padded to four),
@@ -1380,7 +1387,7 @@ static bool supported_impl(const dsph_plan* plan, int32_t Fin, int32_t Fout, int
   if (!ft.ok) return false;
   if (ft.n_r + ft.n_t > 0 && !struct_shape_ok(Fin, std::min(Fout, 64), K)) return false;
   if (ft.n_part == 0) return true;  // every tile is class R
-  const int pr = plane_rows_for(ft.rmax, ft.emax);
+  const int pr = plane_rows_for(ft.rmax, ft.emax, ft.width);
   if (pr == 0) return false;
   // (the weight fragments need not fit beside the planes: the forward then reads them from global memory, cheb_fused_kernel's
   // WG variant; the planes and weight-gradient modes hold no weights)
@@ -1421,7 +1428,7 @@ bool fused_weights_resident(const dsph_plan* plan, int32_t Fin, int32_t Fout, in
   const int32_t Fp = pad4(Fin);
   const FusedTiles& ft = get_tiles(plan, K - 1, want_full(plan, Fp, false));
   if (ft.n_part == 0) return true;
-  const int pr = plane_rows_for(ft.rmax, ft.emax);
+  const int pr = plane_rows_for(ft.rmax, ft.emax, ft.width);
   return (size_t)2 * pr * FUSED_CH * 4 + wfrag_bytes(Fp, std::min(Fout, 64), K) + FUSED_BIAS_BYTES <= (size_t)LDS_BYTES;
 }
 
@@ -1845,7 +1852,7 @@ static int fused_grid(const dsph_plan* plan, const FusedTiles& ft, int ntiles = 
 // slices per launch: as many accumulator tiles (one per slice and order, 8 KiB each) as fit the LDS next to the planes
 static int wgrad_slices_per_launch(const dsph_plan* plan, int32_t K) {
   const FusedTiles& ft = get_tiles(plan, K - 1, true);
-  const int pr = plane_rows_for(ft.rmax, ft.emax);
+  const int pr = plane_rows_for(ft.rmax, ft.emax, ft.width);
   if (pr == 0) return 0;
   const long freeb = (long)LDS_BYTES - 2L * pr * FUSED_CH * 4;
   return (int)(freeb / ((long)K * WG_TILE_BYTES));
@@ -2228,7 +2235,7 @@ static int launch_fused_common(const dsph_plan* plan, const float* x, const floa
 #else
   args.dbg = 0;
 #endif
-  const int pr = plane_rows_for(ft.rmax, ft.emax);
+  const int pr = plane_rows_for(ft.rmax, ft.emax, ft.width);
   const size_t lds = (size_t)2 * pr * FUSED_CH * 4 + wb;
   const int grid = (wgrad_mode && wg_ntiles < 0) ? fused_grid(plan, ft) : fused_grid(plan, ft, args.ntiles);
   if (wgrad_mode) {

@@ -281,6 +281,38 @@ def test_quad_strips_on_a_map_with_an_incomplete_last_tile(drop):
     assert err < 1e-5
 
 
+def test_k10_routes_by_graph():
+    """K = 10 (the reference tutorials' order): ONE pass of the breadth-first tile kernel over 9-ring regions on the 8-neighbour grid
+    (1,156 rows in planes of 1,168, instantiated for ELL width 9), the chain of <= 5-term passes on the reference's k-NN graph (width
+    11 -> 12: its regions have no 1,168-row variant -- a fuzz case found the planes mode asking for one); both against the float64
+    oracle, and the planes of the recurrence wherever the library offers them."""
+    import bench
+
+    K, Fin, Fout, N = 10, 16, 8, 2
+    dev = torch.device("cuda", 0)
+    for graph in ("grid", "knn"):
+        cols, vals = (_grid_ell(32) if graph == "grid" else bench.build_laplacian_knn(32, dev, 8)[:2])
+        M = cols.shape[0]
+        rng = np.random.default_rng(10 + len(graph))
+        x = rng.standard_normal((N, M, Fin)).astype(np.float32)
+        W = (rng.standard_normal((Fin * K, Fout)) * orc.default_kernel_stddev(Fin, K)).astype(np.float32)
+        plan = _native.LaplacianPlan(cols, vals, device=0)
+        assert plan.fused_ok(Fin, Fout, K)
+        assert plan.uses_chain(Fin, Fout, K) == (graph == "knn")
+        ref = orc.chebyshev_forward(_csr(cols, vals), x, W, K)
+        for prec, tol in ((_native.PREC_BF16X3, 1e-5 if graph == "grid" else 2e-5), (_native.PREC_BF16X6, TOL_FP32_EQUIV)):
+            y, _ = _native.cheb_forward(plan, _dev(x), _dev(W), None, K, precision=prec)
+            err = rel_err(y.cpu().numpy(), ref)
+            print(f"K 10 on the {graph} graph (ELL width {cols.shape[1]}), precision {prec}: rel err {err:.2e}")
+            assert err < tol
+        pu = _native.cheb_planes(plan, _dev(x), K, algo=_native.ALGO_UNFUSED)
+        try:
+            pf = _native.cheb_planes(plan, _dev(x), K, algo=_native.ALGO_FUSED)
+            assert all(torch.equal(a, b) for a, b in zip(pf, pu))
+        except RuntimeError as exc:  # refused loudly where the fused planes mode does not exist (the chain's graph)
+            assert graph == "knn" and "cannot run" in str(exc), str(exc)
+
+
 def test_headline_shape_on_the_reference_graph_as_benchmarked():
     """the headline shape (K 5, 64 -> 64, three-term split) on the graph a user of the reference's HealpyGCNN
     gets (healpy_networks.py:110-118: symmetrised 8 nearest neighbours, ELL width 11) at the size bench.py --config knn8h times it
