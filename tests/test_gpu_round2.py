@@ -274,6 +274,9 @@ def test_config5_partial_sky_as_benchmarked():
     err = np.abs(got - ref).max() / s
     print(f"config 5 as benchmarked: M = {M}, {border.size} border rows, tiles {plan.tile_counts(K)}, err {err:.2e}")
     assert err < TOL
+    # (round 6: the tiles on the mask's edge are class T -- a plane cell beyond the mask is a hole of the embedding -- and the
+    # breadth-first kernel keeps the few whose geometry is no plane: 30 of 18,048 at this mask; 428 before)
+    assert plan.tile_counts(K)[1] <= 64, "the mask's edge belongs on the structured kernel"
     # the cost rule at this size and batch (0.95 of the tile cost): the strips are taken, as bench.py --config c5 times it
     n_strip = plan.strip_tiles(Fin, Fout, K, _native.PREC_BF16X3, N=N)
     assert n_strip > 0, "C5 at batch 16 runs its rectangles on the strip kernel"
